@@ -1,0 +1,240 @@
+/*
+ * agimus_hip.h -- C ABI of the MI355X-native OCP solve path (libagimus_hip.so).
+ *
+ * This is the drop-in boundary for the one hot path of agimus_controller:
+ * OCPCrocoGeneric.solve() + warm-start shift + reference update.  Every entry
+ * point cites the reference interface it replaces (paths are relative to the
+ * upstream agimus_controller repository).  Plain pointers and sizes only: no
+ * C++ types, no torch types.  All floating point is IEEE fp64, row-major.
+ *
+ * The same structures are consumed by oracle/ (the CPU checker), which is test
+ * infrastructure and never part of the product path.
+ *
+ * Conventions
+ *   nv = nq = nu        number of 1-DoF revolute joints (full actuation)
+ *   nx = ndx = 2*nv     state x = [q; v]
+ *   T                   number of controls (running nodes); T+1 states
+ *   B                   batch: independent MPC instances resident on one GPU
+ *   spatial vectors     [linear(3); angular(3)] (Pinocchio ordering)
+ *   SE3 as 12 doubles   R row-major (9) then p (3)
+ *
+ * Status codes: 0 = ok, negative = error (message via agx_last_error()).
+ * Handles are thread-compatible, not thread-safe.
+ */
+#ifndef AGIMUS_HIP_H
+#define AGIMUS_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AGX_MAX_ROWS 8   /* cost rows per node type (running / terminal)        */
+#define AGX_MAX_NV 32    /* joints supported by the templated kernels            */
+
+/* Residual kinds: class names of the YAML schema,
+ * agimus_controller/agimus_controller/ocp/ocp_croco_generic.py:147-550.        */
+enum agx_residual_kind {
+  AGX_RES_STATE = 0,             /* ResidualModelState            :154 */
+  AGX_RES_CONTROL = 1,           /* ResidualModelControl          :170 */
+  AGX_RES_CONTROL_GRAV = 2,      /* ResidualModelControlGrav      :186 */
+  AGX_RES_FRAME_PLACEMENT = 3,   /* ResidualModelFramePlacement   :198 (+Static :223, VisualServoing :436) */
+  AGX_RES_FRAME_TRANSLATION = 4, /* ResidualModelFrameTranslation :252 (+Static :277) */
+  AGX_RES_FRAME_ROTATION = 5,    /* ResidualModelFrameRotation    :306 (+Static :331) */
+  AGX_RES_FRAME_VELOCITY = 6,    /* ResidualModelFrameVelocity    :360 (+Static :396) */
+  AGX_RES_COLLISION = 7          /* ResidualDistanceCollision     :524 */
+};
+
+/* Activation kinds, ocp_croco_generic.py:93-143.                               */
+enum agx_activation_kind {
+  AGX_ACT_WEIGHTED_QUAD = 0, /* a = 1/2 sum w_j r_j^2 (also the default quad, w = 1) */
+  AGX_ACT_EXP = 1,           /* colmpc ActivationModelExp(alpha)                    */
+  AGX_ACT_QUAD_EXP = 2       /* colmpc ActivationModelQuadExp(alpha)                */
+};
+
+/* One CostModelSumItem (ocp_croco_generic.py:578-585) lowered to a table row.
+ * Per-node data of the row lives in the reference tile (agx_ocp_set_refs):
+ *   [ item weight (1) | reference (agx_row_nref) | activation weights (agx_row_nr) ]
+ * rows are laid out back to back in table order.                               */
+typedef struct agx_cost_row {
+  int32_t kind;       /* agx_residual_kind                                      */
+  int32_t activation; /* agx_activation_kind                                    */
+  int32_t active;     /* CostModelSumItem.active                                */
+  int32_t frame;      /* default frame id (may be overridden per node)          */
+  double alpha;       /* Exp / QuadExp parameter                                */
+} agx_cost_row;
+
+/* Robot description: what factory/robot_model.py:88-351 extracts from the URDF
+ * (reduced model, armature :346-351), as a flat table.                         */
+typedef struct agx_model_desc {
+  int32_t nv;
+  int32_t nframes;
+  const int32_t *parent;         /* [nv]   parent joint, -1 = world            */
+  const double *placement;       /* [nv][12] joint frame in parent joint frame  */
+  const double *axis;            /* [nv][3]  unit revolute axis, joint frame    */
+  const double *mass;            /* [nv]                                        */
+  const double *com;             /* [nv][3]  joint frame                        */
+  const double *inertia;         /* [nv][9]  about com, joint frame             */
+  const double *armature;        /* [nv]                                        */
+  const double *effort_limit;    /* [nv]                                        */
+  const double *gravity;         /* [3]      linear gravity, world              */
+  const int32_t *frame_parent;   /* [nframes] parent joint, -1 = world          */
+  const double *frame_placement; /* [nframes][12] in parent joint frame         */
+} agx_model_desc;
+
+/* Shooting problem + solver knobs:
+ * OCPCrocoGeneric.create_running_model_list/create_terminal_model
+ * (ocp_croco_generic.py:798-812) and OCPBaseCroco.__init__
+ * (ocp_base_croco.py:55-80), OCPParamsBaseCroco (ocp_param_base.py:31-85).     */
+typedef struct agx_ocp_desc {
+  int32_t horizon;                  /* T = n_controls                           */
+  const double *dt;                 /* [T] timesteps; terminal node has dt = 0  */
+  int32_t n_running_rows;
+  const agx_cost_row *running_rows; /* [n_running_rows]                         */
+  int32_t n_terminal_rows;
+  const agx_cost_row *terminal_rows;
+  double termination_tolerance;     /* KKT tolerance, ocp_param_base.py:54      */
+  int32_t max_qp_iters;             /* ocp_param_base.py:53                     */
+  double eps_abs, eps_rel;          /* ocp_param_base.py:60-61                  */
+  double mu_dynamic, mu_constraint; /* merit penalties (mim_solvers defaults)   */
+  int32_t use_filter_line_search;   /* ocp_param_base.py:64                     */
+} agx_ocp_desc;
+
+/* Per-instance solver report: OCPDebugData fields filled by
+ * OCPBaseCroco.fill_debug_data (ocp_base_croco.py:134-140).                    */
+typedef struct agx_status {
+  double kkt;       /* solver.KKT                                               */
+  double cost;      /* total cost at the returned point's last evaluation       */
+  double merit;     /* merit at that evaluation                                 */
+  double gap_norm;  /* l1 norm of the dynamics gaps at that evaluation          */
+  int32_t iter;     /* solver.iter                                              */
+  int32_t qp_iters; /* solver.qp_iters                                          */
+  int32_t solved;   /* return value of solver.solve()                           */
+  int32_t flags;    /* bit0: non-finite result, bit1: line search failed        */
+} agx_status;
+
+/* Doubles per node in the derivative tile written by the node-parallel pass:
+ * Fx ndx^2 | Fu ndx*nu | f ndx | Lx ndx | Lu nu | Lxx ndx^2 | Lxu ndx*nu | Luu nu^2 | cost 1 */
+#define AGX_TILE_DOUBLES(nv) (4 * (nv) * (nv) + 2 * (nv) * (nv) + 2 * (nv) + 2 * (nv) + (nv) + 4 * (nv) * (nv) + 2 * (nv) * (nv) + (nv) * (nv) + 1)
+
+typedef struct agx_model agx_model;
+typedef struct agx_ocp agx_ocp;
+
+const char *agx_last_error(void);
+/* Number of visible HIP devices (0 when none); never throws.                   */
+int agx_device_count(void);
+
+/* Layout helpers shared by host code and kernels.                              */
+int agx_row_nref(int kind, int nv); /* reference doubles of a row               */
+int agx_row_nr(int kind, int nv);   /* residual dimension of a row              */
+/* doubles per node of the reference tile for this problem (max of running and
+ * terminal tables)                                                             */
+int agx_ref_stride(const agx_ocp_desc *desc, int nv);
+
+/* ---- model ------------------------------------------------------------- */
+int agx_model_create(const agx_model_desc *desc, agx_model **out);
+void agx_model_destroy(agx_model *m);
+
+/* ---- problem ----------------------------------------------------------- */
+/* Replaces OCPBaseCroco.__init__ (ocp_base_croco.py:17-80): allocates the
+ * device-resident horizon buffers for `batch` instances on HIP device `device`. */
+int agx_ocp_create(const agx_model *m, const agx_ocp_desc *desc, int batch, int device, agx_ocp **out);
+void agx_ocp_destroy(agx_ocp *ocp);
+/* Run the kernels on a caller-provided hipStream_t (0 = library-owned stream). */
+int agx_ocp_set_stream(agx_ocp *ocp, void *hip_stream);
+int agx_ocp_sync(agx_ocp *ocp);
+
+/* Replaces OCPCrocoGeneric.set_reference_weighted_trajectory
+ * (ocp_croco_generic.py:855-892): ref_tile [B][T+1][stride] host doubles,
+ * frame_ids [B][T+1][AGX_MAX_ROWS] host int32 (NULL = row defaults).            */
+int agx_ocp_set_refs(agx_ocp *ocp, const double *ref_tile, const int32_t *frame_ids);
+/* Same with device-resident tiles (no copy of the doubles is made when
+ * `adopt` != 0: the solver then reads the caller's buffer directly).            */
+int agx_ocp_set_refs_device(agx_ocp *ocp, const double *d_ref_tile, const int32_t *d_frame_ids, int adopt);
+
+/* Replaces OCPBaseCroco.solve (ocp_base_croco.py:142-182) for B instances.
+ * Host buffers: x0 [B][nx], xs_ws [B][T+1][nx], us_ws [B][T][nu];
+ * outputs xs [B][T+1][nx], us [B][T][nu], K [B][T][nu][ndx], st [B].
+ * max_iter <= 0 means 1000 (use_iteration_limits_and_timeout=False);
+ * max_time <= 0 means no wall-clock cap.                                       */
+int agx_ocp_solve(agx_ocp *ocp, const double *x0, const double *xs_ws, const double *us_ws,
+                  int max_iter, double max_time, double *xs, double *us, double *K, agx_status *st);
+
+/* Device-resident variant: the warm start is whatever currently sits in the
+ * resident xs/us buffers (after agx_ocp_upload_warmstart or
+ * agx_ocp_shift_warmstart); results stay on the device.                        */
+int agx_ocp_upload_x0(agx_ocp *ocp, const double *x0);
+int agx_ocp_upload_warmstart(agx_ocp *ocp, const double *xs_ws, const double *us_ws);
+int agx_ocp_solve_resident(agx_ocp *ocp, int max_iter, double max_time);
+int agx_ocp_download(agx_ocp *ocp, double *xs, double *us, double *K, agx_status *st);
+/* Only what the ROS node publishes (agimus_controller_ros/agimus_controller.py:418-426):
+ * us0 [B][nu], K0 [B][nu][ndx], x1 [B][nx] (may be NULL).                      */
+int agx_ocp_download_first(agx_ocp *ocp, double *us0, double *K0, double *x1, agx_status *st);
+
+/* Replaces WarmStartShiftPreviousSolution.shift
+ * (warm_start_shift_previous_solution.py:85-109) on the resident solution.     */
+int agx_ocp_shift_warmstart(agx_ocp *ocp);
+/* x0 <- xs[1] of the resident solution (closed loop on the own prediction, as
+ * agimus_controller_examples/scripts/dummy_mpc_test.py:127-129).               */
+int agx_ocp_x0_from_prediction(agx_ocp *ocp);
+
+/* Replaces OCPBaseCroco.integrate (ocp_base_croco.py:184-189): one Euler step
+ * of the node-0 model for n states. Host buffers x [n][nx], u [n][nu].         */
+int agx_ocp_integrate(agx_ocp *ocp, int n, const double *x, const double *u, double *xnext);
+
+/* Replaces pin.rnea at warm_start_reference.py:78 and
+ * trajectories/sine_wave_configuration_space.py:56 for n samples (host).       */
+int agx_model_rnea(agx_ocp *ocp, int n, const double *q, const double *v, const double *a, double *tau);
+/* Frame placement (pin.framesForwardKinematics,
+ * trajectories/trajectory_base.py:38-41): out [n][12].                         */
+int agx_model_frame_placement(agx_ocp *ocp, int n, int frame, const double *q, double *out);
+
+/* Replaces the per-node residual copies of OCPCrocoGeneric.fill_debug_data
+ * (ocp_croco_generic.py:840-853): residual of running row `row` at the resident
+ * solution, out [B][T][nr].                                                    */
+int agx_ocp_get_residuals(agx_ocp *ocp, int row, double *out);
+
+/* ---- kernel-level entry points (parity tests and bench instrumentation) - */
+/* Node-parallel derivative pass at the resident (xs, us): writes the tiles to
+ * the workspace and optionally copies them out, tiles [B][T+1][AGX_TILE_DOUBLES]. */
+int agx_ocp_calc_diff(agx_ocp *ocp, double *tiles);
+/* One QP direction (Riccati backward + linear forward + KKT) from the tiles in
+ * the workspace: K [B][T][nu][ndx], k [B][T][nu], dx [B][T+1][ndx], du [B][T][nu]. */
+int agx_ocp_direction(agx_ocp *ocp, double *K, double *k, double *dx, double *du, double *kkt);
+/* Upload tiles into the workspace (to test the Riccati kernel in isolation).   */
+int agx_ocp_upload_tiles(agx_ocp *ocp, const double *tiles);
+/* Average device time in milliseconds of `reps` launches of one kernel,
+ * measured with hipEvents on the problem's stream.
+ * which: 0 = derivative pass, 1 = direction (Riccati+forward), 2 = line search. */
+int agx_ocp_time_kernel(agx_ocp *ocp, int which, int reps, double *avg_ms);
+
+/* ---- device-resident reference trajectory --------------- */
+/* Sine wave in configuration space, trajectories/sine_wave_configuration_space.py:41-72,
+ * for B instances and n_points time samples t_k = t0[b] + k*dt, written as
+ * reference tiles [B][n_points][stride] directly in HBM for the goal-reaching
+ * row table (control | state | frame placement).  Host parameter arrays:
+ * q0 [B][nv], amp [B][nv], pulsation [B][nv], scale_duration [B][nv], t0 [B];
+ * weights w_q, w_qdot, w_effort [nv], w_pose [6].                              */
+int agx_traj_sine_create(agx_ocp *ocp, int n_points, double dt, const double *q0, const double *amp,
+                         const double *pulsation, const double *scale_duration, const double *t0,
+                         const double *w_q, const double *w_qdot, const double *w_effort,
+                         const double *w_pose, int frame);
+/* Point the solver at the horizon window starting at sample `k0` of the
+ * resident trajectory (TrajectoryBuffer.horizon, trajectory.py:218-222, with
+ * uniform horizon indexes).                                                    */
+int agx_traj_set_window(agx_ocp *ocp, int k0);
+/* Copy trajectory sample k of every instance to the host: q,v,a,u [B][nv], pose [B][12]. */
+int agx_traj_get_point(agx_ocp *ocp, int k, double *q, double *v, double *a, double *u, double *pose);
+/* Warm start from the reference (WarmStartReference.generate,
+ * warm_start_reference.py:33-96) on the device: xs <- [x0, ref[1:]], us <- ref efforts. */
+int agx_traj_warmstart_from_reference(agx_ocp *ocp);
+
+/* One receding-horizon step, MPC.run (mpc.py:32-66), fully device resident:
+ * window k0 -> shift warm start -> x0 from prediction (if k0 > first) -> solve.   */
+int agx_ocp_mpc_step(agx_ocp *ocp, int k0, int max_iter, int first);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AGIMUS_HIP_H */

@@ -1,0 +1,1061 @@
+// oracle/agx_oracle.cpp
+//
+// TEST INFRASTRUCTURE -- NOT PART OF THE PRODUCT PATH.
+// Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load
+// the library built from this file (oracle/liboracle.so).
+//
+// CPU fp64 restatement of the arithmetic behind agimus_controller's
+// OCPCrocoGeneric.solve() (agimus_controller/agimus_controller/ocp_base_croco.py:142-182),
+// which upstream delegates to Crocoddyl / Pinocchio / mim_solvers.  Those
+// libraries are NOT vendored in the reference and are not installed here, so
+// this file restates their published algorithms and is
+// pinned by the reference's own model-independent known answers
+// (tests/test_ocp_croco_generic.py:48-72,93-113, tests/test_mpc_unicycle.py:253-257,
+// tests/test_warm_start_shift_previous_reference.py:107-117) plus physical
+// identities and finite differences.  Parity against the Crocoddyl/mim_solvers
+// binaries themselves is UNPINNED (the only golden file,
+// tests/resources/simple_ocp_croco_results.pkl, needs example-robot-data's
+// Panda inertials, absent from this environment).
+//
+// Deliberately written differently from the HIP path so that agreement means
+// something: link-local Featherstone recursions and *forward-mode automatic
+// differentiation* (dual numbers) for every Jacobian, where the HIP kernels use
+// hand-derived world-frame analytical derivatives.
+//
+// Build: make -C oracle   (g++ -O2 -fopenmp -shared -fPIC)
+
+#include "../include/agimus_hip.h"
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+namespace {
+
+// ---------------------------------------------------------------------------
+// forward-mode dual numbers
+// ---------------------------------------------------------------------------
+template <int N>
+struct Dual {
+  double v;
+  double d[N];
+  Dual() : v(0.0) { for (int i = 0; i < N; ++i) d[i] = 0.0; }
+  Dual(double c) : v(c) { for (int i = 0; i < N; ++i) d[i] = 0.0; }
+};
+template <int N> inline Dual<N> operator+(const Dual<N> &a, const Dual<N> &b) { Dual<N> r; r.v = a.v + b.v; for (int i = 0; i < N; ++i) r.d[i] = a.d[i] + b.d[i]; return r; }
+template <int N> inline Dual<N> operator-(const Dual<N> &a, const Dual<N> &b) { Dual<N> r; r.v = a.v - b.v; for (int i = 0; i < N; ++i) r.d[i] = a.d[i] - b.d[i]; return r; }
+template <int N> inline Dual<N> operator-(const Dual<N> &a) { Dual<N> r; r.v = -a.v; for (int i = 0; i < N; ++i) r.d[i] = -a.d[i]; return r; }
+template <int N> inline Dual<N> operator*(const Dual<N> &a, const Dual<N> &b) { Dual<N> r; r.v = a.v * b.v; for (int i = 0; i < N; ++i) r.d[i] = a.d[i] * b.v + a.v * b.d[i]; return r; }
+template <int N> inline Dual<N> operator/(const Dual<N> &a, const Dual<N> &b) { Dual<N> r; double ib = 1.0 / b.v; r.v = a.v * ib; for (int i = 0; i < N; ++i) r.d[i] = (a.d[i] - r.v * b.d[i]) * ib; return r; }
+template <int N> inline Dual<N> operator+(const Dual<N> &a, double b) { Dual<N> r = a; r.v += b; return r; }
+template <int N> inline Dual<N> operator+(double b, const Dual<N> &a) { return a + b; }
+template <int N> inline Dual<N> operator-(const Dual<N> &a, double b) { Dual<N> r = a; r.v -= b; return r; }
+template <int N> inline Dual<N> operator-(double b, const Dual<N> &a) { Dual<N> r = -a; r.v += b; return r; }
+template <int N> inline Dual<N> operator*(const Dual<N> &a, double b) { Dual<N> r; r.v = a.v * b; for (int i = 0; i < N; ++i) r.d[i] = a.d[i] * b; return r; }
+template <int N> inline Dual<N> operator*(double b, const Dual<N> &a) { return a * b; }
+template <int N> inline Dual<N> operator/(const Dual<N> &a, double b) { return a * (1.0 / b); }
+template <int N> inline Dual<N> operator/(double a, const Dual<N> &b) { return Dual<N>(a) / b; }
+template <int N> inline Dual<N> &operator+=(Dual<N> &a, const Dual<N> &b) { a = a + b; return a; }
+template <int N> inline Dual<N> &operator-=(Dual<N> &a, const Dual<N> &b) { a = a - b; return a; }
+template <int N> inline Dual<N> chain(const Dual<N> &a, double f, double df) { Dual<N> r; r.v = f; for (int i = 0; i < N; ++i) r.d[i] = df * a.d[i]; return r; }
+template <int N> inline Dual<N> sqrt(const Dual<N> &a) { double s = std::sqrt(a.v); return chain(a, s, 0.5 / s); }
+template <int N> inline Dual<N> sin(const Dual<N> &a) { return chain(a, std::sin(a.v), std::cos(a.v)); }
+template <int N> inline Dual<N> cos(const Dual<N> &a) { return chain(a, std::cos(a.v), -std::sin(a.v)); }
+template <int N> inline Dual<N> exp(const Dual<N> &a) { double e = std::exp(a.v); return chain(a, e, e); }
+template <int N> inline Dual<N> atan2(const Dual<N> &y, const Dual<N> &x) {
+  double den = x.v * x.v + y.v * y.v;
+  Dual<N> r; r.v = std::atan2(y.v, x.v);
+  for (int i = 0; i < N; ++i) r.d[i] = (x.v * y.d[i] - y.v * x.d[i]) / den;
+  return r;
+}
+inline double val(double a) { return a; }
+template <int N> inline double val(const Dual<N> &a) { return a.v; }
+using std::atan2; using std::cos; using std::exp; using std::sin; using std::sqrt;
+
+// ---------------------------------------------------------------------------
+// model (host copy of agx_model_desc)
+// ---------------------------------------------------------------------------
+struct Model {
+  int nv = 0, nframes = 0;
+  std::vector<int> parent, frame_parent;
+  std::vector<double> placement, axis, mass, com, inertia, armature, effort_limit, frame_placement;
+  double gravity[3] = {0, 0, -9.81};
+};
+
+void copy_model(const agx_model_desc *d, Model &m) {
+  m.nv = d->nv; m.nframes = d->nframes;
+  m.parent.assign(d->parent, d->parent + d->nv);
+  m.placement.assign(d->placement, d->placement + 12 * d->nv);
+  m.axis.assign(d->axis, d->axis + 3 * d->nv);
+  m.mass.assign(d->mass, d->mass + d->nv);
+  m.com.assign(d->com, d->com + 3 * d->nv);
+  m.inertia.assign(d->inertia, d->inertia + 9 * d->nv);
+  m.armature.assign(d->armature, d->armature + d->nv);
+  if (d->effort_limit) m.effort_limit.assign(d->effort_limit, d->effort_limit + d->nv);
+  if (d->gravity) for (int i = 0; i < 3; ++i) m.gravity[i] = d->gravity[i];
+  if (d->nframes > 0) {
+    m.frame_parent.assign(d->frame_parent, d->frame_parent + d->nframes);
+    m.frame_placement.assign(d->frame_placement, d->frame_placement + 12 * d->nframes);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// small 3-vector helpers, generic in the scalar
+// ---------------------------------------------------------------------------
+template <class S> inline void cross(const S *a, const S *b, S *c) {
+  S c0 = a[1] * b[2] - a[2] * b[1];
+  S c1 = a[2] * b[0] - a[0] * b[2];
+  S c2 = a[0] * b[1] - a[1] * b[0];
+  c[0] = c0; c[1] = c1; c[2] = c2;
+}
+template <class S> inline void matvec3(const S *R, const S *x, S *y) {  // y = R x
+  S y0 = R[0] * x[0] + R[1] * x[1] + R[2] * x[2];
+  S y1 = R[3] * x[0] + R[4] * x[1] + R[5] * x[2];
+  S y2 = R[6] * x[0] + R[7] * x[1] + R[8] * x[2];
+  y[0] = y0; y[1] = y1; y[2] = y2;
+}
+template <class S> inline void matTvec3(const S *R, const S *x, S *y) {  // y = R^T x
+  S y0 = R[0] * x[0] + R[3] * x[1] + R[6] * x[2];
+  S y1 = R[1] * x[0] + R[4] * x[1] + R[7] * x[2];
+  S y2 = R[2] * x[0] + R[5] * x[1] + R[8] * x[2];
+  y[0] = y0; y[1] = y1; y[2] = y2;
+}
+template <class S> inline void matmul3(const S *A, const S *B, S *C) {  // C = A B
+  S t[9];
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) t[3 * i + j] = A[3 * i] * B[j] + A[3 * i + 1] * B[3 + j] + A[3 * i + 2] * B[6 + j];
+  for (int i = 0; i < 9; ++i) C[i] = t[i];
+}
+
+// Rotation of joint i: R = Rfix * Rodrigues(axis, q).  (liMi of Pinocchio.)
+template <class S> void joint_rotation(const Model &m, int i, const S &q, S *R) {
+  const double *ax = &m.axis[3 * i];
+  S c = cos(q), s = sin(q);
+  S omc = 1.0 - c;
+  S Rq[9];
+  Rq[0] = c + omc * (ax[0] * ax[0]);
+  Rq[1] = omc * (ax[0] * ax[1]) - s * ax[2];
+  Rq[2] = omc * (ax[0] * ax[2]) + s * ax[1];
+  Rq[3] = omc * (ax[1] * ax[0]) + s * ax[2];
+  Rq[4] = c + omc * (ax[1] * ax[1]);
+  Rq[5] = omc * (ax[1] * ax[2]) - s * ax[0];
+  Rq[6] = omc * (ax[2] * ax[0]) - s * ax[1];
+  Rq[7] = omc * (ax[2] * ax[1]) + s * ax[0];
+  Rq[8] = c + omc * (ax[2] * ax[2]);
+  S Rf[9];
+  for (int k = 0; k < 9; ++k) Rf[k] = S(m.placement[12 * i + k]);
+  matmul3(Rf, Rq, R);
+}
+
+// ---------------------------------------------------------------------------
+// RNEA in link-local coordinates (Featherstone, RBDA table 5.1), spatial
+// vectors ordered [linear; angular].  Restates pinocchio::rnea, the call at
+// warm_start_reference.py:78 and inside crocoddyl's free-forward dynamics.
+// ---------------------------------------------------------------------------
+template <class S>
+void rnea(const Model &m, const S *q, const S *v, const S *a, S *tau, bool with_gravity) {
+  const int n = m.nv;
+  std::vector<S> R(9 * n), vl(3 * n), vw(3 * n), al(3 * n), aw(3 * n), fl(3 * n), fw(3 * n);
+  for (int i = 0; i < n; ++i) {
+    S *Ri = &R[9 * i];
+    joint_rotation(m, i, q[i], Ri);
+    const double *p = &m.placement[12 * i + 9];
+    const double *ax = &m.axis[3 * i];
+    S pv[3] = {S(p[0]), S(p[1]), S(p[2])};
+    S pl[3], pw[3], pal[3], paw[3];  // parent velocity / acceleration
+    int par = m.parent[i];
+    if (par >= 0) {
+      for (int k = 0; k < 3; ++k) { pl[k] = vl[3 * par + k]; pw[k] = vw[3 * par + k]; pal[k] = al[3 * par + k]; paw[k] = aw[3 * par + k]; }
+    } else {
+      for (int k = 0; k < 3; ++k) { pl[k] = S(0.0); pw[k] = S(0.0); pal[k] = S(with_gravity ? -m.gravity[k] : 0.0); paw[k] = S(0.0); }
+    }
+    // actInv: lin' = R^T (lin - p x ang), ang' = R^T ang
+    S t[3], u[3];
+    cross(pv, pw, t);
+    for (int k = 0; k < 3; ++k) u[k] = pl[k] - t[k];
+    matTvec3(Ri, u, &vl[3 * i]);
+    matTvec3(Ri, pw, &vw[3 * i]);
+    cross(pv, paw, t);
+    for (int k = 0; k < 3; ++k) u[k] = pal[k] - t[k];
+    matTvec3(Ri, u, &al[3 * i]);
+    matTvec3(Ri, paw, &aw[3 * i]);
+    // joint motion S qd = (0; axis qd)
+    S jw[3] = {ax[0] * v[i], ax[1] * v[i], ax[2] * v[i]};
+    for (int k = 0; k < 3; ++k) vw[3 * i + k] += jw[k];
+    // a += S qdd + v x (S qd): motion cross (vl,vw) x (0,jw) = (vl x jw ; vw x jw)
+    S c1[3], c2[3];
+    cross(&vl[3 * i], jw, c1);
+    cross(&vw[3 * i], jw, c2);
+    for (int k = 0; k < 3; ++k) { al[3 * i + k] += c1[k]; aw[3 * i + k] += ax[k] * a[i] + c2[k]; }
+    // f = I a + v x* (I v)
+    const double mass = m.mass[i];
+    const double *c = &m.com[3 * i];
+    const double *I = &m.inertia[9 * i];
+    S cv[3] = {S(c[0]), S(c[1]), S(c[2])};
+    S Iv[9];
+    for (int k = 0; k < 9; ++k) Iv[k] = S(I[k]);
+    S hl[3], hw[3], gl[3], gw[3], tmp[3], tmp2[3];
+    // h = I v
+    cross(cv, &vw[3 * i], tmp);
+    for (int k = 0; k < 3; ++k) hl[k] = mass * (vl[3 * i + k] - tmp[k]);
+    matvec3(Iv, &vw[3 * i], tmp);
+    cross(cv, hl, tmp2);
+    for (int k = 0; k < 3; ++k) hw[k] = tmp[k] + tmp2[k];
+    // g = I a
+    cross(cv, &aw[3 * i], tmp);
+    for (int k = 0; k < 3; ++k) gl[k] = mass * (al[3 * i + k] - tmp[k]);
+    matvec3(Iv, &aw[3 * i], tmp);
+    cross(cv, gl, tmp2);
+    for (int k = 0; k < 3; ++k) gw[k] = tmp[k] + tmp2[k];
+    // v x* h = (w x hl ; w x hw + vl x hl)
+    S x1[3], x2[3], x3[3];
+    cross(&vw[3 * i], hl, x1);
+    cross(&vw[3 * i], hw, x2);
+    cross(&vl[3 * i], hl, x3);
+    for (int k = 0; k < 3; ++k) { fl[3 * i + k] = gl[k] + x1[k]; fw[3 * i + k] = gw[k] + x2[k] + x3[k]; }
+  }
+  for (int i = n - 1; i >= 0; --i) {
+    const double *ax = &m.axis[3 * i];
+    tau[i] = ax[0] * fw[3 * i] + ax[1] * fw[3 * i + 1] + ax[2] * fw[3 * i + 2];
+    int par = m.parent[i];
+    if (par >= 0) {
+      const double *p = &m.placement[12 * i + 9];
+      S pv[3] = {S(p[0]), S(p[1]), S(p[2])};
+      S Rf[3], Rn[3], t[3];
+      matvec3(&R[9 * i], &fl[3 * i], Rf);
+      matvec3(&R[9 * i], &fw[3 * i], Rn);
+      cross(pv, Rf, t);
+      for (int k = 0; k < 3; ++k) { fl[3 * par + k] += Rf[k]; fw[3 * par + k] += Rn[k] + t[k]; }
+    }
+  }
+}
+
+// Joint-space inertia by unit accelerations (column j = rnea(q, 0, e_j) without
+// gravity), plus armature on the diagonal: what crocoddyl's armature branch of
+// DifferentialActionModelFreeFwdDynamics factorises.
+template <class S> void mass_matrix(const Model &m, const S *q, S *M) {
+  const int n = m.nv;
+  std::vector<S> zero(n, S(0.0)), e(n, S(0.0)), col(n);
+  for (int j = 0; j < n; ++j) {
+    e[j] = S(1.0);
+    rnea(m, q, zero.data(), e.data(), col.data(), false);
+    e[j] = S(0.0);
+    for (int i = 0; i < n; ++i) M[i * n + j] = col[i];
+  }
+  for (int i = 0; i < n; ++i) M[i * n + i] = M[i * n + i] + m.armature[i];
+}
+
+// In-place Cholesky (lower) and solve; generic scalar.
+template <class S> void cholesky(int n, S *A) {
+  for (int j = 0; j < n; ++j) {
+    S d = A[j * n + j];
+    for (int k = 0; k < j; ++k) d -= A[j * n + k] * A[j * n + k];
+    d = sqrt(d);
+    A[j * n + j] = d;
+    for (int i = j + 1; i < n; ++i) {
+      S s = A[i * n + j];
+      for (int k = 0; k < j; ++k) s -= A[i * n + k] * A[j * n + k];
+      A[i * n + j] = s / d;
+    }
+  }
+}
+template <class S> void chol_solve(int n, const S *L, S *b) {
+  for (int i = 0; i < n; ++i) {
+    S s = b[i];
+    for (int k = 0; k < i; ++k) s -= L[i * n + k] * b[k];
+    b[i] = s / L[i * n + i];
+  }
+  for (int i = n - 1; i >= 0; --i) {
+    S s = b[i];
+    for (int k = i + 1; k < n; ++k) s -= L[k * n + i] * b[k];
+    b[i] = s / L[i * n + i];
+  }
+}
+
+// a = (M + diag(armature))^-1 (u - nle(q, v))     
+template <class S> void forward_dynamics(const Model &m, const S *q, const S *v, const S *u, S *a) {
+  const int n = m.nv;
+  std::vector<S> M(n * n), nle(n), zero(n, S(0.0));
+  mass_matrix(m, q, M.data());
+  rnea(m, q, v, zero.data(), nle.data(), true);
+  for (int i = 0; i < n; ++i) a[i] = u[i] - nle[i];
+  cholesky(n, M.data());
+  chol_solve(n, M.data(), a);
+}
+
+// World placement of every joint, then of one frame.
+template <class S> void joint_placements(const Model &m, const S *q, S *Rw, S *pw) {
+  for (int i = 0; i < m.nv; ++i) {
+    S Ri[9];
+    joint_rotation(m, i, q[i], Ri);
+    const double *p = &m.placement[12 * i + 9];
+    S pv[3] = {S(p[0]), S(p[1]), S(p[2])};
+    int par = m.parent[i];
+    if (par >= 0) {
+      matmul3(&Rw[9 * par], Ri, &Rw[9 * i]);
+      S t[3];
+      matvec3(&Rw[9 * par], pv, t);
+      for (int k = 0; k < 3; ++k) pw[3 * i + k] = pw[3 * par + k] + t[k];
+    } else {
+      for (int k = 0; k < 9; ++k) Rw[9 * i + k] = Ri[k];
+      for (int k = 0; k < 3; ++k) pw[3 * i + k] = pv[k];
+    }
+  }
+}
+template <class S> void frame_placement(const Model &m, int frame, const S *q, S *R, S *p) {
+  std::vector<S> Rw(9 * m.nv), pw(3 * m.nv);
+  joint_placements(m, q, Rw.data(), pw.data());
+  const double *fp = &m.frame_placement[12 * frame];
+  int par = m.frame_parent[frame];
+  S Rf[9], pf[3];
+  for (int k = 0; k < 9; ++k) Rf[k] = S(fp[k]);
+  for (int k = 0; k < 3; ++k) pf[k] = S(fp[9 + k]);
+  if (par >= 0) {
+    matmul3(&Rw[9 * par], Rf, R);
+    S t[3];
+    matvec3(&Rw[9 * par], pf, t);
+    for (int k = 0; k < 3; ++k) p[k] = pw[3 * par + k] + t[k];
+  } else {
+    for (int k = 0; k < 9; ++k) R[k] = Rf[k];
+    for (int k = 0; k < 3; ++k) p[k] = pf[k];
+  }
+}
+
+// log maps with pinocchio's conventions (pinocchio/spatial/log.hxx), used by
+// crocoddyl::ResidualModelFramePlacement: r = log6(Mref^-1 oMf), [lin; ang],
+// Rq = Jlog6(rMf) * fJf.  The branch for theta near pi (explicit formula with the
+// sign taken from the antisymmetric part) matters: at q = 0 the Panda tool frame
+// is exactly pi away from the identity, and the branch decides which way the
+// reference's golden solution (tests/test_ocp_croco_base.py) turns the wrist.
+inline void log3d(const double *R, double *w) {
+  double tr = R[0] + R[4] + R[8];
+  if (tr > 3.0) tr = 3.0;
+  if (tr < -1.0) tr = -1.0;
+  const double ct = 0.5 * (tr - 1.0);
+  const double theta = std::acos(ct);
+  if (theta >= M_PI - 1e-2) {
+    const double cphi = -ct;
+    const double beta = theta * theta / (1.0 + cphi);
+    const double v0 = (R[0] + cphi) * beta, v1 = (R[4] + cphi) * beta, v2 = (R[8] + cphi) * beta;
+    w[0] = (R[7] > R[5] ? 1.0 : -1.0) * (v0 > 0.0 ? std::sqrt(v0) : 0.0);
+    w[1] = (R[2] > R[6] ? 1.0 : -1.0) * (v1 > 0.0 ? std::sqrt(v1) : 0.0);
+    w[2] = (R[3] > R[1] ? 1.0 : -1.0) * (v2 > 0.0 ? std::sqrt(v2) : 0.0);
+  } else {
+    const double t = 0.5 * (theta > 1e-8 ? theta / std::sin(theta) : 1.0);
+    w[0] = t * (R[7] - R[5]);
+    w[1] = t * (R[2] - R[6]);
+    w[2] = t * (R[3] - R[1]);
+  }
+}
+inline void log6d(const double *R, const double *p, double *r) {
+  double w[3];
+  log3d(R, w);
+  const double t2 = w[0] * w[0] + w[1] * w[1] + w[2] * w[2];
+  double alpha, beta;
+  if (t2 < 1e-12) {
+    alpha = 1.0 - t2 / 12.0;
+    beta = 1.0 / 12.0 + t2 / 720.0;
+  } else {
+    const double t = std::sqrt(t2), st = std::sin(t), ct = std::cos(t);
+    alpha = t * st / (2.0 * (1.0 - ct));
+    beta = 1.0 / t2 - st / (2.0 * t * (1.0 - ct));
+  }
+  double wxp[3];
+  cross(w, p, wxp);
+  const double wp = w[0] * p[0] + w[1] * p[1] + w[2] * p[2];
+  for (int k = 0; k < 3; ++k) {
+    r[k] = alpha * p[k] - 0.5 * wxp[k] + beta * wp * w[k];
+    r[3 + k] = w[k];
+  }
+}
+// Jlog3 / Jlog6 for a right (local) perturbation, pinocchio::Jlog3 / Jlog6.
+inline void jlog3d(const double *w, double *J) {
+  const double t2 = w[0] * w[0] + w[1] * w[1] + w[2] * w[2], t = std::sqrt(t2);
+  double alpha, diag;
+  if (t < 1e-4) {
+    alpha = 1.0 / 12.0 + t2 / 720.0;
+    diag = 0.5 * (2.0 - t2 / 6.0);
+  } else {
+    const double st = std::sin(t), ct = std::cos(t), s1 = st / (1.0 - ct);
+    alpha = 1.0 / t2 - s1 / (2.0 * t);
+    diag = 0.5 * t * s1;
+  }
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) J[3 * i + j] = alpha * w[i] * w[j] + (i == j ? diag : 0.0);
+  J[1] -= 0.5 * w[2]; J[2] += 0.5 * w[1];
+  J[3] += 0.5 * w[2]; J[5] -= 0.5 * w[0];
+  J[6] -= 0.5 * w[1]; J[7] += 0.5 * w[0];
+}
+inline void jlog6d(const double *R, const double *p, double *J /*6x6*/) {
+  double w[3], TL[9];
+  log3d(R, w);
+  jlog3d(w, TL);
+  const double t2 = w[0] * w[0] + w[1] * w[1] + w[2] * w[2], t = std::sqrt(t2);
+  double beta, bdot;
+  if (t < 1e-4) {
+    beta = 1.0 / 12.0 + t2 / 720.0;
+    bdot = 1.0 / 360.0;
+  } else {
+    const double tinv = 1.0 / t, t2inv = tinv * tinv, st = std::sin(t), ct = std::cos(t), i22 = 1.0 / (2.0 * (1.0 - ct));
+    beta = t2inv - st * tinv * i22;
+    bdot = -2.0 * t2inv * t2inv + (1.0 + st * tinv) * t2inv * i22;
+  }
+  const double wp = w[0] * p[0] + w[1] * p[1] + w[2] * p[2];
+  double v3[3], Cm[9], TR[9];
+  for (int k = 0; k < 3; ++k) v3[k] = (bdot * wp) * w[k] - (t2 * bdot + 2.0 * beta) * p[k];
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) Cm[3 * i + j] = v3[i] * w[j] + beta * w[i] * p[j] + (i == j ? wp * beta : 0.0);
+  Cm[1] -= 0.5 * p[2]; Cm[2] += 0.5 * p[1];
+  Cm[3] += 0.5 * p[2]; Cm[5] -= 0.5 * p[0];
+  Cm[6] -= 0.5 * p[1]; Cm[7] += 0.5 * p[0];
+  matmul3(Cm, TL, TR);
+  for (int i = 0; i < 36; ++i) J[i] = 0.0;
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) { J[6 * i + j] = TL[3 * i + j]; J[6 * (i + 3) + 3 + j] = TL[3 * i + j]; J[6 * i + 3 + j] = TR[3 * i + j]; }
+}
+
+// residual value through the log map, tangents through Jlog * (local twist of the
+// AD-propagated placement): exactly crocoddyl's Rq = Jlog6(rMf) * fJf, with the
+// frame Jacobian obtained by automatic differentiation of the forward kinematics.
+inline void log6_residual(const double *R, const double *p, double *r) { log6d(R, p, r); }
+inline void log3_residual(const double *R, double *r) { log3d(R, r); }
+template <int N> void log6_residual(const Dual<N> *R, const Dual<N> *p, Dual<N> *r) {
+  double Rv[9], pv[3], rv[6], J[36];
+  for (int k = 0; k < 9; ++k) Rv[k] = R[k].v;
+  for (int k = 0; k < 3; ++k) pv[k] = p[k].v;
+  log6d(Rv, pv, rv);
+  jlog6d(Rv, pv, J);
+  for (int k = 0; k < 6; ++k) r[k] = Dual<N>(rv[k]);
+  for (int d = 0; d < N; ++d) {
+    double dR[9], dp[3], W[9], xi[6];
+    for (int k = 0; k < 9; ++k) dR[k] = R[k].d[d];
+    for (int k = 0; k < 3; ++k) dp[k] = p[k].d[d];
+    matTvec3(Rv, dp, xi);
+    for (int i = 0; i < 3; ++i)
+      for (int j = 0; j < 3; ++j) W[3 * i + j] = Rv[i] * dR[j] + Rv[3 + i] * dR[3 + j] + Rv[6 + i] * dR[6 + j];
+    xi[3] = 0.5 * (W[7] - W[5]); xi[4] = 0.5 * (W[2] - W[6]); xi[5] = 0.5 * (W[3] - W[1]);
+    for (int i = 0; i < 6; ++i) { double s = 0.0; for (int j = 0; j < 6; ++j) s += J[6 * i + j] * xi[j]; r[i].d[d] = s; }
+  }
+}
+template <int N> void log3_residual(const Dual<N> *R, Dual<N> *r) {
+  double Rv[9], rv[3], J[9];
+  for (int k = 0; k < 9; ++k) Rv[k] = R[k].v;
+  log3d(Rv, rv);
+  jlog3d(rv, J);
+  for (int k = 0; k < 3; ++k) r[k] = Dual<N>(rv[k]);
+  for (int d = 0; d < N; ++d) {
+    double dR[9], W[9], xi[3];
+    for (int k = 0; k < 9; ++k) dR[k] = R[k].d[d];
+    for (int i = 0; i < 3; ++i)
+      for (int j = 0; j < 3; ++j) W[3 * i + j] = Rv[i] * dR[j] + Rv[3 + i] * dR[3 + j] + Rv[6 + i] * dR[6 + j];
+    xi[0] = 0.5 * (W[7] - W[5]); xi[1] = 0.5 * (W[2] - W[6]); xi[2] = 0.5 * (W[3] - W[1]);
+    for (int i = 0; i < 3; ++i) r[i].d[d] = J[3 * i] * xi[0] + J[3 * i + 1] * xi[1] + J[3 * i + 2] * xi[2];
+  }
+}
+
+// ---------------------------------------------------------------------------
+// problem description
+// ---------------------------------------------------------------------------
+struct Ocp {
+  int T = 0;
+  std::vector<double> dt;
+  std::vector<agx_cost_row> rows[2];  // 0 running, 1 terminal
+  std::vector<int> row_off[2];
+  int stride = 0;
+  double tol = 1e-3, mu_dyn = 10.0, mu_con = 10.0;
+  int max_qp = 200;
+};
+
+}  // namespace
+
+extern "C" {
+int agx_row_nref(int kind, int nv) {
+  switch (kind) {
+    case AGX_RES_STATE: return 2 * nv;
+    case AGX_RES_CONTROL: return nv;
+    case AGX_RES_CONTROL_GRAV: return 0;
+    case AGX_RES_FRAME_PLACEMENT: return 12;
+    case AGX_RES_FRAME_TRANSLATION: return 3;
+    case AGX_RES_FRAME_ROTATION: return 9;
+    case AGX_RES_FRAME_VELOCITY: return 6;
+    case AGX_RES_COLLISION: return 0;
+  }
+  return -1;
+}
+int agx_row_nr(int kind, int nv) {
+  switch (kind) {
+    case AGX_RES_STATE: return 2 * nv;
+    case AGX_RES_CONTROL: return nv;
+    case AGX_RES_CONTROL_GRAV: return nv;
+    case AGX_RES_FRAME_PLACEMENT: return 6;
+    case AGX_RES_FRAME_TRANSLATION: return 3;
+    case AGX_RES_FRAME_ROTATION: return 3;
+    case AGX_RES_FRAME_VELOCITY: return 6;
+    case AGX_RES_COLLISION: return 1;
+  }
+  return -1;
+}
+int agx_ref_stride(const agx_ocp_desc *d, int nv) {
+  int s0 = 0, s1 = 0;
+  for (int r = 0; r < d->n_running_rows; ++r) s0 += 1 + agx_row_nref(d->running_rows[r].kind, nv) + agx_row_nr(d->running_rows[r].kind, nv);
+  for (int r = 0; r < d->n_terminal_rows; ++r) s1 += 1 + agx_row_nref(d->terminal_rows[r].kind, nv) + agx_row_nr(d->terminal_rows[r].kind, nv);
+  return std::max(s0, s1);
+}
+}
+
+namespace {
+
+void copy_ocp(const agx_ocp_desc *d, int nv, Ocp &o) {
+  o.T = d->horizon;
+  o.dt.assign(d->dt, d->dt + d->horizon);
+  o.rows[0].assign(d->running_rows, d->running_rows + d->n_running_rows);
+  o.rows[1].assign(d->terminal_rows, d->terminal_rows + d->n_terminal_rows);
+  for (int s = 0; s < 2; ++s) {
+    int off = 0;
+    o.row_off[s].clear();
+    for (auto &r : o.rows[s]) { o.row_off[s].push_back(off); off += 1 + agx_row_nref(r.kind, nv) + agx_row_nr(r.kind, nv); }
+  }
+  o.stride = agx_ref_stride(d, nv);
+  o.tol = d->termination_tolerance;
+  o.mu_dyn = d->mu_dynamic;
+  o.mu_con = d->mu_constraint;
+  o.max_qp = d->max_qp_iters;
+}
+
+// ---------------------------------------------------------------------------
+// One shooting node: IntegratedActionModelEuler(DifferentialActionModelFreeFwdDynamics)
+// calc (S = double) or calc + calcDiff (S = Dual) -- SURVEY App. A.1-A.3.
+// ---------------------------------------------------------------------------
+struct NodeOut {  // plain doubles
+  std::vector<double> xnext, Fx, Fu, Lx, Lu, Lxx, Lxu, Luu;
+  double cost = 0.0;
+  std::vector<double> residuals;  // concatenated per-row residual values
+};
+
+template <class S>
+void node_eval(const Model &m, const Ocp &o, bool terminal, double dt, const S *x, const S *u,
+               const double *ref, const int32_t *frames, S *xnext, std::vector<S> &res,
+               std::vector<double> &act_r, std::vector<double> &act_rr, std::vector<double> &row_w,
+               std::vector<int> &row_nr, double &cost) {
+  const int nv = m.nv;
+  const S *q = x, *v = x + nv;
+  if (!terminal) {
+    std::vector<S> a(nv);
+    forward_dynamics(m, q, v, u, a.data());
+    // semi-implicit Euler, crocoddyl IntegratedActionModelEuler::calc (App. A.2)
+    for (int i = 0; i < nv; ++i) {
+      S vn = v[i] + dt * a[i];
+      xnext[nv + i] = vn;
+      xnext[i] = q[i] + dt * v[i] + (dt * dt) * a[i];
+    }
+  } else {
+    for (int i = 0; i < 2 * nv; ++i) xnext[i] = x[i];
+  }
+  const auto &rows = o.rows[terminal ? 1 : 0];
+  const auto &offs = o.row_off[terminal ? 1 : 0];
+  res.clear(); act_r.clear(); act_rr.clear(); row_w.clear(); row_nr.clear();
+  cost = 0.0;
+  for (size_t ri = 0; ri < rows.size(); ++ri) {
+    const agx_cost_row &row = rows[ri];
+    const double *tile = ref + offs[ri];
+    const double w_item = tile[0];
+    const double *rref = tile + 1;
+    const int nref = agx_row_nref(row.kind, nv);
+    const int nr = agx_row_nr(row.kind, nv);
+    const double *aw = rref + nref;
+    int frame = frames ? frames[ri] : row.frame;
+    if (frame < 0) frame = row.frame;
+    std::vector<S> r(nr);
+    switch (row.kind) {
+      case AGX_RES_STATE:
+        for (int i = 0; i < 2 * nv; ++i) r[i] = x[i] - rref[i];
+        break;
+      case AGX_RES_CONTROL:
+        for (int i = 0; i < nv; ++i) r[i] = terminal ? S(0.0) : (u[i] - rref[i]);
+        break;
+      case AGX_RES_CONTROL_GRAV: {
+        std::vector<S> zero(nv, S(0.0)), g(nv);
+        rnea(m, q, zero.data(), zero.data(), g.data(), true);
+        for (int i = 0; i < nv; ++i) r[i] = terminal ? S(0.0) : (u[i] - g[i]);
+      } break;
+      case AGX_RES_FRAME_PLACEMENT: {
+        S R[9], p[3];
+        frame_placement(m, frame, q, R, p);
+        S Rr[9], pr[3];
+        for (int k = 0; k < 9; ++k) Rr[k] = S(rref[k]);
+        for (int k = 0; k < 3; ++k) pr[k] = S(rref[9 + k]);
+        // rMf = Mref^-1 * oMf
+        S Rt[9] = {Rr[0], Rr[3], Rr[6], Rr[1], Rr[4], Rr[7], Rr[2], Rr[5], Rr[8]};
+        S Rrel[9], d[3], prel[3];
+        matmul3(Rt, R, Rrel);
+        for (int k = 0; k < 3; ++k) d[k] = p[k] - pr[k];
+        matvec3(Rt, d, prel);
+        log6_residual(Rrel, prel, r.data());
+      } break;
+      case AGX_RES_FRAME_TRANSLATION: {
+        S R[9], p[3];
+        frame_placement(m, frame, q, R, p);
+        for (int k = 0; k < 3; ++k) r[k] = p[k] - rref[k];
+      } break;
+      case AGX_RES_FRAME_ROTATION: {
+        S R[9], p[3];
+        frame_placement(m, frame, q, R, p);
+        S Rt[9] = {S(rref[0]), S(rref[3]), S(rref[6]), S(rref[1]), S(rref[4]), S(rref[7]), S(rref[2]), S(rref[5]), S(rref[8])};
+        S Rrel[9];
+        matmul3(Rt, R, Rrel);
+        log3_residual(Rrel, r.data());
+      } break;
+      default:
+        for (int i = 0; i < nr; ++i) r[i] = S(0.0);
+        break;
+    }
+    double a_val = 0.0;
+    for (int j = 0; j < nr; ++j) {
+      double rv = val(r[j]);
+      // ActivationModelWeightedQuad: a = 1/2 sum w r^2 (tests/test_ocp_croco_generic.py:70-72)
+      a_val += 0.5 * aw[j] * rv * rv;
+      act_r.push_back(aw[j] * rv);
+      act_rr.push_back(aw[j]);
+    }
+    const bool active = row.active != 0;
+    row_w.push_back(active ? w_item : 0.0);
+    row_nr.push_back(nr);
+    if (active) cost += w_item * a_val;
+    for (int j = 0; j < nr; ++j) res.push_back(r[j]);
+  }
+  if (!terminal) cost *= dt;
+}
+
+template <int N>
+void node_calc_diff_n(const Model &m, const Ocp &o, bool terminal, double dt, const double *x,
+                      const double *u, const double *ref, const int32_t *frames, NodeOut &out) {
+  typedef Dual<N> D;
+  const int nv = m.nv, nx = 2 * nv, nu = nv;
+  std::vector<D> xd(nx), ud(nu), xn(nx);
+  for (int i = 0; i < nx; ++i) { xd[i] = D(x[i]); xd[i].d[i] = 1.0; }
+  for (int i = 0; i < nu; ++i) { ud[i] = D(terminal ? 0.0 : u[i]); ud[i].d[nx + i] = 1.0; }
+  std::vector<D> res;
+  std::vector<double> ar, arr, rw;
+  std::vector<int> rnr;
+  double cost;
+  node_eval<D>(m, o, terminal, dt, xd.data(), ud.data(), ref, frames, xn.data(), res, ar, arr, rw, rnr, cost);
+  out.cost = cost;
+  out.xnext.resize(nx); out.Fx.assign(nx * nx, 0.0); out.Fu.assign(nx * nu, 0.0);
+  out.Lx.assign(nx, 0.0); out.Lu.assign(nu, 0.0); out.Lxx.assign(nx * nx, 0.0); out.Lxu.assign(nx * nu, 0.0); out.Luu.assign(nu * nu, 0.0);
+  for (int i = 0; i < nx; ++i) {
+    out.xnext[i] = xn[i].v;
+    for (int j = 0; j < nx; ++j) out.Fx[i * nx + j] = xn[i].d[j];
+    for (int j = 0; j < nu; ++j) out.Fu[i * nu + j] = terminal ? 0.0 : xn[i].d[nx + j];
+  }
+  const double scale = terminal ? 1.0 : dt;
+  out.residuals.resize(res.size());
+  int k = 0;
+  for (size_t ri = 0; ri < rnr.size(); ++ri) {
+    const double w = rw[ri] * scale;
+    for (int j = 0; j < rnr[ri]; ++j, ++k) {
+      out.residuals[k] = res[k].v;
+      if (w == 0.0) continue;
+      const double *g = res[k].d;  // [d/dx (nx) | d/du (nu)]
+      // Gauss-Newton: Lx = Rx^T a_r, Lxx = Rx^T a_rr Rx
+      for (int a = 0; a < nx; ++a) {
+        out.Lx[a] += w * ar[k] * g[a];
+        for (int b = 0; b < nx; ++b) out.Lxx[a * nx + b] += w * arr[k] * g[a] * g[b];
+        for (int b = 0; b < nu; ++b) out.Lxu[a * nu + b] += w * arr[k] * g[a] * g[nx + b];
+      }
+      for (int a = 0; a < nu; ++a) {
+        out.Lu[a] += w * ar[k] * g[nx + a];
+        for (int b = 0; b < nu; ++b) out.Luu[a * nu + b] += w * arr[k] * g[nx + a] * g[nx + b];
+      }
+    }
+  }
+}
+
+void node_calc_diff(const Model &m, const Ocp &o, bool terminal, double dt, const double *x,
+                    const double *u, const double *ref, const int32_t *frames, NodeOut &out) {
+  const int nd = 3 * m.nv;
+  if (nd <= 8) node_calc_diff_n<8>(m, o, terminal, dt, x, u, ref, frames, out);
+  else if (nd <= 24) node_calc_diff_n<24>(m, o, terminal, dt, x, u, ref, frames, out);
+  else node_calc_diff_n<96>(m, o, terminal, dt, x, u, ref, frames, out);
+}
+
+void node_calc(const Model &m, const Ocp &o, bool terminal, double dt, const double *x, const double *u,
+               const double *ref, const int32_t *frames, double *xnext, double &cost,
+               std::vector<double> *residuals = nullptr) {
+  std::vector<double> res, ar, arr, rw;
+  std::vector<int> rnr;
+  std::vector<double> uz(m.nv, 0.0);
+  node_eval<double>(m, o, terminal, dt, x, terminal ? uz.data() : u, ref, frames, xnext, res, ar, arr, rw, rnr, cost);
+  if (residuals) *residuals = res;
+}
+
+void pack_tile(int nv, const NodeOut &n, const double *xs_next, double *tile) {
+  const int nx = 2 * nv, nu = nv;
+  double *p = tile;
+  std::memcpy(p, n.Fx.data(), sizeof(double) * nx * nx); p += nx * nx;
+  std::memcpy(p, n.Fu.data(), sizeof(double) * nx * nu); p += nx * nu;
+  for (int i = 0; i < nx; ++i) p[i] = xs_next ? n.xnext[i] - xs_next[i] : 0.0;  // gap f_{t+1}
+  p += nx;
+  std::memcpy(p, n.Lx.data(), sizeof(double) * nx); p += nx;
+  std::memcpy(p, n.Lu.data(), sizeof(double) * nu); p += nu;
+  std::memcpy(p, n.Lxx.data(), sizeof(double) * nx * nx); p += nx * nx;
+  std::memcpy(p, n.Lxu.data(), sizeof(double) * nx * nu); p += nx * nu;
+  std::memcpy(p, n.Luu.data(), sizeof(double) * nu * nu); p += nu * nu;
+  p[0] = n.cost;
+}
+
+// ---------------------------------------------------------------------------
+// QP direction: Riccati backward + linear forward + KKT,
+// the unconstrained branch of mim_solvers::SolverCSQP::computeDirection.
+// tiles [T+1][TILE] in the layout of AGX_TILE_DOUBLES.
+// ---------------------------------------------------------------------------
+struct Direction {
+  std::vector<double> K, k, dx, du, Vxx, Vx, lag;
+  double kkt = 0.0;
+};
+
+// sigma > 0 selects the proximal (ADMM) form of mim_solvers::SolverCSQP::backwardPass:
+// sigma on Vxx_T, Qxx, Quu and -sigma*dxtilde/-sigma*dutilde on the gradients (prox
+// centre = the previous iterate cx, cu).  preg/dreg are crocoddyl's primal/dual
+// regularisations (Quu += preg, Vxx += dreg), floor reg_min = 1e-9.
+bool direction(int nv, int T, const double *tiles, Direction &d, double sigma = 0.0, double preg = 0.0,
+               double dreg = 0.0, const double *cx = nullptr, const double *cu = nullptr) {
+  const int nx = 2 * nv, nu = nv, TILE = AGX_TILE_DOUBLES(nv);
+  const int oFx = 0, oFu = oFx + nx * nx, of = oFu + nx * nu, oLx = of + nx, oLu = oLx + nx, oLxx = oLu + nu, oLxu = oLxx + nx * nx, oLuu = oLxu + nx * nu;
+  d.K.assign((size_t)T * nu * nx, 0.0); d.k.assign((size_t)T * nu, 0.0);
+  d.dx.assign((size_t)(T + 1) * nx, 0.0); d.du.assign((size_t)T * nu, 0.0);
+  d.Vxx.assign((size_t)(T + 1) * nx * nx, 0.0); d.Vx.assign((size_t)(T + 1) * nx, 0.0);
+  d.lag.assign((size_t)(T + 1) * nx, 0.0);
+  const double *tt = tiles + (size_t)T * TILE;
+  std::memcpy(&d.Vxx[(size_t)T * nx * nx], tt + oLxx, sizeof(double) * nx * nx);
+  std::memcpy(&d.Vx[(size_t)T * nx], tt + oLx, sizeof(double) * nx);
+  for (int i = 0; i < nx; ++i) {
+    d.Vxx[(size_t)T * nx * nx + i * nx + i] += sigma + dreg;
+    if (cx) d.Vx[(size_t)T * nx + i] -= sigma * cx[(size_t)T * nx + i];
+  }
+  std::vector<double> Vp(nx), FxTV(nx * nx), FuTV(nu * nx), Qxx(nx * nx), Qxu(nx * nu), Quu(nu * nu), Qx(nx), Qu(nu), L(nu * nu), col(nu);
+  bool ok = true;
+  for (int t = T - 1; t >= 0; --t) {
+    const double *n = tiles + (size_t)t * TILE;
+    const double *Fx = n + oFx, *Fu = n + oFu, *f = n + of, *Lx = n + oLx, *Lu = n + oLu, *Lxx = n + oLxx, *Lxu = n + oLxu, *Luu = n + oLuu;
+    const double *Vn = &d.Vxx[(size_t)(t + 1) * nx * nx];
+    const double *vn = &d.Vx[(size_t)(t + 1) * nx];
+    for (int i = 0; i < nx; ++i) { double s = vn[i]; for (int j = 0; j < nx; ++j) s += Vn[i * nx + j] * f[j]; Vp[i] = s; }
+    for (int i = 0; i < nx; ++i) for (int j = 0; j < nx; ++j) { double s = 0; for (int k = 0; k < nx; ++k) s += Fx[k * nx + i] * Vn[k * nx + j]; FxTV[i * nx + j] = s; }
+    for (int i = 0; i < nu; ++i) for (int j = 0; j < nx; ++j) { double s = 0; for (int k = 0; k < nx; ++k) s += Fu[k * nu + i] * Vn[k * nx + j]; FuTV[i * nx + j] = s; }
+    for (int i = 0; i < nx; ++i) for (int j = 0; j < nx; ++j) { double s = Lxx[i * nx + j]; for (int k = 0; k < nx; ++k) s += FxTV[i * nx + k] * Fx[k * nx + j]; Qxx[i * nx + j] = s; }
+    for (int i = 0; i < nx; ++i) for (int j = 0; j < nu; ++j) { double s = Lxu[i * nu + j]; for (int k = 0; k < nx; ++k) s += FxTV[i * nx + k] * Fu[k * nu + j]; Qxu[i * nu + j] = s; }
+    for (int i = 0; i < nu; ++i) for (int j = 0; j < nu; ++j) { double s = Luu[i * nu + j]; for (int k = 0; k < nx; ++k) s += FuTV[i * nx + k] * Fu[k * nu + j]; Quu[i * nu + j] = s; }
+    for (int i = 0; i < nx; ++i) { double s = Lx[i]; for (int k = 0; k < nx; ++k) s += Fx[k * nx + i] * Vp[k]; Qx[i] = s; }
+    for (int i = 0; i < nu; ++i) { double s = Lu[i]; for (int k = 0; k < nx; ++k) s += Fu[k * nu + i] * Vp[k]; Qu[i] = s; }
+    for (int i = 0; i < nx; ++i) { Qxx[i * nx + i] += sigma; if (cx) Qx[i] -= sigma * cx[(size_t)t * nx + i]; }
+    for (int i = 0; i < nu; ++i) { Quu[i * nu + i] += sigma + preg; if (cu) Qu[i] -= sigma * cu[(size_t)t * nu + i]; }
+    L = Quu;
+    for (int j = 0; j < nu; ++j) { double dd = L[j * nu + j]; for (int k = 0; k < j; ++k) dd -= L[j * nu + k] * L[j * nu + k]; if (!(dd > 0.0)) ok = false; }
+    cholesky(nu, L.data());
+    double *K = &d.K[(size_t)t * nu * nx], *kk = &d.k[(size_t)t * nu];
+    for (int j = 0; j < nx; ++j) {
+      for (int i = 0; i < nu; ++i) col[i] = Qxu[j * nu + i];
+      chol_solve(nu, L.data(), col.data());
+      for (int i = 0; i < nu; ++i) K[i * nx + j] = col[i];
+    }
+    for (int i = 0; i < nu; ++i) kk[i] = Qu[i];
+    chol_solve(nu, L.data(), kk);
+    double *V = &d.Vxx[(size_t)t * nx * nx], *vx = &d.Vx[(size_t)t * nx];
+    for (int i = 0; i < nx; ++i) { double s = Qx[i]; for (int k = 0; k < nu; ++k) s -= K[k * nx + i] * Qu[k]; vx[i] = s; }
+    for (int i = 0; i < nx; ++i) for (int j = 0; j < nx; ++j) { double s = Qxx[i * nx + j]; for (int k = 0; k < nu; ++k) s -= Qxu[i * nu + k] * K[k * nx + j]; V[i * nx + j] = s; }
+    for (int i = 0; i < nx; ++i) for (int j = i + 1; j < nx; ++j) { double s = 0.5 * (V[i * nx + j] + V[j * nx + i]); V[i * nx + j] = s; V[j * nx + i] = s; }
+    for (int i = 0; i < nx; ++i) V[i * nx + i] += dreg;
+  }
+  // forward (dx_0 = x0 - xs_0 = 0 because the solver pins xs_0 = x0)
+  for (int t = 0; t < T; ++t) {
+    const double *n = tiles + (size_t)t * TILE;
+    const double *Fx = n + oFx, *Fu = n + oFu, *f = n + of;
+    const double *K = &d.K[(size_t)t * nu * nx], *kk = &d.k[(size_t)t * nu];
+    const double *dx = &d.dx[(size_t)t * nx];
+    double *du = &d.du[(size_t)t * nu], *dxn = &d.dx[(size_t)(t + 1) * nx];
+    for (int i = 0; i < nu; ++i) { double s = -kk[i]; for (int j = 0; j < nx; ++j) s -= K[i * nx + j] * dx[j]; du[i] = s; }
+    for (int i = 0; i < nx; ++i) { double s = f[i]; for (int j = 0; j < nx; ++j) s += Fx[i * nx + j] * dx[j]; for (int j = 0; j < nu; ++j) s += Fu[i * nu + j] * du[j]; dxn[i] = s; }
+  }
+  for (int t = 0; t <= T; ++t) {
+    const double *V = &d.Vxx[(size_t)t * nx * nx], *vx = &d.Vx[(size_t)t * nx], *dx = &d.dx[(size_t)t * nx];
+    double *lm = &d.lag[(size_t)t * nx];
+    for (int i = 0; i < nx; ++i) { double s = vx[i]; for (int j = 0; j < nx; ++j) s += V[i * nx + j] * dx[j]; lm[i] = s; }
+  }
+  // KKT by definition with the multipliers (mim_solvers checkKKTConditions)
+  double kkt = 0.0;
+  for (int t = 0; t < T; ++t) {
+    const double *n = tiles + (size_t)t * TILE;
+    const double *Fx = n + oFx, *Fu = n + oFu, *f = n + of, *Lx = n + oLx, *Lu = n + oLu;
+    const double *ln = &d.lag[(size_t)(t + 1) * nx], *lt = &d.lag[(size_t)t * nx];
+    if (t > 0)
+      for (int i = 0; i < nx; ++i) { double s = Lx[i] - lt[i]; for (int k = 0; k < nx; ++k) s += Fx[k * nx + i] * ln[k]; kkt = std::max(kkt, std::fabs(s)); }
+    for (int i = 0; i < nu; ++i) { double s = Lu[i]; for (int k = 0; k < nx; ++k) s += Fu[k * nu + i] * ln[k]; kkt = std::max(kkt, std::fabs(s)); }
+    for (int i = 0; i < nx; ++i) kkt = std::max(kkt, std::fabs(f[i]));
+  }
+  {
+    const double *Lx = tiles + (size_t)T * TILE + oLx;
+    const double *lt = &d.lag[(size_t)T * nx];
+    for (int i = 0; i < nx; ++i) kkt = std::max(kkt, std::fabs(Lx[i] - lt[i]));
+  }
+  d.kkt = kkt;
+  return ok;
+}
+
+// ---------------------------------------------------------------------------
+// SQP outer loop for one instance.
+// ---------------------------------------------------------------------------
+struct Workspace {
+  std::vector<double> tiles, xs_try, us_try, xn;
+  Direction dir;
+  NodeOut node;
+};
+
+void eval_tiles(const Model &m, const Ocp &o, const double *xs, const double *us, const double *ref,
+                const int32_t *frames, Workspace &w, double &cost, double &gap1) {
+  const int nv = m.nv, nx = 2 * nv, nu = nv, T = o.T, TILE = AGX_TILE_DOUBLES(nv);
+  w.tiles.resize((size_t)(T + 1) * TILE);
+  cost = 0.0; gap1 = 0.0;
+  for (int t = 0; t <= T; ++t) {
+    const bool term = (t == T);
+    node_calc_diff(m, o, term, term ? 0.0 : o.dt[t], xs + (size_t)t * nx, term ? nullptr : us + (size_t)t * nu,
+                   ref + (size_t)t * o.stride, frames ? frames + (size_t)t * AGX_MAX_ROWS : nullptr, w.node);
+    pack_tile(nv, w.node, term ? nullptr : xs + (size_t)(t + 1) * nx, &w.tiles[(size_t)t * TILE]);
+    cost += w.node.cost;
+    if (!term) for (int i = 0; i < nx; ++i) gap1 += std::fabs(w.node.xnext[i] - xs[(size_t)(t + 1) * nx + i]);
+  }
+}
+
+void solve_one(const Model &m, const Ocp &o, const double *ref, const int32_t *frames, const double *x0,
+               const double *xs_ws, const double *us_ws, int max_iter, double max_time, double *xs, double *us,
+               double *K, agx_status *st, Workspace &w) {
+  const int nv = m.nv, nx = 2 * nv, nu = nv, T = o.T;
+  auto t_start = std::chrono::steady_clock::now();
+  std::memcpy(xs, xs_ws, sizeof(double) * (T + 1) * nx);
+  std::memcpy(us, us_ws, sizeof(double) * T * nu);
+  std::memcpy(xs, x0, sizeof(double) * nx);  // xs_[0] = problem.x0
+  if (max_iter <= 0) max_iter = 1000;
+  std::memset(st, 0, sizeof(*st));
+  std::memset(K, 0, sizeof(double) * T * nu * nx);
+  w.xs_try.resize((size_t)(T + 1) * nx); w.us_try.resize((size_t)T * nu); w.xn.resize(nx);
+  int it = 0;
+  // crocoddyl regularisation state (SolverDDP defaults: reg_min 1e-9, reg_max 1e9, factor 10,
+  // th_stepdec 0.5, th_stepinc 0.01); sigma = 1e-6 is SolverCSQP's proximal weight.
+  const double reg_min = 1e-9, reg_max = 1e9, sigma = 1e-6;
+  double preg = reg_min, dreg = reg_min;
+  Direction dirK;
+  auto final_gains = [&]() {
+    // K reported by the solver comes from the sigma-regularised ADMM backward pass
+    direction(nv, T, w.tiles.data(), dirK, sigma, preg, dreg, w.dir.dx.data(), w.dir.du.data());
+    std::memcpy(K, dirK.K.data(), sizeof(double) * T * nu * nx);
+  };
+  bool have_dir = false;
+  for (; it < max_iter; ++it) {
+    double cost, gap1;
+    eval_tiles(m, o, xs, us, ref, frames, w, cost, gap1);
+    const double merit = cost + o.mu_dyn * gap1;
+    bool ok = direction(nv, T, w.tiles.data(), w.dir, 0.0, preg, dreg);
+    have_dir = true;
+    st->kkt = w.dir.kkt; st->cost = cost; st->merit = merit; st->gap_norm = gap1; st->qp_iters = 1;
+    if (!ok) st->flags |= 1;
+    if (w.dir.kkt <= o.tol) { st->solved = 1; break; }
+    // merit line search, alpha = 2^-n, n = 0..9, no rollout
+    bool accepted = false;
+    double alpha = 1.0, used = 1.0;
+    for (int n = 0; n < 10; ++n, alpha *= 0.5) {
+      used = alpha;
+      for (size_t i = 0; i < (size_t)(T + 1) * nx; ++i) w.xs_try[i] = xs[i] + alpha * w.dir.dx[i];
+      for (size_t i = 0; i < (size_t)T * nu; ++i) w.us_try[i] = us[i] + alpha * w.dir.du[i];
+      double cost_try = 0.0, gap_try = 0.0;
+      for (int t = 0; t <= T; ++t) {
+        const bool term = (t == T);
+        double c;
+        node_calc(m, o, term, term ? 0.0 : o.dt[t], &w.xs_try[(size_t)t * nx], term ? nullptr : &w.us_try[(size_t)t * nu],
+                  ref + (size_t)t * o.stride, frames ? frames + (size_t)t * AGX_MAX_ROWS : nullptr, w.xn.data(), c);
+        cost_try += c;
+        if (!term) for (int i = 0; i < nx; ++i) gap_try += std::fabs(w.xn[i] - w.xs_try[(size_t)(t + 1) * nx + i]);
+      }
+      const double merit_try = cost_try + o.mu_dyn * gap_try;
+      if (merit > merit_try) { accepted = true; break; }
+    }
+    const bool last = (it + 1 == max_iter);
+    if (last || !accepted) final_gains();  // gains belong to the point the direction was computed at
+    if (accepted) {
+      std::memcpy(xs, w.xs_try.data(), sizeof(double) * (T + 1) * nx);
+      std::memcpy(us, w.us_try.data(), sizeof(double) * T * nu);
+    } else {
+      st->flags |= 2;
+    }
+    if (used > 0.5) { preg = std::max(preg / 10.0, reg_min); dreg = std::max(dreg / 10.0, reg_min); }
+    if (used <= 0.01) {
+      preg = std::min(preg * 10.0, reg_max); dreg = std::min(dreg * 10.0, reg_max);
+      if (preg == reg_max) { ++it; break; }
+    }
+    if (max_time > 0.0) {
+      double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
+      if (el > max_time) { if (!last && accepted) final_gains(); ++it; break; }
+    }
+  }
+  if (st->solved && have_dir) final_gains();
+  st->iter = it;
+  for (size_t i = 0; i < (size_t)(T + 1) * nx; ++i) if (!std::isfinite(xs[i])) st->flags |= 1;
+}
+
+struct OrcOcp {
+  Model m;
+  Ocp o;
+  int B;
+};
+
+thread_local std::string g_err;
+
+}  // namespace
+
+extern "C" {
+
+const char *orc_last_error(void) { return g_err.c_str(); }
+
+int orc_ocp_create(const agx_model_desc *md, const agx_ocp_desc *od, int batch, void **out) {
+  if (!md || !od || !out || md->nv < 1 || md->nv > AGX_MAX_NV) { g_err = "orc_ocp_create: bad arguments"; return -1; }
+  OrcOcp *p = new OrcOcp();
+  copy_model(md, p->m);
+  copy_ocp(od, md->nv, p->o);
+  p->B = batch;
+  *out = p;
+  return 0;
+}
+void orc_ocp_destroy(void *h) { delete static_cast<OrcOcp *>(h); }
+
+int orc_rnea(void *h, int n, const double *q, const double *v, const double *a, double *tau) {
+  OrcOcp *p = static_cast<OrcOcp *>(h);
+  const int nv = p->m.nv;
+  for (int i = 0; i < n; ++i) rnea<double>(p->m, q + (size_t)i * nv, v + (size_t)i * nv, a + (size_t)i * nv, tau + (size_t)i * nv, true);
+  return 0;
+}
+int orc_mass_matrix(void *h, const double *q, double *M) {
+  OrcOcp *p = static_cast<OrcOcp *>(h);
+  mass_matrix<double>(p->m, q, M);
+  return 0;
+}
+int orc_forward_dynamics(void *h, int n, const double *q, const double *v, const double *u, double *a) {
+  OrcOcp *p = static_cast<OrcOcp *>(h);
+  const int nv = p->m.nv;
+  for (int i = 0; i < n; ++i) forward_dynamics<double>(p->m, q + (size_t)i * nv, v + (size_t)i * nv, u + (size_t)i * nv, a + (size_t)i * nv);
+  return 0;
+}
+int orc_frame_placement(void *h, int n, int frame, const double *q, double *out) {
+  OrcOcp *p = static_cast<OrcOcp *>(h);
+  if (frame < 0 || frame >= p->m.nframes) { g_err = "orc_frame_placement: bad frame"; return -1; }
+  for (int i = 0; i < n; ++i) frame_placement<double>(p->m, frame, q + (size_t)i * p->m.nv, out + (size_t)i * 12, out + (size_t)i * 12 + 9);
+  return 0;
+}
+int orc_log6(const double *M12, double *r6) { log6d(M12, M12 + 9, r6); return 0; }
+int orc_jlog6(const double *M12, double *J36) { jlog6d(M12, M12 + 9, J36); return 0; }
+
+int orc_integrate(void *h, int n, const double *x, const double *u, double *xnext) {
+  OrcOcp *p = static_cast<OrcOcp *>(h);
+  const int nv = p->m.nv, nx = 2 * nv;
+  Ocp bare = p->o;
+  bare.rows[0].clear(); bare.row_off[0].clear();
+  for (int i = 0; i < n; ++i) {
+    double c;
+    node_calc(p->m, bare, false, p->o.dt[0], x + (size_t)i * nx, u + (size_t)i * nv, nullptr, nullptr, xnext + (size_t)i * nx, c);
+  }
+  return 0;
+}
+
+// One node: calc + calcDiff into a tile (gap is xnext - xs_next when given).
+int orc_node_calc_diff(void *h, int terminal, double dt, const double *x, const double *u, const double *ref,
+                       const int32_t *frames, const double *xs_next, double *tile, double *xnext, double *residuals) {
+  OrcOcp *p = static_cast<OrcOcp *>(h);
+  NodeOut n;
+  node_calc_diff(p->m, p->o, terminal != 0, dt, x, u, ref, frames, n);
+  pack_tile(p->m.nv, n, xs_next, tile);
+  if (xnext) std::memcpy(xnext, n.xnext.data(), sizeof(double) * 2 * p->m.nv);
+  if (residuals) std::memcpy(residuals, n.residuals.data(), sizeof(double) * n.residuals.size());
+  return 0;
+}
+int orc_node_calc(void *h, int terminal, double dt, const double *x, const double *u, const double *ref,
+                  const int32_t *frames, double *xnext, double *cost, double *residuals) {
+  OrcOcp *p = static_cast<OrcOcp *>(h);
+  std::vector<double> res;
+  node_calc(p->m, p->o, terminal != 0, dt, x, u, ref, frames, xnext, *cost, &res);
+  if (residuals) std::memcpy(residuals, res.data(), sizeof(double) * res.size());
+  return 0;
+}
+
+// tiles for B instances at (xs, us): [B][T+1][TILE]
+int orc_calc_diff(void *h, const double *ref, const int32_t *frames, const double *xs, const double *us, double *tiles) {
+  OrcOcp *p = static_cast<OrcOcp *>(h);
+  const int nv = p->m.nv, nx = 2 * nv, T = p->o.T, TILE = AGX_TILE_DOUBLES(nv);
+#pragma omp parallel for schedule(dynamic)
+  for (int b = 0; b < p->B; ++b) {
+    Workspace w;
+    double c, g;
+    eval_tiles(p->m, p->o, xs + (size_t)b * (T + 1) * nx, us + (size_t)b * T * nv, ref + (size_t)b * (T + 1) * p->o.stride,
+               frames ? frames + (size_t)b * (T + 1) * AGX_MAX_ROWS : nullptr, w, c, g);
+    std::memcpy(tiles + (size_t)b * (T + 1) * TILE, w.tiles.data(), sizeof(double) * (T + 1) * TILE);
+  }
+  return 0;
+}
+
+int orc_direction(void *h, const double *tiles, double *K, double *k, double *dx, double *du, double *kkt) {
+  OrcOcp *p = static_cast<OrcOcp *>(h);
+  const int nv = p->m.nv, nx = 2 * nv, nu = nv, T = p->o.T, TILE = AGX_TILE_DOUBLES(nv);
+#pragma omp parallel for schedule(dynamic)
+  for (int b = 0; b < p->B; ++b) {
+    Direction d;
+    direction(nv, T, tiles + (size_t)b * (T + 1) * TILE, d);
+    if (K) std::memcpy(K + (size_t)b * T * nu * nx, d.K.data(), sizeof(double) * T * nu * nx);
+    if (k) std::memcpy(k + (size_t)b * T * nu, d.k.data(), sizeof(double) * T * nu);
+    if (dx) std::memcpy(dx + (size_t)b * (T + 1) * nx, d.dx.data(), sizeof(double) * (T + 1) * nx);
+    if (du) std::memcpy(du + (size_t)b * T * nu, d.du.data(), sizeof(double) * T * nu);
+    if (kkt) kkt[b] = d.kkt;
+  }
+  return 0;
+}
+
+int orc_solve(void *h, const double *ref, const int32_t *frames, const double *x0, const double *xs_ws,
+              const double *us_ws, int max_iter, double max_time, double *xs, double *us, double *K,
+              agx_status *st, int nthreads) {
+  OrcOcp *p = static_cast<OrcOcp *>(h);
+  const int nv = p->m.nv, nx = 2 * nv, nu = nv, T = p->o.T;
+  (void)nthreads;
+#pragma omp parallel for schedule(dynamic) num_threads(nthreads > 0 ? nthreads : 1)
+  for (int b = 0; b < p->B; ++b) {
+    Workspace w;
+    solve_one(p->m, p->o, ref + (size_t)b * (T + 1) * p->o.stride, frames ? frames + (size_t)b * (T + 1) * AGX_MAX_ROWS : nullptr,
+              x0 + (size_t)b * nx, xs_ws + (size_t)b * (T + 1) * nx, us_ws + (size_t)b * T * nu, max_iter, max_time,
+              xs + (size_t)b * (T + 1) * nx, us + (size_t)b * T * nu, K + (size_t)b * T * nu * nx, st + b, w);
+  }
+  return 0;
+}
+
+// WarmStartShiftPreviousSolution.shift (warm_start_shift_previous_solution.py:85-109)
+int orc_shift_warmstart(void *h, double *xs, double *us) {
+  OrcOcp *p = static_cast<OrcOcp *>(h);
+  const int nv = p->m.nv, nx = 2 * nv, nu = nv, T = p->o.T;
+  Ocp bare = p->o;
+  bare.rows[0].clear(); bare.row_off[0].clear();
+  const double dt0 = p->o.dt[0];
+  for (int b = 0; b < p->B; ++b) {
+    double *X = xs + (size_t)b * (T + 1) * nx, *U = us + (size_t)b * T * nu;
+    std::vector<double> xn(nx);
+    for (int i = 0; i < T; ++i) {
+      if (p->o.dt[i] == dt0) {
+        std::memcpy(X + (size_t)i * nx, X + (size_t)(i + 1) * nx, sizeof(double) * nx);
+        if (i < T - 1) std::memcpy(U + (size_t)i * nu, U + (size_t)(i + 1) * nu, sizeof(double) * nu);
+      } else {
+        double c;
+        node_calc(p->m, bare, false, dt0, X + (size_t)i * nx, U + (size_t)i * nu, nullptr, nullptr, xn.data(), c);
+        std::memcpy(X + (size_t)i * nx, xn.data(), sizeof(double) * nx);
+      }
+    }
+  }
+  return 0;
+}
+
+}  // extern "C"
