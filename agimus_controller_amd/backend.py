@@ -1,0 +1,260 @@
+"""Loader and thin object wrapper of libagimus_hip.so (the product path).
+
+There is no CPU fallback: if the shared library is missing, or no HIP device is
+visible, creating a `HipOcp` raises.  The CPU checker under oracle/ is never
+imported from here.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import os
+import pathlib
+import subprocess
+
+import numpy as np
+
+from . import _abi
+
+_CSRC = pathlib.Path(__file__).resolve().parent / "csrc"
+LIB_PATH = _CSRC / "libagimus_hip.so"
+_LIB = None
+
+# Every symbol include/agimus_hip.h declares (checked by the CPU test-suite).
+EXPORTED_SYMBOLS = [
+    "agx_last_error", "agx_device_count", "agx_row_nref", "agx_row_nr", "agx_ref_stride",
+    "agx_model_create", "agx_model_destroy", "agx_ocp_create", "agx_ocp_destroy", "agx_ocp_set_stream",
+    "agx_ocp_sync", "agx_ocp_set_refs", "agx_ocp_set_refs_device", "agx_ocp_solve", "agx_ocp_upload_x0",
+    "agx_ocp_upload_warmstart", "agx_ocp_solve_resident", "agx_ocp_download", "agx_ocp_download_first",
+    "agx_ocp_shift_warmstart", "agx_ocp_x0_from_prediction", "agx_ocp_integrate", "agx_model_rnea",
+    "agx_model_frame_placement", "agx_ocp_get_residuals", "agx_ocp_calc_diff", "agx_ocp_direction",
+    "agx_ocp_upload_tiles", "agx_ocp_time_kernel", "agx_traj_sine_create", "agx_traj_set_window",
+    "agx_traj_get_point", "agx_traj_warmstart_from_reference", "agx_ocp_mpc_step",
+]  # fmt: skip
+
+
+def build(force: bool = False, verbose: bool = False) -> pathlib.Path:
+    """Compile the HIP sources for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+    srcs = [_CSRC / "agimus_hip.hip", _CSRC / "agx_kernels.hpp", _CSRC / "agx_device.hpp",
+            _CSRC.parent.parent / "include" / "agimus_hip.h"]  # fmt: skip
+    if not force and LIB_PATH.exists() and LIB_PATH.stat().st_mtime >= max(s.stat().st_mtime for s in srcs):
+        return LIB_PATH
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-o", str(LIB_PATH), str(srcs[0])]
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if verbose or res.returncode != 0:
+        print(res.stdout, res.stderr)
+    if res.returncode != 0:
+        raise RuntimeError(f"hipcc failed ({res.returncode}): {res.stderr[-2000:]}")
+    return LIB_PATH
+
+
+def lib():
+    """The loaded library; raises if it has not been built."""
+    global _LIB
+    if _LIB is None:
+        if not LIB_PATH.exists():
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(the HIP path has no CPU fallback)"
+            )
+        _LIB = C.CDLL(str(LIB_PATH))
+        _LIB.agx_last_error.restype = C.c_char_p
+    return _LIB
+
+
+def device_count() -> int:
+    return int(lib().agx_device_count())
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _f8(a, shape=None):
+    a = np.ascontiguousarray(np.asarray(a, dtype=np.float64))
+    if shape is not None:
+        assert a.shape == tuple(shape), f"expected shape {tuple(shape)}, got {a.shape}"
+    return a
+
+
+class HipError(RuntimeError):
+    pass
+
+
+def _chk(rc):
+    if rc != 0:
+        raise HipError(lib().agx_last_error().decode())
+
+
+class HipOcp:
+    """Device-resident batch of B shooting problems sharing one model and cost table."""
+
+    def __init__(self, table, packed_ocp: _abi.PackedOcp, batch: int = 1, device: int = 0):
+        L = lib()
+        self.table = table
+        self.pm = _abi.PackedModel(table)
+        self.po = packed_ocp
+        self.nv = self.pm.nv
+        self.nx, self.nu = 2 * self.nv, self.nv
+        self.T, self.B = packed_ocp.horizon, int(batch)
+        self.stride = packed_ocp.stride
+        self.tile = _abi.tile_doubles(self.nv)
+        self._m = C.c_void_p()
+        self._h = C.c_void_p()
+        _chk(L.agx_model_create(C.byref(self.pm.desc), C.byref(self._m)))
+        rc = L.agx_ocp_create(self._m, C.byref(self.po.desc), self.B, int(device), C.byref(self._h))
+        if rc != 0:
+            msg = L.agx_last_error().decode()
+            L.agx_model_destroy(self._m)
+            self._m = None
+            raise HipError(msg)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().agx_ocp_destroy(self._h)
+            self._h = None
+        if getattr(self, "_m", None):
+            lib().agx_model_destroy(self._m)
+            self._m = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- references ---------------------------------------------------------
+    def set_refs(self, ref_tile, frames=None):
+        ref = _f8(ref_tile, (self.B, self.T + 1, self.stride))
+        fr = None
+        if frames is not None:
+            fr = np.ascontiguousarray(frames, dtype=np.int32)
+            assert fr.shape == (self.B, self.T + 1, _abi.AGX_MAX_ROWS)
+        _chk(lib().agx_ocp_set_refs(self._h, _p(ref), _p(fr)))
+
+    def set_stream(self, raw_stream: int):
+        _chk(lib().agx_ocp_set_stream(self._h, C.c_void_p(raw_stream)))
+
+    def sync(self):
+        _chk(lib().agx_ocp_sync(self._h))
+
+    # -- solve --------------------------------------------------------------
+    def solve(self, x0, xs_ws, us_ws, max_iter, max_time=0.0):
+        x0 = _f8(x0, (self.B, self.nx))
+        xs_ws = _f8(xs_ws, (self.B, self.T + 1, self.nx))
+        us_ws = _f8(us_ws, (self.B, self.T, self.nu))
+        xs = np.empty_like(xs_ws)
+        us = np.empty_like(us_ws)
+        K = np.empty((self.B, self.T, self.nu, self.nx))
+        st = np.zeros(self.B, dtype=_abi.STATUS_DTYPE)
+        _chk(lib().agx_ocp_solve(self._h, _p(x0), _p(xs_ws), _p(us_ws), int(max_iter), C.c_double(max_time),
+                                 _p(xs), _p(us), _p(K), _p(st)))  # fmt: skip
+        return xs, us, K, st
+
+    def upload_x0(self, x0):
+        _chk(lib().agx_ocp_upload_x0(self._h, _p(_f8(x0, (self.B, self.nx)))))
+
+    def upload_warmstart(self, xs, us):
+        xs = _f8(xs, (self.B, self.T + 1, self.nx))
+        us = _f8(us, (self.B, self.T, self.nu))
+        _chk(lib().agx_ocp_upload_warmstart(self._h, _p(xs), _p(us)))
+
+    def solve_resident(self, max_iter, max_time=0.0):
+        _chk(lib().agx_ocp_solve_resident(self._h, int(max_iter), C.c_double(max_time)))
+
+    def download(self, want_K=True):
+        xs = np.empty((self.B, self.T + 1, self.nx))
+        us = np.empty((self.B, self.T, self.nu))
+        K = np.empty((self.B, self.T, self.nu, self.nx)) if want_K else None
+        st = np.zeros(self.B, dtype=_abi.STATUS_DTYPE)
+        _chk(lib().agx_ocp_download(self._h, _p(xs), _p(us), _p(K), _p(st)))
+        return xs, us, K, st
+
+    def download_first(self, want_status=True):
+        us0 = np.empty((self.B, self.nu))
+        K0 = np.empty((self.B, self.nu, self.nx))
+        x1 = np.empty((self.B, self.nx))
+        st = np.zeros(self.B, dtype=_abi.STATUS_DTYPE) if want_status else None
+        _chk(lib().agx_ocp_download_first(self._h, _p(us0), _p(K0), _p(x1), _p(st)))
+        return us0, K0, x1, st
+
+    def shift_warmstart(self):
+        _chk(lib().agx_ocp_shift_warmstart(self._h))
+
+    def x0_from_prediction(self):
+        _chk(lib().agx_ocp_x0_from_prediction(self._h))
+
+    def integrate(self, x, u):
+        x = _f8(x).reshape(-1, self.nx)
+        u = _f8(u).reshape(-1, self.nu)
+        out = np.empty_like(x)
+        _chk(lib().agx_ocp_integrate(self._h, x.shape[0], _p(x), _p(u), _p(out)))
+        return out
+
+    def rnea(self, q, v, a):
+        q = _f8(q).reshape(-1, self.nv)
+        v = _f8(v).reshape(-1, self.nv)
+        a = _f8(a).reshape(-1, self.nv)
+        tau = np.empty_like(q)
+        _chk(lib().agx_model_rnea(self._h, q.shape[0], _p(q), _p(v), _p(a), _p(tau)))
+        return tau
+
+    def frame_placement(self, frame: int, q):
+        q = _f8(q).reshape(-1, self.nv)
+        out = np.empty((q.shape[0], 12))
+        _chk(lib().agx_model_frame_placement(self._h, q.shape[0], int(frame), _p(q), _p(out)))
+        return out
+
+    def residuals(self, row: int):
+        nr = _abi.row_nr(self.po.running[row].kind, self.nv)
+        out = np.empty((self.B, self.T, nr))
+        _chk(lib().agx_ocp_get_residuals(self._h, int(row), _p(out)))
+        return out
+
+    # -- kernel level -------------------------------------------------------
+    def calc_diff(self, want_tiles=True):
+        tiles = np.empty((self.B, self.T + 1, self.tile)) if want_tiles else None
+        _chk(lib().agx_ocp_calc_diff(self._h, _p(tiles)))
+        return tiles
+
+    def upload_tiles(self, tiles):
+        _chk(lib().agx_ocp_upload_tiles(self._h, _p(_f8(tiles, (self.B, self.T + 1, self.tile)))))
+
+    def direction(self):
+        K = np.empty((self.B, self.T, self.nu, self.nx))
+        k = np.empty((self.B, self.T, self.nu))
+        dx = np.empty((self.B, self.T + 1, self.nx))
+        du = np.empty((self.B, self.T, self.nu))
+        kkt = np.empty(self.B)
+        _chk(lib().agx_ocp_direction(self._h, _p(K), _p(k), _p(dx), _p(du), _p(kkt)))
+        return K, k, dx, du, kkt
+
+    def time_kernel(self, which: int, reps: int) -> float:
+        ms = C.c_double()
+        _chk(lib().agx_ocp_time_kernel(self._h, int(which), int(reps), C.byref(ms)))
+        return ms.value
+
+    # -- resident trajectory -------------------------------------------------
+    def sine_trajectory(self, n_points, dt, q0, amp, pulsation, scale_duration, t0, w_q, w_qdot, w_effort, w_pose, frame):
+        B, nv = self.B, self.nv
+        bc = lambda a, shape: np.ascontiguousarray(np.broadcast_to(np.asarray(a, dtype=np.float64), shape))  # noqa: E731
+        args = [bc(q0, (B, nv)), bc(amp, (B, nv)), bc(pulsation, (B, nv)), bc(scale_duration, (B, nv)), bc(t0, (B,)),
+                bc(w_q, (nv,)), bc(w_qdot, (nv,)), bc(w_effort, (nv,)), bc(w_pose, (6,))]  # fmt: skip
+        _chk(lib().agx_traj_sine_create(self._h, int(n_points), C.c_double(dt), *[_p(a) for a in args], int(frame)))
+
+    def set_window(self, k0: int):
+        _chk(lib().agx_traj_set_window(self._h, int(k0)))
+
+    def traj_point(self, k: int):
+        B, nv = self.B, self.nv
+        q, v, a, u = (np.empty((B, nv)) for _ in range(4))
+        pose = np.empty((B, 12))
+        _chk(lib().agx_traj_get_point(self._h, int(k), _p(q), _p(v), _p(a), _p(u), _p(pose)))
+        return q, v, a, u, pose
+
+    def warmstart_from_reference(self):
+        _chk(lib().agx_traj_warmstart_from_reference(self._h))
+
+    def mpc_step(self, k0: int, max_iter: int, first: bool):
+        _chk(lib().agx_ocp_mpc_step(self._h, int(k0), int(max_iter), 1 if first else 0))

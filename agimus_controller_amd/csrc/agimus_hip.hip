@@ -1,0 +1,754 @@
+// agimus_hip.hip -- C ABI of libagimus_hip.so (see include/agimus_hip.h).
+// Host-side orchestration of the gfx950 kernels in agx_kernels.hpp: device-resident
+// horizon buffers, the SQP iteration loop, warm-start shift, resident reference
+// trajectories.  No CPU fallback: every compute entry point needs a HIP device.
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "agx_kernels.hpp"
+
+namespace {
+
+thread_local std::string g_err;
+int fail(const std::string &msg) {
+  g_err = msg;
+  return -1;
+}
+#define HIPCHK(expr)                                                                                      \
+  do {                                                                                                    \
+    hipError_t e_ = (expr);                                                                               \
+    if (e_ != hipSuccess) return fail(std::string(#expr) + ": " + hipGetErrorString(e_));                \
+  } while (0)
+
+}  // namespace
+
+struct agx_model {
+  DevModel h;
+};
+
+struct agx_ocp {
+  DevModel hm;
+  DevOcp ho;
+  int nv = 0, nx = 0, nu = 0, T = 0, B = 0, tile = 0, stride = 0, device = 0;
+  bool chain = false;
+  std::vector<double> dt;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  // device buffers
+  DevModel *d_model = nullptr;
+  DevOcp *d_ocp = nullptr;
+  double *d_dt = nullptr, *d_xs = nullptr, *d_us = nullptr, *d_x0 = nullptr, *d_tiles = nullptr;
+  double *d_Kws = nullptr, *d_kws = nullptr, *d_Kout = nullptr, *d_dx = nullptr, *d_du = nullptr;
+  double *d_ref = nullptr;  // owned tile [B][T+1][stride]
+  int *d_frames = nullptr;  // owned [B][T+1][AGX_MAX_ROWS]
+  bool frames_set = false;
+  DevState *d_state = nullptr;
+  int *d_ndone = nullptr;
+  int *h_ndone = nullptr;  // pinned
+  double *d_scratch = nullptr;
+  size_t scratch_bytes = 0;
+  RefView rv{};
+  // resident trajectory
+  double *d_traj = nullptr, *d_pts = nullptr;
+  double *d_sine = nullptr;  // q0, amp, puls, scale, t0
+  int n_points = 0;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  int last_max_iter = 0;
+};
+
+namespace {
+
+int set_device(agx_ocp *o) {
+  HIPCHK(hipSetDevice(o->device));
+  return 0;
+}
+
+int ensure_scratch(agx_ocp *o, size_t bytes) {
+  if (bytes <= o->scratch_bytes) return 0;
+  if (o->d_scratch) HIPCHK(hipFree(o->d_scratch));
+  o->d_scratch = nullptr;
+  o->scratch_bytes = 0;
+  HIPCHK(hipMalloc(&o->d_scratch, bytes));
+  o->scratch_bytes = bytes;
+  return 0;
+}
+
+void fill_rows(const agx_cost_row *rows, int n, int nv, DevRows &d) {
+  std::memset(&d, 0, sizeof(d));
+  d.n = n;
+  int off = 0;
+  for (int r = 0; r < n; ++r) {
+    d.kind[r] = rows[r].kind;
+    d.act[r] = rows[r].activation;
+    d.active[r] = rows[r].active;
+    d.frame[r] = rows[r].frame;
+    d.alpha[r] = rows[r].alpha;
+    d.nref[r] = agx_row_nref(rows[r].kind, nv);
+    d.nr[r] = agx_row_nr(rows[r].kind, nv);
+    d.off[r] = off;
+    off += 1 + d.nref[r] + d.nr[r];
+  }
+}
+
+// ---- dispatch over the compiled (NV, CHAIN) instantiations --------------------
+#define AGX_FOR_NV(MACRO) MACRO(1) MACRO(2) MACRO(3) MACRO(4) MACRO(6) MACRO(7)
+
+template <typename F>
+int dispatch(int nv, bool chain, F &&f) {
+  switch (nv) {
+#define AGX_CASE(N)                                                  \
+  case N:                                                            \
+    if (chain) return f(std::integral_constant<int, N>(), std::true_type()); \
+    return f(std::integral_constant<int, N>(), std::false_type());
+    AGX_FOR_NV(AGX_CASE)
+#undef AGX_CASE
+  }
+  return fail("no kernel instantiation for nv = " + std::to_string(nv) + " (compiled: 1,2,3,4,6,7)");
+}
+
+int launch_calc_diff(agx_ocp *o, bool masked) {
+  return dispatch(o->nv, o->chain, [&](auto NVc, auto CHc) -> int {
+    constexpr int NV = decltype(NVc)::value;
+    constexpr bool CH = decltype(CHc)::value;
+    const long long units = (long long)o->B * o->T;
+    const int grid = (int)((units + 63) / 64);
+    hipLaunchKernelGGL((agx::k_calc_diff<NV, CH>), dim3(grid), dim3(64), 0, o->stream, o->d_model, o->d_ocp, o->d_dt, o->d_xs,
+                       o->d_us, o->rv, o->d_tiles, masked ? o->d_state : nullptr);
+    hipLaunchKernelGGL((agx::k_calc_diff_term<NV, CH>), dim3((o->B + 63) / 64), dim3(64), 0, o->stream, o->d_model, o->d_ocp,
+                       o->d_xs, o->rv, o->d_tiles, masked ? o->d_state : nullptr);
+    HIPCHK(hipGetLastError());
+    return 0;
+  });
+}
+
+int launch_direction(agx_ocp *o, int iter, int mode) {
+  return dispatch(o->nv, o->chain, [&](auto NVc, auto CHc) -> int {
+    constexpr int NV = decltype(NVc)::value;
+    hipLaunchKernelGGL((agx::k_direction<NV>), dim3(o->B), dim3(64), 0, o->stream, o->d_ocp, o->d_tiles, o->d_Kws, o->d_kws,
+                       o->d_Kout, o->d_dx, o->d_du, o->d_state, iter, mode, o->d_ndone);
+    HIPCHK(hipGetLastError());
+    return 0;
+  });
+}
+
+int launch_linesearch(agx_ocp *o, int iter, int max_iter) {
+  if (o->T + 1 > 512) return fail("line search kernel supports horizons up to 511 nodes");
+  return dispatch(o->nv, o->chain, [&](auto NVc, auto CHc) -> int {
+    constexpr int NV = decltype(NVc)::value;
+    constexpr bool CH = decltype(CHc)::value;
+    hipLaunchKernelGGL((agx::k_linesearch<NV, CH>), dim3(o->B), dim3(128), 0, o->stream, o->d_model, o->d_ocp, o->d_dt, o->d_xs,
+                       o->d_us, o->rv, o->d_dx, o->d_du, o->d_state, iter, max_iter, o->d_ndone);
+    HIPCHK(hipGetLastError());
+    return 0;
+  });
+}
+
+int reset_state(agx_ocp *o) {
+  hipLaunchKernelGGL(agx::k_reset_state, dim3((o->B + 255) / 256), dim3(256), 0, o->stream, o->d_state, o->B, o->d_ndone);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+// The SQP loop of SolverCSQP::solve on the resident buffers.
+int solve_resident(agx_ocp *o, int max_iter, double max_time) {
+  if (max_iter <= 0) max_iter = 1000;
+  o->last_max_iter = max_iter;
+  auto t0 = std::chrono::steady_clock::now();
+  if (reset_state(o)) return -1;
+  hipLaunchKernelGGL(agx::k_pin_x0, dim3((o->B * o->nx + 255) / 256), dim3(256), 0, o->stream, o->d_xs, o->d_x0, o->B, o->T, o->nx);
+  for (int it = 0; it < max_iter; ++it) {
+    if (launch_calc_diff(o, true)) return -1;
+    const bool last = (it + 1 == max_iter);
+    if (launch_direction(o, it, last ? 3 : 1)) return -1;
+    if (launch_linesearch(o, it, max_iter)) return -1;
+    if (last) break;
+    // early exit once every instance has finished (one 4-byte read back)
+    HIPCHK(hipMemcpyAsync(o->h_ndone, o->d_ndone, sizeof(int), hipMemcpyDeviceToHost, o->stream));
+    HIPCHK(hipStreamSynchronize(o->stream));
+    if (*o->h_ndone >= o->B) break;
+    if (max_time > 0.0) {
+      const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+      if (el > max_time) {
+        // gains of the last direction for the instances still running, then stop
+        if (launch_direction(o, it, 2)) return -1;
+        break;
+      }
+    }
+  }
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *agx_last_error(void) { return g_err.c_str(); }
+
+int agx_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int agx_row_nref(int kind, int nv) {
+  switch (kind) {
+    case AGX_RES_STATE: return 2 * nv;
+    case AGX_RES_CONTROL: return nv;
+    case AGX_RES_CONTROL_GRAV: return 0;
+    case AGX_RES_FRAME_PLACEMENT: return 12;
+    case AGX_RES_FRAME_TRANSLATION: return 3;
+    case AGX_RES_FRAME_ROTATION: return 9;
+    case AGX_RES_FRAME_VELOCITY: return 6;
+    case AGX_RES_COLLISION: return 0;
+  }
+  return -1;
+}
+int agx_row_nr(int kind, int nv) {
+  switch (kind) {
+    case AGX_RES_STATE: return 2 * nv;
+    case AGX_RES_CONTROL: return nv;
+    case AGX_RES_CONTROL_GRAV: return nv;
+    case AGX_RES_FRAME_PLACEMENT: return 6;
+    case AGX_RES_FRAME_TRANSLATION: return 3;
+    case AGX_RES_FRAME_ROTATION: return 3;
+    case AGX_RES_FRAME_VELOCITY: return 6;
+    case AGX_RES_COLLISION: return 1;
+  }
+  return -1;
+}
+int agx_ref_stride(const agx_ocp_desc *d, int nv) {
+  int s0 = 0, s1 = 0;
+  for (int r = 0; r < d->n_running_rows; ++r) s0 += 1 + agx_row_nref(d->running_rows[r].kind, nv) + agx_row_nr(d->running_rows[r].kind, nv);
+  for (int r = 0; r < d->n_terminal_rows; ++r) s1 += 1 + agx_row_nref(d->terminal_rows[r].kind, nv) + agx_row_nr(d->terminal_rows[r].kind, nv);
+  return std::max(std::max(s0, s1), 1);
+}
+
+int agx_model_create(const agx_model_desc *d, agx_model **out) {
+  if (!d || !out) return fail("agx_model_create: null argument");
+  if (d->nv < 1 || d->nv > AGX_MAX_NV) return fail("agx_model_create: nv out of range");
+  if (d->nframes < 0 || d->nframes > AGX_MAX_FRAMES) return fail("agx_model_create: too many frames");
+  agx_model *m = new agx_model();
+  DevModel &h = m->h;
+  std::memset(&h, 0, sizeof(h));
+  h.nv = d->nv;
+  h.nframes = d->nframes;
+  h.is_chain = 1;
+  for (int i = 0; i < d->nv; ++i) {
+    h.parent[i] = d->parent[i];
+    if (d->parent[i] >= i || d->parent[i] < -1) { delete m; return fail("agx_model_create: parents must precede children"); }
+    if (d->parent[i] != i - 1) h.is_chain = 0;
+    h.anc[i] = (1u << i) | (d->parent[i] >= 0 ? h.anc[d->parent[i]] : 0u);
+    std::memcpy(h.placement[i], d->placement + 12 * i, sizeof(double) * 12);
+    std::memcpy(h.axis[i], d->axis + 3 * i, sizeof(double) * 3);
+    h.mass[i] = d->mass[i];
+    std::memcpy(h.com[i], d->com + 3 * i, sizeof(double) * 3);
+    std::memcpy(h.inertia[i], d->inertia + 9 * i, sizeof(double) * 9);
+    h.armature[i] = d->armature ? d->armature[i] : 0.0;
+  }
+  h.gravity[0] = d->gravity ? d->gravity[0] : 0.0;
+  h.gravity[1] = d->gravity ? d->gravity[1] : 0.0;
+  h.gravity[2] = d->gravity ? d->gravity[2] : -9.81;
+  for (int f = 0; f < d->nframes; ++f) {
+    h.frame_parent[f] = d->frame_parent[f];
+    if (d->frame_parent[f] >= d->nv) { delete m; return fail("agx_model_create: bad frame parent"); }
+    std::memcpy(h.frame_placement[f], d->frame_placement + 12 * f, sizeof(double) * 12);
+  }
+  *out = m;
+  return 0;
+}
+void agx_model_destroy(agx_model *m) { delete m; }
+
+int agx_ocp_create(const agx_model *m, const agx_ocp_desc *d, int batch, int device, agx_ocp **out) {
+  if (!m || !d || !out) return fail("agx_ocp_create: null argument");
+  if (batch < 1) return fail("agx_ocp_create: batch must be positive");
+  if (d->horizon < 1) return fail("agx_ocp_create: horizon must be positive");
+  if (d->n_running_rows > AGX_MAX_ROWS || d->n_terminal_rows > AGX_MAX_ROWS) return fail("agx_ocp_create: too many cost rows");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail("agx_ocp_create: no HIP device available (this library has no CPU path)");
+  if (device < 0 || device >= ndev) return fail("agx_ocp_create: bad device index");
+  for (int r = 0; r < d->n_running_rows + d->n_terminal_rows; ++r) {
+    const agx_cost_row &row = r < d->n_running_rows ? d->running_rows[r] : d->terminal_rows[r - d->n_running_rows];
+    switch (row.kind) {
+      case AGX_RES_STATE: case AGX_RES_CONTROL: case AGX_RES_FRAME_PLACEMENT: case AGX_RES_FRAME_TRANSLATION: case AGX_RES_FRAME_ROTATION: break;
+      default: return fail("agx_ocp_create: residual kind " + std::to_string(row.kind) + " is not implemented on the HIP path yet");
+    }
+    if (row.activation != AGX_ACT_WEIGHTED_QUAD) return fail("agx_ocp_create: only ActivationModelWeightedQuad is implemented on the HIP path yet");
+    if ((row.kind == AGX_RES_FRAME_PLACEMENT || row.kind == AGX_RES_FRAME_TRANSLATION || row.kind == AGX_RES_FRAME_ROTATION) &&
+        (row.frame < 0 || row.frame >= m->h.nframes))
+      return fail("agx_ocp_create: frame id out of range");
+  }
+  agx_ocp *o = new agx_ocp();
+  o->hm = m->h;
+  o->nv = m->h.nv; o->nx = 2 * o->nv; o->nu = o->nv;
+  o->chain = m->h.is_chain != 0;
+  o->T = d->horizon; o->B = batch; o->device = device;
+  o->tile = AGX_TILE_DOUBLES(o->nv);
+  o->stride = agx_ref_stride(d, o->nv);
+  o->dt.assign(d->dt, d->dt + d->horizon);
+  std::memset(&o->ho, 0, sizeof(o->ho));
+  o->ho.T = o->T; o->ho.B = o->B; o->ho.stride = o->stride;
+  fill_rows(d->running_rows, d->n_running_rows, o->nv, o->ho.rows[0]);
+  fill_rows(d->terminal_rows, d->n_terminal_rows, o->nv, o->ho.rows[1]);
+  o->ho.tol = d->termination_tolerance;
+  o->ho.mu_dyn = d->mu_dynamic;
+  o->ho.mu_con = d->mu_constraint;
+  // probe that a kernel instantiation exists
+  if (dispatch(o->nv, o->chain, [](auto, auto) -> int { return 0; })) { delete o; return -1; }
+  if (set_device(o)) { delete o; return -1; }
+  const size_t B = o->B, T = o->T, nx = o->nx, nu = o->nu;
+#define ALLOC(ptr, count)                                                                                   \
+  do {                                                                                                      \
+    hipError_t e_ = hipMalloc((void **)&(ptr), sizeof(*(ptr)) * (count));                                  \
+    if (e_ != hipSuccess) { agx_ocp_destroy(o); return fail(std::string("hipMalloc " #ptr ": ") + hipGetErrorString(e_)); } \
+    (void)hipMemset((ptr), 0, sizeof(*(ptr)) * (count));                                                   \
+  } while (0)
+  ALLOC(o->d_model, 1);
+  ALLOC(o->d_ocp, 1);
+  ALLOC(o->d_dt, T);
+  ALLOC(o->d_xs, 2 * B * (T + 1) * nx);  // second half: shift staging
+  ALLOC(o->d_us, 2 * B * T * nu);
+  ALLOC(o->d_x0, B * nx);
+  ALLOC(o->d_tiles, B * (T + 1) * (size_t)o->tile);
+  ALLOC(o->d_Kws, B * T * nu * nx);
+  ALLOC(o->d_kws, B * T * nu);
+  ALLOC(o->d_Kout, B * T * nu * nx);
+  ALLOC(o->d_dx, B * (T + 1) * nx);
+  ALLOC(o->d_du, B * T * nu);
+  ALLOC(o->d_ref, B * (T + 1) * (size_t)o->stride);
+  ALLOC(o->d_frames, B * (T + 1) * AGX_MAX_ROWS);
+  ALLOC(o->d_state, B);
+  ALLOC(o->d_ndone, 1);
+#undef ALLOC
+  if (hipHostMalloc((void **)&o->h_ndone, sizeof(int)) != hipSuccess) { agx_ocp_destroy(o); return fail("hipHostMalloc failed"); }
+  if (hipMemcpy(o->d_model, &o->hm, sizeof(DevModel), hipMemcpyHostToDevice) != hipSuccess ||
+      hipMemcpy(o->d_ocp, &o->ho, sizeof(DevOcp), hipMemcpyHostToDevice) != hipSuccess ||
+      hipMemcpy(o->d_dt, o->dt.data(), sizeof(double) * T, hipMemcpyHostToDevice) != hipSuccess) {
+    agx_ocp_destroy(o);
+    return fail("agx_ocp_create: upload of the problem description failed");
+  }
+  if (hipStreamCreateWithFlags(&o->stream, hipStreamNonBlocking) != hipSuccess) { agx_ocp_destroy(o); return fail("hipStreamCreate failed"); }
+  o->own_stream = true;
+  (void)hipEventCreate(&o->ev0);
+  (void)hipEventCreate(&o->ev1);
+  o->rv.base = o->d_ref;
+  o->rv.bstride = (long long)(T + 1) * o->stride;
+  o->rv.tstride = o->stride;
+  o->rv.term_off = 0;
+  o->rv.frames = nullptr;
+  if (reset_state(o) || hipStreamSynchronize(o->stream) != hipSuccess) { agx_ocp_destroy(o); return fail("agx_ocp_create: state reset failed"); }
+  *out = o;
+  return 0;
+}
+
+void agx_ocp_destroy(agx_ocp *o) {
+  if (!o) return;
+  (void)hipSetDevice(o->device);
+  if (o->stream) (void)hipStreamSynchronize(o->stream);
+  void *ptrs[] = {o->d_model, o->d_ocp, o->d_dt, o->d_xs, o->d_us, o->d_x0, o->d_tiles, o->d_Kws, o->d_kws, o->d_Kout, o->d_dx,
+                  o->d_du, o->d_ref, o->d_frames, o->d_state, o->d_ndone, o->d_scratch, o->d_traj, o->d_pts, o->d_sine};
+  for (void *p : ptrs)
+    if (p) (void)hipFree(p);
+  if (o->h_ndone) (void)hipHostFree(o->h_ndone);
+  if (o->ev0) (void)hipEventDestroy(o->ev0);
+  if (o->ev1) (void)hipEventDestroy(o->ev1);
+  if (o->own_stream && o->stream) (void)hipStreamDestroy(o->stream);
+  delete o;
+}
+
+int agx_ocp_set_stream(agx_ocp *o, void *hip_stream) {
+  if (!o) return fail("null handle");
+  if (set_device(o)) return -1;
+  if (o->stream) HIPCHK(hipStreamSynchronize(o->stream));
+  if (hip_stream) {
+    if (o->own_stream && o->stream) (void)hipStreamDestroy(o->stream);
+    o->stream = (hipStream_t)hip_stream;
+    o->own_stream = false;
+  } else if (!o->own_stream) {
+    HIPCHK(hipStreamCreateWithFlags(&o->stream, hipStreamNonBlocking));
+    o->own_stream = true;
+  }
+  return 0;
+}
+
+int agx_ocp_sync(agx_ocp *o) {
+  if (!o) return fail("null handle");
+  if (set_device(o)) return -1;
+  HIPCHK(hipStreamSynchronize(o->stream));
+  return 0;
+}
+
+int agx_ocp_set_refs(agx_ocp *o, const double *ref_tile, const int32_t *frame_ids) {
+  if (!o || !ref_tile) return fail("agx_ocp_set_refs: null argument");
+  if (set_device(o)) return -1;
+  const size_t n = (size_t)o->B * (o->T + 1);
+  HIPCHK(hipMemcpyAsync(o->d_ref, ref_tile, sizeof(double) * n * o->stride, hipMemcpyHostToDevice, o->stream));
+  if (frame_ids) HIPCHK(hipMemcpyAsync(o->d_frames, frame_ids, sizeof(int) * n * AGX_MAX_ROWS, hipMemcpyHostToDevice, o->stream));
+  HIPCHK(hipStreamSynchronize(o->stream));  // the caller may reuse its buffers
+  o->rv.base = o->d_ref;
+  o->rv.bstride = (long long)(o->T + 1) * o->stride;
+  o->rv.tstride = o->stride;
+  o->rv.term_off = 0;
+  o->rv.frames = frame_ids ? o->d_frames : nullptr;
+  return 0;
+}
+
+int agx_ocp_set_refs_device(agx_ocp *o, const double *d_ref_tile, const int32_t *d_frame_ids, int adopt) {
+  if (!o || !d_ref_tile) return fail("agx_ocp_set_refs_device: null argument");
+  if (set_device(o)) return -1;
+  const size_t n = (size_t)o->B * (o->T + 1);
+  if (adopt) {
+    o->rv.base = d_ref_tile;
+    o->rv.frames = d_frame_ids;
+  } else {
+    HIPCHK(hipMemcpyAsync(o->d_ref, d_ref_tile, sizeof(double) * n * o->stride, hipMemcpyDeviceToDevice, o->stream));
+    if (d_frame_ids) HIPCHK(hipMemcpyAsync(o->d_frames, d_frame_ids, sizeof(int) * n * AGX_MAX_ROWS, hipMemcpyDeviceToDevice, o->stream));
+    o->rv.base = o->d_ref;
+    o->rv.frames = d_frame_ids ? o->d_frames : nullptr;
+  }
+  o->rv.bstride = (long long)(o->T + 1) * o->stride;
+  o->rv.tstride = o->stride;
+  o->rv.term_off = 0;
+  return 0;
+}
+
+int agx_ocp_upload_x0(agx_ocp *o, const double *x0) {
+  if (!o || !x0) return fail("agx_ocp_upload_x0: null argument");
+  if (set_device(o)) return -1;
+  HIPCHK(hipMemcpyAsync(o->d_x0, x0, sizeof(double) * o->B * o->nx, hipMemcpyHostToDevice, o->stream));
+  HIPCHK(hipStreamSynchronize(o->stream));
+  return 0;
+}
+
+int agx_ocp_upload_warmstart(agx_ocp *o, const double *xs_ws, const double *us_ws) {
+  if (!o || !xs_ws || !us_ws) return fail("agx_ocp_upload_warmstart: null argument");
+  if (set_device(o)) return -1;
+  HIPCHK(hipMemcpyAsync(o->d_xs, xs_ws, sizeof(double) * o->B * (o->T + 1) * o->nx, hipMemcpyHostToDevice, o->stream));
+  HIPCHK(hipMemcpyAsync(o->d_us, us_ws, sizeof(double) * o->B * o->T * o->nu, hipMemcpyHostToDevice, o->stream));
+  HIPCHK(hipStreamSynchronize(o->stream));
+  return 0;
+}
+
+int agx_ocp_solve_resident(agx_ocp *o, int max_iter, double max_time) {
+  if (!o) return fail("null handle");
+  if (set_device(o)) return -1;
+  return solve_resident(o, max_iter, max_time);
+}
+
+int agx_ocp_download(agx_ocp *o, double *xs, double *us, double *K, agx_status *st) {
+  if (!o) return fail("null handle");
+  if (set_device(o)) return -1;
+  const size_t B = o->B, T = o->T, nx = o->nx, nu = o->nu;
+  if (xs) HIPCHK(hipMemcpyAsync(xs, o->d_xs, sizeof(double) * B * (T + 1) * nx, hipMemcpyDeviceToHost, o->stream));
+  if (us) HIPCHK(hipMemcpyAsync(us, o->d_us, sizeof(double) * B * T * nu, hipMemcpyDeviceToHost, o->stream));
+  if (K) HIPCHK(hipMemcpyAsync(K, o->d_Kout, sizeof(double) * B * T * nu * nx, hipMemcpyDeviceToHost, o->stream));
+  std::vector<DevState> hs;
+  if (st) {
+    hs.resize(B);
+    HIPCHK(hipMemcpyAsync(hs.data(), o->d_state, sizeof(DevState) * B, hipMemcpyDeviceToHost, o->stream));
+  }
+  HIPCHK(hipStreamSynchronize(o->stream));
+  if (st)
+    for (size_t b = 0; b < B; ++b) {
+      st[b].kkt = hs[b].kkt; st[b].cost = hs[b].cost; st[b].merit = hs[b].merit; st[b].gap_norm = hs[b].gap;
+      st[b].iter = hs[b].done ? hs[b].iter : o->last_max_iter;
+      st[b].qp_iters = hs[b].qp_iters; st[b].solved = hs[b].solved; st[b].flags = hs[b].flags;
+    }
+  return 0;
+}
+
+int agx_ocp_download_first(agx_ocp *o, double *us0, double *K0, double *x1, agx_status *st) {
+  if (!o) return fail("null handle");
+  if (set_device(o)) return -1;
+  const size_t B = o->B, T = o->T, nx = o->nx, nu = o->nu;
+  if (us0) HIPCHK(hipMemcpy2DAsync(us0, sizeof(double) * nu, o->d_us, sizeof(double) * T * nu, sizeof(double) * nu, B, hipMemcpyDeviceToHost, o->stream));
+  if (K0) HIPCHK(hipMemcpy2DAsync(K0, sizeof(double) * nu * nx, o->d_Kout, sizeof(double) * T * nu * nx, sizeof(double) * nu * nx, B, hipMemcpyDeviceToHost, o->stream));
+  if (x1) HIPCHK(hipMemcpy2DAsync(x1, sizeof(double) * nx, o->d_xs + nx, sizeof(double) * (T + 1) * nx, sizeof(double) * nx, B, hipMemcpyDeviceToHost, o->stream));
+  if (st) return agx_ocp_download(o, nullptr, nullptr, nullptr, st);
+  HIPCHK(hipStreamSynchronize(o->stream));
+  return 0;
+}
+
+int agx_ocp_solve(agx_ocp *o, const double *x0, const double *xs_ws, const double *us_ws, int max_iter, double max_time,
+                  double *xs, double *us, double *K, agx_status *st) {
+  if (!o || !x0 || !xs_ws || !us_ws) return fail("agx_ocp_solve: null argument");
+  if (agx_ocp_upload_x0(o, x0)) return -1;
+  if (agx_ocp_upload_warmstart(o, xs_ws, us_ws)) return -1;
+  if (solve_resident(o, max_iter, max_time)) return -1;
+  return agx_ocp_download(o, xs, us, K, st);
+}
+
+int agx_ocp_shift_warmstart(agx_ocp *o) {
+  if (!o) return fail("null handle");
+  if (set_device(o)) return -1;
+  return dispatch(o->nv, o->chain, [&](auto NVc, auto CHc) -> int {
+    constexpr int NV = decltype(NVc)::value;
+    constexpr bool CH = decltype(CHc)::value;
+    const long long units = (long long)o->B * o->T;
+    hipLaunchKernelGGL((agx::k_shift<NV, CH>), dim3((int)((units + 63) / 64)), dim3(64), 0, o->stream, o->d_model, o->d_ocp, o->d_dt, o->d_xs, o->d_us);
+    const long long n = (long long)o->B * (o->T + 1) * o->nx;
+    hipLaunchKernelGGL(agx::k_shift_commit, dim3((int)((n + 255) / 256)), dim3(256), 0, o->stream, o->d_xs, o->d_us, o->B, o->T, o->nx, o->nu);
+    HIPCHK(hipGetLastError());
+    return 0;
+  });
+}
+
+int agx_ocp_x0_from_prediction(agx_ocp *o) {
+  if (!o) return fail("null handle");
+  if (set_device(o)) return -1;
+  hipLaunchKernelGGL(agx::k_x0_from_pred, dim3((o->B * o->nx + 255) / 256), dim3(256), 0, o->stream, o->d_x0, o->d_xs, o->B, o->T, o->nx);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+int agx_ocp_integrate(agx_ocp *o, int n, const double *x, const double *u, double *xnext) {
+  if (!o || !x || !u || !xnext || n < 1) return fail("agx_ocp_integrate: bad argument");
+  if (set_device(o)) return -1;
+  const size_t bytes = sizeof(double) * n * (2 * o->nx + o->nu);
+  if (ensure_scratch(o, bytes)) return -1;
+  double *dx = o->d_scratch, *du = dx + (size_t)n * o->nx, *dn = du + (size_t)n * o->nu;
+  HIPCHK(hipMemcpyAsync(dx, x, sizeof(double) * n * o->nx, hipMemcpyHostToDevice, o->stream));
+  HIPCHK(hipMemcpyAsync(du, u, sizeof(double) * n * o->nu, hipMemcpyHostToDevice, o->stream));
+  int rc = dispatch(o->nv, o->chain, [&](auto NVc, auto CHc) -> int {
+    constexpr int NV = decltype(NVc)::value;
+    constexpr bool CH = decltype(CHc)::value;
+    hipLaunchKernelGGL((agx::k_integrate<NV, CH>), dim3((n + 63) / 64), dim3(64), 0, o->stream, o->d_model, o->dt[0], n, dx, du, dn);
+    HIPCHK(hipGetLastError());
+    return 0;
+  });
+  if (rc) return rc;
+  HIPCHK(hipMemcpyAsync(xnext, dn, sizeof(double) * n * o->nx, hipMemcpyDeviceToHost, o->stream));
+  HIPCHK(hipStreamSynchronize(o->stream));
+  return 0;
+}
+
+int agx_model_rnea(agx_ocp *o, int n, const double *q, const double *v, const double *a, double *tau) {
+  if (!o || !q || !v || !a || !tau || n < 1) return fail("agx_model_rnea: bad argument");
+  if (set_device(o)) return -1;
+  const size_t cnt = (size_t)n * o->nv;
+  if (ensure_scratch(o, sizeof(double) * 4 * cnt)) return -1;
+  double *dq = o->d_scratch, *dv = dq + cnt, *da = dv + cnt, *dt = da + cnt;
+  HIPCHK(hipMemcpyAsync(dq, q, sizeof(double) * cnt, hipMemcpyHostToDevice, o->stream));
+  HIPCHK(hipMemcpyAsync(dv, v, sizeof(double) * cnt, hipMemcpyHostToDevice, o->stream));
+  HIPCHK(hipMemcpyAsync(da, a, sizeof(double) * cnt, hipMemcpyHostToDevice, o->stream));
+  int rc = dispatch(o->nv, o->chain, [&](auto NVc, auto CHc) -> int {
+    constexpr int NV = decltype(NVc)::value;
+    constexpr bool CH = decltype(CHc)::value;
+    hipLaunchKernelGGL((agx::k_rnea<NV, CH>), dim3((n + 63) / 64), dim3(64), 0, o->stream, o->d_model, n, dq, dv, da, dt);
+    HIPCHK(hipGetLastError());
+    return 0;
+  });
+  if (rc) return rc;
+  HIPCHK(hipMemcpyAsync(tau, dt, sizeof(double) * cnt, hipMemcpyDeviceToHost, o->stream));
+  HIPCHK(hipStreamSynchronize(o->stream));
+  return 0;
+}
+
+int agx_model_frame_placement(agx_ocp *o, int n, int frame, const double *q, double *out) {
+  if (!o || !q || !out || n < 1) return fail("agx_model_frame_placement: bad argument");
+  if (frame < 0 || frame >= o->hm.nframes) return fail("agx_model_frame_placement: frame id out of range");
+  if (set_device(o)) return -1;
+  const size_t cnt = (size_t)n * o->nv;
+  if (ensure_scratch(o, sizeof(double) * (cnt + (size_t)n * 12))) return -1;
+  double *dq = o->d_scratch, *dout = dq + cnt;
+  HIPCHK(hipMemcpyAsync(dq, q, sizeof(double) * cnt, hipMemcpyHostToDevice, o->stream));
+  int rc = dispatch(o->nv, o->chain, [&](auto NVc, auto CHc) -> int {
+    constexpr int NV = decltype(NVc)::value;
+    constexpr bool CH = decltype(CHc)::value;
+    hipLaunchKernelGGL((agx::k_frame<NV, CH>), dim3((n + 63) / 64), dim3(64), 0, o->stream, o->d_model, n, frame, dq, dout);
+    HIPCHK(hipGetLastError());
+    return 0;
+  });
+  if (rc) return rc;
+  HIPCHK(hipMemcpyAsync(out, dout, sizeof(double) * n * 12, hipMemcpyDeviceToHost, o->stream));
+  HIPCHK(hipStreamSynchronize(o->stream));
+  return 0;
+}
+
+int agx_ocp_get_residuals(agx_ocp *o, int row, double *out) {
+  if (!o || !out) return fail("agx_ocp_get_residuals: null argument");
+  if (row < 0 || row >= o->ho.rows[0].n) return fail("agx_ocp_get_residuals: row out of range");
+  if (set_device(o)) return -1;
+  const int nr = o->ho.rows[0].nr[row];
+  const size_t cnt = (size_t)o->B * o->T * nr;
+  if (ensure_scratch(o, sizeof(double) * cnt)) return -1;
+  int rc = dispatch(o->nv, o->chain, [&](auto NVc, auto CHc) -> int {
+    constexpr int NV = decltype(NVc)::value;
+    constexpr bool CH = decltype(CHc)::value;
+    const long long units = (long long)o->B * o->T;
+    hipLaunchKernelGGL((agx::k_residuals<NV, CH>), dim3((int)((units + 63) / 64)), dim3(64), 0, o->stream, o->d_model, o->d_ocp, o->d_xs, o->d_us, o->rv, row, o->d_scratch);
+    HIPCHK(hipGetLastError());
+    return 0;
+  });
+  if (rc) return rc;
+  HIPCHK(hipMemcpyAsync(out, o->d_scratch, sizeof(double) * cnt, hipMemcpyDeviceToHost, o->stream));
+  HIPCHK(hipStreamSynchronize(o->stream));
+  return 0;
+}
+
+int agx_ocp_calc_diff(agx_ocp *o, double *tiles) {
+  if (!o) return fail("null handle");
+  if (set_device(o)) return -1;
+  if (launch_calc_diff(o, false)) return -1;
+  if (tiles) HIPCHK(hipMemcpyAsync(tiles, o->d_tiles, sizeof(double) * o->B * (o->T + 1) * (size_t)o->tile, hipMemcpyDeviceToHost, o->stream));
+  HIPCHK(hipStreamSynchronize(o->stream));
+  return 0;
+}
+
+int agx_ocp_upload_tiles(agx_ocp *o, const double *tiles) {
+  if (!o || !tiles) return fail("agx_ocp_upload_tiles: null argument");
+  if (set_device(o)) return -1;
+  HIPCHK(hipMemcpyAsync(o->d_tiles, tiles, sizeof(double) * o->B * (o->T + 1) * (size_t)o->tile, hipMemcpyHostToDevice, o->stream));
+  HIPCHK(hipStreamSynchronize(o->stream));
+  return 0;
+}
+
+int agx_ocp_direction(agx_ocp *o, double *K, double *k, double *dx, double *du, double *kkt) {
+  if (!o) return fail("null handle");
+  if (set_device(o)) return -1;
+  if (reset_state(o)) return -1;
+  if (launch_direction(o, 0, 3)) return -1;
+  const size_t B = o->B, T = o->T, nx = o->nx, nu = o->nu;
+  if (K) HIPCHK(hipMemcpyAsync(K, o->d_Kout, sizeof(double) * B * T * nu * nx, hipMemcpyDeviceToHost, o->stream));
+  if (k) HIPCHK(hipMemcpyAsync(k, o->d_kws, sizeof(double) * B * T * nu, hipMemcpyDeviceToHost, o->stream));
+  if (dx) HIPCHK(hipMemcpyAsync(dx, o->d_dx, sizeof(double) * B * (T + 1) * nx, hipMemcpyDeviceToHost, o->stream));
+  if (du) HIPCHK(hipMemcpyAsync(du, o->d_du, sizeof(double) * B * T * nu, hipMemcpyDeviceToHost, o->stream));
+  std::vector<DevState> hs(B);
+  HIPCHK(hipMemcpyAsync(hs.data(), o->d_state, sizeof(DevState) * B, hipMemcpyDeviceToHost, o->stream));
+  HIPCHK(hipStreamSynchronize(o->stream));
+  if (kkt) for (size_t b = 0; b < B; ++b) kkt[b] = hs[b].kkt;
+  return 0;
+}
+
+int agx_ocp_time_kernel(agx_ocp *o, int which, int reps, double *avg_ms) {
+  if (!o || !avg_ms || reps < 1) return fail("agx_ocp_time_kernel: bad argument");
+  if (set_device(o)) return -1;
+  // warm-up launch, then `reps` timed launches bracketed by events on the problem's stream
+  for (int pass = 0; pass < 2; ++pass) {
+    const int n = pass == 0 ? 1 : reps;
+    if (pass == 1) HIPCHK(hipEventRecord(o->ev0, o->stream));
+    for (int r = 0; r < n; ++r) {
+      int rc = 0;
+      if (which == 0) rc = launch_calc_diff(o, false);
+      else if (which == 1) { if (reset_state(o)) return -1; rc = launch_direction(o, 0, 1); }
+      else if (which == 2) rc = launch_linesearch(o, 0, 1000000);
+      else return fail("agx_ocp_time_kernel: unknown kernel");
+      if (rc) return rc;
+    }
+    if (pass == 1) HIPCHK(hipEventRecord(o->ev1, o->stream));
+    HIPCHK(hipStreamSynchronize(o->stream));
+  }
+  float ms = 0.f;
+  HIPCHK(hipEventElapsedTime(&ms, o->ev0, o->ev1));
+  *avg_ms = (double)ms / reps;
+  return 0;
+}
+
+int agx_traj_sine_create(agx_ocp *o, int n_points, double dt, const double *q0, const double *amp, const double *pulsation,
+                         const double *scale_duration, const double *t0, const double *w_q, const double *w_qdot,
+                         const double *w_effort, const double *w_pose, int frame) {
+  if (!o || !q0 || !amp || !pulsation || !scale_duration || !t0 || !w_q || !w_qdot || !w_effort || !w_pose)
+    return fail("agx_traj_sine_create: null argument");
+  if (n_points < o->T + 1) return fail("agx_traj_sine_create: need at least T+1 samples");
+  if (frame < 0 || frame >= o->hm.nframes) return fail("agx_traj_sine_create: frame id out of range");
+  if (set_device(o)) return -1;
+  const size_t B = o->B, nv = o->nv;
+  if (o->d_traj) { (void)hipFree(o->d_traj); o->d_traj = nullptr; }
+  if (o->d_pts) { (void)hipFree(o->d_pts); o->d_pts = nullptr; }
+  if (o->d_sine) { (void)hipFree(o->d_sine); o->d_sine = nullptr; }
+  HIPCHK(hipMalloc((void **)&o->d_traj, sizeof(double) * B * n_points * 2 * o->stride));
+  HIPCHK(hipMalloc((void **)&o->d_pts, sizeof(double) * B * n_points * (4 * nv + 12)));
+  HIPCHK(hipMalloc((void **)&o->d_sine, sizeof(double) * (4 * B * nv + B)));
+  double *d = o->d_sine;
+  HIPCHK(hipMemcpyAsync(d, q0, sizeof(double) * B * nv, hipMemcpyHostToDevice, o->stream));
+  HIPCHK(hipMemcpyAsync(d + B * nv, amp, sizeof(double) * B * nv, hipMemcpyHostToDevice, o->stream));
+  HIPCHK(hipMemcpyAsync(d + 2 * B * nv, pulsation, sizeof(double) * B * nv, hipMemcpyHostToDevice, o->stream));
+  HIPCHK(hipMemcpyAsync(d + 3 * B * nv, scale_duration, sizeof(double) * B * nv, hipMemcpyHostToDevice, o->stream));
+  HIPCHK(hipMemcpyAsync(d + 4 * B * nv, t0, sizeof(double) * B, hipMemcpyHostToDevice, o->stream));
+  agx::SineParams sp;
+  std::memset(&sp, 0, sizeof(sp));
+  sp.q0 = d; sp.amp = d + B * nv; sp.puls = d + 2 * B * nv; sp.scale = d + 3 * B * nv; sp.t0 = d + 4 * B * nv;
+  for (size_t i = 0; i < nv; ++i) { sp.w_q[i] = w_q[i]; sp.w_qdot[i] = w_qdot[i]; sp.w_effort[i] = w_effort[i]; }
+  for (int i = 0; i < 6; ++i) sp.w_pose[i] = w_pose[i];
+  sp.dt = dt; sp.n_points = n_points; sp.frame = frame;
+  o->n_points = n_points;
+  int rc = dispatch(o->nv, o->chain, [&](auto NVc, auto CHc) -> int {
+    constexpr int NV = decltype(NVc)::value;
+    constexpr bool CH = decltype(CHc)::value;
+    const long long units = (long long)B * n_points;
+    hipLaunchKernelGGL((agx::k_sine_fill<NV, CH>), dim3((int)((units + 63) / 64)), dim3(64), 0, o->stream, o->d_model, o->d_ocp, sp, o->d_traj, o->d_pts);
+    HIPCHK(hipGetLastError());
+    return 0;
+  });
+  if (rc) return rc;
+  HIPCHK(hipStreamSynchronize(o->stream));
+  return agx_traj_set_window(o, 0);
+}
+
+int agx_traj_set_window(agx_ocp *o, int k0) {
+  if (!o) return fail("null handle");
+  if (!o->d_traj) return fail("agx_traj_set_window: no resident trajectory");
+  if (k0 < 0 || k0 + o->T + 1 > o->n_points) return fail("agx_traj_set_window: window leaves the trajectory");
+  o->rv.base = o->d_traj + (long long)k0 * 2 * o->stride;
+  o->rv.bstride = (long long)o->n_points * 2 * o->stride;
+  o->rv.tstride = 2 * o->stride;
+  o->rv.term_off = o->stride;
+  o->rv.frames = nullptr;
+  return 0;
+}
+
+int agx_traj_get_point(agx_ocp *o, int k, double *q, double *v, double *a, double *u, double *pose) {
+  if (!o || !o->d_pts) return fail("agx_traj_get_point: no resident trajectory");
+  if (k < 0 || k >= o->n_points) return fail("agx_traj_get_point: sample out of range");
+  if (set_device(o)) return -1;
+  const size_t B = o->B, nv = o->nv, w = 4 * nv + 12;
+  std::vector<double> h(B * w);
+  HIPCHK(hipMemcpy2DAsync(h.data(), sizeof(double) * w, o->d_pts + (size_t)k * w, sizeof(double) * o->n_points * w, sizeof(double) * w, B, hipMemcpyDeviceToHost, o->stream));
+  HIPCHK(hipStreamSynchronize(o->stream));
+  for (size_t b = 0; b < B; ++b) {
+    const double *p = &h[b * w];
+    if (q) std::memcpy(q + b * nv, p, sizeof(double) * nv);
+    if (v) std::memcpy(v + b * nv, p + nv, sizeof(double) * nv);
+    if (a) std::memcpy(a + b * nv, p + 2 * nv, sizeof(double) * nv);
+    if (u) std::memcpy(u + b * nv, p + 3 * nv, sizeof(double) * nv);
+    if (pose) std::memcpy(pose + b * 12, p + 4 * nv, sizeof(double) * 12);
+  }
+  return 0;
+}
+
+static int ws_from_ref(agx_ocp *o, int k0, int set_x0) {
+  const long long units = (long long)o->B * (o->T + 1);
+  hipLaunchKernelGGL(agx::k_ws_from_ref, dim3((int)((units + 255) / 256)), dim3(256), 0, o->stream, o->d_xs, o->d_us, o->d_x0, o->d_pts,
+                     o->B, o->T, o->nv, o->n_points, k0, set_x0);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+int agx_traj_warmstart_from_reference(agx_ocp *o) {
+  if (!o || !o->d_pts) return fail("agx_traj_warmstart_from_reference: no resident trajectory");
+  if (set_device(o)) return -1;
+  const int k0 = (int)((o->rv.base - o->d_traj) / (2 * o->stride));
+  return ws_from_ref(o, k0, 1);
+}
+
+int agx_ocp_mpc_step(agx_ocp *o, int k0, int max_iter, int first) {
+  if (!o) return fail("null handle");
+  if (set_device(o)) return -1;
+  if (agx_traj_set_window(o, k0)) return -1;
+  if (first) {
+    if (ws_from_ref(o, k0, 1)) return -1;
+  } else {
+    if (agx_ocp_x0_from_prediction(o)) return -1;
+    if (agx_ocp_shift_warmstart(o)) return -1;
+  }
+  return solve_resident(o, max_iter, 0.0);
+}
+
+}  // extern "C"

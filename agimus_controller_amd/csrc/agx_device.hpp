@@ -1,0 +1,783 @@
+// agx_device.hpp -- device-side rigid-body dynamics and shooting-node evaluation
+// for gfx950 (MI355X).  Hand-derived world-frame analytical derivatives; the CPU
+// checker under oracle/ uses link-local recursions + automatic differentiation
+// instead, so the two share no derivation.
+//
+// What this replaces (third-party, reached through Python bindings upstream):
+//   pinocchio computeAllTerms / Cholesky Minv / computeRNEADerivatives / frame
+//   Jacobians / log6 / Jlog6, and crocoddyl DifferentialActionModelFreeFwdDynamics
+//   + IntegratedActionModelEuler + CostModelSum (ocp_croco_generic.py:688-711,743-745).
+//
+// Spatial vectors are [linear(3); angular(3)], expressed in the WORLD frame.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/agimus_hip.h"
+
+#define AGX_MAX_FRAMES 72
+
+struct DevModel {
+  int nv, nframes, is_chain, pad;
+  int parent[AGX_MAX_NV];
+  unsigned anc[AGX_MAX_NV];  // bit j: joint j is i itself or an ancestor of i
+  double placement[AGX_MAX_NV][12];
+  double axis[AGX_MAX_NV][3];
+  double mass[AGX_MAX_NV];
+  double com[AGX_MAX_NV][3];
+  double inertia[AGX_MAX_NV][9];
+  double armature[AGX_MAX_NV];
+  double gravity[3];
+  int frame_parent[AGX_MAX_FRAMES];
+  double frame_placement[AGX_MAX_FRAMES][12];
+};
+
+struct DevRows {
+  int n;
+  int kind[AGX_MAX_ROWS], act[AGX_MAX_ROWS], active[AGX_MAX_ROWS], frame[AGX_MAX_ROWS];
+  int off[AGX_MAX_ROWS], nref[AGX_MAX_ROWS], nr[AGX_MAX_ROWS];
+  double alpha[AGX_MAX_ROWS];
+};
+
+struct DevOcp {
+  int T, B, stride, pad;
+  DevRows rows[2];  // 0 running, 1 terminal
+  double tol, mu_dyn, mu_con;
+};
+
+#define AGX_DEV __device__ __forceinline__
+#define AGX_UNROLL(NV) _Pragma("unroll")
+
+namespace agx {
+
+// ------------------------------------------------------------------ 3-vectors
+AGX_DEV void cross3(const double *a, const double *b, double *c) {
+  double c0 = a[1] * b[2] - a[2] * b[1];
+  double c1 = a[2] * b[0] - a[0] * b[2];
+  double c2 = a[0] * b[1] - a[1] * b[0];
+  c[0] = c0; c[1] = c1; c[2] = c2;
+}
+AGX_DEV double dot3(const double *a, const double *b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+AGX_DEV double dot6(const double *a, const double *b) { return dot3(a, b) + dot3(a + 3, b + 3); }
+AGX_DEV void mv3(const double *R, const double *x, double *y) {
+  double y0 = R[0] * x[0] + R[1] * x[1] + R[2] * x[2];
+  double y1 = R[3] * x[0] + R[4] * x[1] + R[5] * x[2];
+  double y2 = R[6] * x[0] + R[7] * x[1] + R[8] * x[2];
+  y[0] = y0; y[1] = y1; y[2] = y2;
+}
+AGX_DEV void mtv3(const double *R, const double *x, double *y) {
+  double y0 = R[0] * x[0] + R[3] * x[1] + R[6] * x[2];
+  double y1 = R[1] * x[0] + R[4] * x[1] + R[7] * x[2];
+  double y2 = R[2] * x[0] + R[5] * x[1] + R[8] * x[2];
+  y[0] = y0; y[1] = y1; y[2] = y2;
+}
+AGX_DEV void mm3(const double *A, const double *B, double *C) {
+  double t[9];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) t[3 * i + j] = A[3 * i] * B[j] + A[3 * i + 1] * B[3 + j] + A[3 * i + 2] * B[6 + j];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) C[i] = t[i];
+}
+// C = A^T B
+AGX_DEV void mtm3(const double *A, const double *B, double *C) {
+  double t[9];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) t[3 * i + j] = A[i] * B[j] + A[3 + i] * B[3 + j] + A[6 + i] * B[6 + j];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) C[i] = t[i];
+}
+
+// ------------------------------------------------------------ spatial algebra
+// motion cross product  m1 x m2
+AGX_DEV void mcross(const double *a, const double *b, double *c) {
+  double t1[3], t2[3], t3[3];
+  cross3(a + 3, b, t1);
+  cross3(a, b + 3, t2);
+  cross3(a + 3, b + 3, t3);
+  c[0] = t1[0] + t2[0]; c[1] = t1[1] + t2[1]; c[2] = t1[2] + t2[2];
+  c[3] = t3[0]; c[4] = t3[1]; c[5] = t3[2];
+}
+// force cross product  m x* f
+AGX_DEV void fcross(const double *m, const double *f, double *c) {
+  double t1[3], t2[3], t3[3];
+  cross3(m + 3, f, t1);
+  cross3(m + 3, f + 3, t2);
+  cross3(m, f, t3);
+  c[0] = t1[0]; c[1] = t1[1]; c[2] = t1[2];
+  c[3] = t2[0] + t3[0]; c[4] = t2[1] + t3[1]; c[5] = t2[2] + t3[2];
+}
+// rigid inertia about the world origin: I = {m, h[3], Ixx,Ixy,Ixz,Iyy,Iyz,Izz}
+AGX_DEV void iapply(const double *I, const double *mot, double *f) {
+  const double m = I[0];
+  const double *h = I + 1;
+  double hxw[3], hxv[3];
+  cross3(h, mot + 3, hxw);
+  cross3(h, mot, hxv);
+  const double *w = mot + 3;
+  f[0] = m * mot[0] - hxw[0];
+  f[1] = m * mot[1] - hxw[1];
+  f[2] = m * mot[2] - hxw[2];
+  f[3] = hxv[0] + I[4] * w[0] + I[5] * w[1] + I[6] * w[2];
+  f[4] = hxv[1] + I[5] * w[0] + I[7] * w[1] + I[8] * w[2];
+  f[5] = hxv[2] + I[6] * w[0] + I[8] * w[1] + I[9] * w[2];
+}
+
+// ------------------------------------------------------------------ kinematics
+template <int NV>
+struct Kin {
+  double R[NV][9];  // world rotation of joint frame
+  double p[NV][3];  // world position of joint origin
+  double S[NV][6];  // world joint axis (p x z ; z)
+};
+
+template <int NV, bool CHAIN>
+AGX_DEV int parent_of(const DevModel &m, int i) { return CHAIN ? i - 1 : m.parent[i]; }
+template <int NV, bool CHAIN>
+AGX_DEV bool is_anc(const DevModel &m, int i, int j) {  // j ancestor-or-self of i
+  return CHAIN ? (j <= i) : ((m.anc[i] >> j) & 1u);
+}
+
+template <int NV, bool CHAIN>
+AGX_DEV void kinematics(const DevModel &m, const double *q, Kin<NV> &k) {
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const double *ax = m.axis[i];
+    double s, c;
+    sincos(q[i], &s, &c);
+    const double omc = 1.0 - c;
+    double Rq[9];
+    Rq[0] = c + omc * ax[0] * ax[0];
+    Rq[1] = omc * ax[0] * ax[1] - s * ax[2];
+    Rq[2] = omc * ax[0] * ax[2] + s * ax[1];
+    Rq[3] = omc * ax[1] * ax[0] + s * ax[2];
+    Rq[4] = c + omc * ax[1] * ax[1];
+    Rq[5] = omc * ax[1] * ax[2] - s * ax[0];
+    Rq[6] = omc * ax[2] * ax[0] - s * ax[1];
+    Rq[7] = omc * ax[2] * ax[1] + s * ax[0];
+    Rq[8] = c + omc * ax[2] * ax[2];
+    double Rl[9];
+    mm3(m.placement[i], Rq, Rl);
+    const int par = parent_of<NV, CHAIN>(m, i);
+    if (par >= 0) {
+      mm3(k.R[par], Rl, k.R[i]);
+      double t[3];
+      mv3(k.R[par], &m.placement[i][9], t);
+      k.p[i][0] = k.p[par][0] + t[0]; k.p[i][1] = k.p[par][1] + t[1]; k.p[i][2] = k.p[par][2] + t[2];
+    } else {
+#pragma unroll
+      for (int e = 0; e < 9; ++e) k.R[i][e] = Rl[e];
+      k.p[i][0] = m.placement[i][9]; k.p[i][1] = m.placement[i][10]; k.p[i][2] = m.placement[i][11];
+    }
+    double z[3];
+    mv3(k.R[i], ax, z);
+    cross3(k.p[i], z, k.S[i]);
+    k.S[i][3] = z[0]; k.S[i][4] = z[1]; k.S[i][5] = z[2];
+  }
+}
+
+// world inertia of the body carried by joint i
+template <int NV>
+AGX_DEV void body_inertia(const DevModel &m, const Kin<NV> &k, int i, double *I) {
+  double c[3];
+  mv3(k.R[i], m.com[i], c);
+  c[0] += k.p[i][0]; c[1] += k.p[i][1]; c[2] += k.p[i][2];
+  const double ms = m.mass[i];
+  double T[9], Iw[9];
+  mm3(k.R[i], m.inertia[i], T);
+  // Iw = T R^T
+#pragma unroll
+  for (int a = 0; a < 3; ++a)
+#pragma unroll
+    for (int b = 0; b < 3; ++b) Iw[3 * a + b] = T[3 * a] * k.R[i][3 * b] + T[3 * a + 1] * k.R[i][3 * b + 1] + T[3 * a + 2] * k.R[i][3 * b + 2];
+  const double cc = dot3(c, c);
+  I[0] = ms;
+  I[1] = ms * c[0]; I[2] = ms * c[1]; I[3] = ms * c[2];
+  I[4] = Iw[0] + ms * (cc - c[0] * c[0]);
+  I[5] = 0.5 * (Iw[1] + Iw[3]) - ms * c[0] * c[1];
+  I[6] = 0.5 * (Iw[2] + Iw[6]) - ms * c[0] * c[2];
+  I[7] = Iw[4] + ms * (cc - c[1] * c[1]);
+  I[8] = 0.5 * (Iw[5] + Iw[7]) - ms * c[1] * c[2];
+  I[9] = Iw[8] + ms * (cc - c[2] * c[2]);
+}
+
+// State carried between the two dynamics passes.
+template <int NV>
+struct Dyn {
+  double v[NV][6];    // spatial velocity
+  double Sd[NV][6];   // dS/dt = v x S
+  double Ib[NV][10];  // body inertia (world)
+  double Ic[NV][10];  // composite inertia (after crba)
+  double a0[NV][6];   // bias acceleration (qdd = 0), includes gravity
+};
+
+// Pass A: bias torques nle = C v + g (RNEA with qdd = 0) and joint-space inertia
+// M (CRBA), both in the world frame.  M gets the armature on its diagonal.
+template <int NV, bool CHAIN>
+AGX_DEV void bias_and_inertia(const DevModel &m, const Kin<NV> &k, const double *qd, Dyn<NV> &d, double *nle, double (*M)[NV]) {
+  double f[NV][6];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int par = parent_of<NV, CHAIN>(m, i);
+#pragma unroll
+    for (int e = 0; e < 6; ++e) d.v[i][e] = (par >= 0 ? d.v[par][e] : 0.0) + k.S[i][e] * qd[i];
+    mcross(d.v[i], k.S[i], d.Sd[i]);
+#pragma unroll
+    for (int e = 0; e < 6; ++e) d.a0[i][e] = (par >= 0 ? d.a0[par][e] : (e < 3 ? -m.gravity[e] : 0.0)) + d.Sd[i][e] * qd[i];
+    body_inertia<NV>(m, k, i, d.Ib[i]);
+#pragma unroll
+    for (int e = 0; e < 10; ++e) d.Ic[i][e] = d.Ib[i][e];
+    double h[6], g[6], x[6];
+    iapply(d.Ib[i], d.v[i], h);
+    iapply(d.Ib[i], d.a0[i], g);
+    fcross(d.v[i], h, x);
+#pragma unroll
+    for (int e = 0; e < 6; ++e) f[i][e] = g[e] + x[e];
+  }
+#pragma unroll
+  for (int i = NV - 1; i >= 0; --i) {
+    nle[i] = dot6(k.S[i], f[i]);
+    double m6[6];
+    iapply(d.Ic[i], k.S[i], m6);
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      if (j <= i || !CHAIN) {
+        if (j == i) {
+          M[i][i] = dot6(k.S[i], m6) + m.armature[i];
+        } else if (is_anc<NV, CHAIN>(m, i, j)) {
+          const double val = dot6(k.S[j], m6);
+          M[i][j] = val;
+          M[j][i] = val;
+        } else if (!CHAIN && !is_anc<NV, CHAIN>(m, j, i)) {
+          M[i][j] = 0.0;  // different branches
+        }
+      }
+    }
+    const int par = parent_of<NV, CHAIN>(m, i);
+    if (par >= 0) {
+#pragma unroll
+      for (int e = 0; e < 6; ++e) f[par][e] += f[i][e];
+#pragma unroll
+      for (int e = 0; e < 10; ++e) d.Ic[par][e] += d.Ic[i][e];
+    }
+  }
+}
+
+// In-place lower Cholesky of a dense NV x NV SPD matrix (registers), then
+// explicit inverse Minv = L^-T L^-1.
+template <int NV>
+AGX_DEV void spd_inverse(double (*A)[NV], double (*Ainv)[NV]) {
+  double Li[NV][NV];  // L^-1 (lower)
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    double dd = A[j][j];
+#pragma unroll
+    for (int kk = 0; kk < j; ++kk) dd -= A[j][kk] * A[j][kk];
+    const double l = sqrt(dd);
+    const double il = 1.0 / l;
+    A[j][j] = l;
+#pragma unroll
+    for (int i = j + 1; i < NV; ++i) {
+      double s = A[i][j];
+#pragma unroll
+      for (int kk = 0; kk < j; ++kk) s -= A[i][kk] * A[j][kk];
+      A[i][j] = s * il;
+    }
+  }
+  // invert L: Li[i][j] for j <= i
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    Li[j][j] = 1.0 / A[j][j];
+#pragma unroll
+    for (int i = j + 1; i < NV; ++i) {
+      double s = 0.0;
+#pragma unroll
+      for (int kk = j; kk < i; ++kk) s -= A[i][kk] * Li[kk][j];
+      Li[i][j] = s / A[i][i];
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < NV; ++i)
+#pragma unroll
+    for (int j = 0; j <= i; ++j) {
+      double s = 0.0;
+#pragma unroll
+      for (int kk = i; kk < NV; ++kk) s += Li[kk][i] * Li[kk][j];
+      Ainv[i][j] = s;
+      Ainv[j][i] = s;
+    }
+}
+
+// Pass B: partial derivatives of RNEA at (q, qd, qdd) in the world frame.
+//   dq[i][j] = d tau_i / d q_j ,  dv[i][j] = d tau_i / d qd_j
+// Derivation ("RNEA derivatives"): with Sd = v x S, psi = a x S + v x Sd,
+// composite inertia Ic, composite force fC and the composite Coriolis-like matrix
+// D = 2B whose only non-zero blocks are  D_lin,ang = -2 [f0]x  and  D_ang,ang = E:
+//   j on the path root..i :  dv = 2 (Ic_i S_i).Sd_j + (D_i^T S_i).S_j
+//                            dq = (D_i^T S_i).Sd_j + (Ic_i S_i).psi_j
+//   i strict ancestor of j:  dv = S_i.(2 Ic_j Sd_j + D_j S_j)
+//                            dq = S_i.(S_j x* fC_j + D_j Sd_j + Ic_j psi_j)
+template <int NV, bool CHAIN>
+AGX_DEV void rnea_derivatives(const DevModel &m, const Kin<NV> &k, const Dyn<NV> &d, const double *qd, const double *qdd,
+                              double (*dq)[NV], double (*dv)[NV]) {
+  double a[NV][6], psi[NV][6], fC[NV][6], f0C[NV][3], EC[NV][9];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int par = parent_of<NV, CHAIN>(m, i);
+#pragma unroll
+    for (int e = 0; e < 6; ++e)
+      a[i][e] = (par >= 0 ? a[par][e] : (e < 3 ? -m.gravity[e] : 0.0)) + k.S[i][e] * qdd[i] + d.Sd[i][e] * qd[i];
+    double t1[6], t2[6];
+    mcross(a[i], k.S[i], t1);
+    mcross(d.v[i], d.Sd[i], t2);
+#pragma unroll
+    for (int e = 0; e < 6; ++e) psi[i][e] = t1[e] + t2[e];
+    double h[6], g[6], x[6];
+    iapply(d.Ib[i], d.v[i], h);
+    iapply(d.Ib[i], a[i], g);
+    fcross(d.v[i], h, x);
+#pragma unroll
+    for (int e = 0; e < 6; ++e) fC[i][e] = g[e] + x[e];
+    f0C[i][0] = h[0]; f0C[i][1] = h[1]; f0C[i][2] = h[2];
+    // E = W Io + (W Io)^T - v hh^T - hh v^T + 2 (v.hh) 1 - [n0]x
+    const double *I = d.Ib[i];
+    const double *vl = d.v[i], *w = d.v[i] + 3, *hh = I + 1;
+    const double Io[9] = {I[4], I[5], I[6], I[5], I[7], I[8], I[6], I[8], I[9]};
+    double WI[9];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      WI[0 + c] = w[1] * Io[6 + c] - w[2] * Io[3 + c];
+      WI[3 + c] = w[2] * Io[0 + c] - w[0] * Io[6 + c];
+      WI[6 + c] = w[0] * Io[3 + c] - w[1] * Io[0 + c];
+    }
+    const double vh = dot3(vl, hh);
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int c = 0; c < 3; ++c)
+        EC[i][3 * r + c] = WI[3 * r + c] + WI[3 * c + r] - vl[r] * hh[c] - hh[r] * vl[c] + (r == c ? 2.0 * vh : 0.0);
+    const double *n0 = h + 3;
+    EC[i][1] += n0[2]; EC[i][2] -= n0[1];
+    EC[i][3] -= n0[2]; EC[i][5] += n0[0];
+    EC[i][6] += n0[1]; EC[i][7] -= n0[0];
+  }
+#pragma unroll
+  for (int i = NV - 1; i >= 0; --i) {
+    double m6[6];
+    iapply(d.Ic[i], k.S[i], m6);
+    // Dt_ang = 2 f0C x S_lin + E^T S_ang
+    double Dt[3], t[3];
+    cross3(f0C[i], k.S[i], t);
+    const double *sa = k.S[i] + 3;
+    Dt[0] = 2.0 * t[0] + EC[i][0] * sa[0] + EC[i][3] * sa[1] + EC[i][6] * sa[2];
+    Dt[1] = 2.0 * t[1] + EC[i][1] * sa[0] + EC[i][4] * sa[1] + EC[i][7] * sa[2];
+    Dt[2] = 2.0 * t[2] + EC[i][2] * sa[0] + EC[i][5] * sa[1] + EC[i][8] * sa[2];
+    // column vectors of joint i
+    double IcSd[6], IcPs[6], colv[6], colq[6], sxf[6], u1[3], u2[3], e1[3], e2[3];
+    iapply(d.Ic[i], d.Sd[i], IcSd);
+    iapply(d.Ic[i], psi[i], IcPs);
+    fcross(k.S[i], fC[i], sxf);
+    cross3(f0C[i], k.S[i] + 3, u1);   // f0 x S_ang
+    cross3(f0C[i], d.Sd[i] + 3, u2);  // f0 x Sd_ang
+    mv3(EC[i], k.S[i] + 3, e1);
+    mv3(EC[i], d.Sd[i] + 3, e2);
+#pragma unroll
+    for (int e = 0; e < 3; ++e) {
+      colv[e] = 2.0 * IcSd[e] - 2.0 * u1[e];
+      colv[3 + e] = 2.0 * IcSd[3 + e] + e1[e];
+      colq[e] = sxf[e] - 2.0 * u2[e] + IcPs[e];
+      colq[3 + e] = sxf[3 + e] + e2[e] + IcPs[3 + e];
+    }
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      if (j == i) {
+        dv[i][i] = 2.0 * dot6(m6, d.Sd[i]) + dot3(Dt, k.S[i] + 3);
+        dq[i][i] = dot3(Dt, d.Sd[i] + 3) + dot6(m6, psi[i]);
+      } else if ((CHAIN && j < i) || (!CHAIN && is_anc<NV, CHAIN>(m, i, j))) {
+        // j strict ancestor of i: row i, column j  and  row j, column i
+        dv[i][j] = 2.0 * dot6(m6, d.Sd[j]) + dot3(Dt, k.S[j] + 3);
+        dq[i][j] = dot3(Dt, d.Sd[j] + 3) + dot6(m6, psi[j]);
+        dv[j][i] = dot6(k.S[j], colv);
+        dq[j][i] = dot6(k.S[j], colq);
+      } else if (!CHAIN && !is_anc<NV, CHAIN>(m, j, i)) {
+        dv[i][j] = 0.0;
+        dq[i][j] = 0.0;
+      }
+    }
+    const int par = parent_of<NV, CHAIN>(m, i);
+    if (par >= 0) {
+#pragma unroll
+      for (int e = 0; e < 6; ++e) fC[par][e] += fC[i][e];
+#pragma unroll
+      for (int e = 0; e < 3; ++e) f0C[par][e] += f0C[i][e];
+#pragma unroll
+      for (int e = 0; e < 9; ++e) EC[par][e] += EC[i][e];
+    }
+  }
+}
+
+// Plain RNEA (warm start / reference generators): tau = M(q) qdd + nle(q, qd), no armature.
+template <int NV, bool CHAIN>
+AGX_DEV void rnea(const DevModel &m, const Kin<NV> &k, const double *qd, const double *qdd, double *tau) {
+  double v[NV][6], a[NV][6], f[NV][6];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int par = parent_of<NV, CHAIN>(m, i);
+    double Sd[6], I[10];
+#pragma unroll
+    for (int e = 0; e < 6; ++e) v[i][e] = (par >= 0 ? v[par][e] : 0.0) + k.S[i][e] * qd[i];
+    mcross(v[i], k.S[i], Sd);
+#pragma unroll
+    for (int e = 0; e < 6; ++e)
+      a[i][e] = (par >= 0 ? a[par][e] : (e < 3 ? -m.gravity[e] : 0.0)) + k.S[i][e] * qdd[i] + Sd[e] * qd[i];
+    body_inertia<NV>(m, k, i, I);
+    double h[6], g[6], x[6];
+    iapply(I, v[i], h);
+    iapply(I, a[i], g);
+    fcross(v[i], h, x);
+#pragma unroll
+    for (int e = 0; e < 6; ++e) f[i][e] = g[e] + x[e];
+  }
+#pragma unroll
+  for (int i = NV - 1; i >= 0; --i) {
+    tau[i] = dot6(k.S[i], f[i]);
+    const int par = parent_of<NV, CHAIN>(m, i);
+    if (par >= 0) {
+#pragma unroll
+      for (int e = 0; e < 6; ++e) f[par][e] += f[i][e];
+    }
+  }
+}
+
+// ------------------------------------------------------------------ log maps
+// pinocchio::log3 including its explicit branch near pi (spatial/log.hxx); the
+// branch decides the sign of the axis at theta = pi, which the reference's golden
+// solution depends on (Panda tool frame at q = 0 is exactly pi from identity).
+AGX_DEV void log3(const double *R, double *w) {
+  double tr = R[0] + R[4] + R[8];
+  tr = fmin(3.0, fmax(-1.0, tr));
+  const double ct = 0.5 * (tr - 1.0);
+  const double theta = acos(ct);
+  if (theta >= 3.14159265358979323846 - 1e-2) {
+    const double cphi = -ct;
+    const double beta = theta * theta / (1.0 + cphi);
+    const double v0 = (R[0] + cphi) * beta, v1 = (R[4] + cphi) * beta, v2 = (R[8] + cphi) * beta;
+    w[0] = (R[7] > R[5] ? 1.0 : -1.0) * (v0 > 0.0 ? sqrt(v0) : 0.0);
+    w[1] = (R[2] > R[6] ? 1.0 : -1.0) * (v1 > 0.0 ? sqrt(v1) : 0.0);
+    w[2] = (R[3] > R[1] ? 1.0 : -1.0) * (v2 > 0.0 ? sqrt(v2) : 0.0);
+  } else {
+    const double t = 0.5 * (theta > 1e-8 ? theta / sin(theta) : 1.0);
+    w[0] = t * (R[7] - R[5]);
+    w[1] = t * (R[2] - R[6]);
+    w[2] = t * (R[3] - R[1]);
+  }
+}
+AGX_DEV void jlog3(const double *w, double *J) {
+  const double t2 = dot3(w, w), t = sqrt(t2);
+  double alpha, diag;
+  if (t < 1e-4) {
+    alpha = 1.0 / 12.0 + t2 / 720.0;
+    diag = 0.5 * (2.0 - t2 / 6.0);
+  } else {
+    double st, ct;
+    sincos(t, &st, &ct);
+    const double s1 = st / (1.0 - ct);
+    alpha = 1.0 / t2 - s1 / (2.0 * t);
+    diag = 0.5 * t * s1;
+  }
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) J[3 * i + j] = alpha * w[i] * w[j] + (i == j ? diag : 0.0);
+  J[1] -= 0.5 * w[2]; J[2] += 0.5 * w[1];
+  J[3] += 0.5 * w[2]; J[5] -= 0.5 * w[0];
+  J[6] -= 0.5 * w[1]; J[7] += 0.5 * w[0];
+}
+// r = log6(R, p) and (optionally) the blocks of Jlog6: TL (= BR) and TR; BL = 0.
+template <bool JAC>
+AGX_DEV void log6(const double *R, const double *p, double *r, double *TL, double *TR) {
+  double w[3];
+  log3(R, w);
+  const double t2 = dot3(w, w);
+  double alpha, beta, bdot = 1.0 / 360.0;
+  const double t = sqrt(t2);
+  if (t2 < 1e-12) {
+    alpha = 1.0 - t2 / 12.0;
+    beta = 1.0 / 12.0 + t2 / 720.0;
+  } else {
+    double st, ct;
+    sincos(t, &st, &ct);
+    const double i22 = 1.0 / (2.0 * (1.0 - ct));
+    alpha = t * st * i22;
+    beta = 1.0 / t2 - st / t * i22;
+    if (t >= 1e-4) {
+      const double tinv = 1.0 / t, t2inv = tinv * tinv;
+      bdot = -2.0 * t2inv * t2inv + (1.0 + st * tinv) * t2inv * i22;
+    }
+  }
+  double wxp[3];
+  cross3(w, p, wxp);
+  const double wp = dot3(w, p);
+#pragma unroll
+  for (int e = 0; e < 3; ++e) {
+    r[e] = alpha * p[e] - 0.5 * wxp[e] + beta * wp * w[e];
+    r[3 + e] = w[e];
+  }
+  if (JAC) {
+    jlog3(w, TL);
+    // pinocchio::Jlog6 uses the Taylor beta below 1e-4 (not 1e-6): keep its thresholds
+    double betaJ = beta;
+    if (t < 1e-4) betaJ = 1.0 / 12.0 + t2 / 720.0;
+    double v3[3], C[9];
+#pragma unroll
+    for (int e = 0; e < 3; ++e) v3[e] = (bdot * wp) * w[e] - (t2 * bdot + 2.0 * betaJ) * p[e];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) C[3 * i + j] = v3[i] * w[j] + betaJ * w[i] * p[j] + (i == j ? wp * betaJ : 0.0);
+    C[1] -= 0.5 * p[2]; C[2] += 0.5 * p[1];
+    C[3] += 0.5 * p[2]; C[5] -= 0.5 * p[0];
+    C[6] -= 0.5 * p[1]; C[7] += 0.5 * p[0];
+    mm3(C, TL, TR);
+  }
+}
+
+// world placement of an operational frame
+template <int NV>
+AGX_DEV void frame_world(const DevModel &m, const Kin<NV> &k, int frame, double *R, double *p, int *joint) {
+  const int par = m.frame_parent[frame];
+  *joint = par;
+  if (par >= 0) {
+    // dynamic joint index: select with uniform compares so that Kin stays in registers
+    double Rp[9], pp[3];
+#pragma unroll
+    for (int e = 0; e < 9; ++e) Rp[e] = 0.0;
+#pragma unroll
+    for (int e = 0; e < 3; ++e) pp[e] = 0.0;
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+      if (i == par) {
+#pragma unroll
+        for (int e = 0; e < 9; ++e) Rp[e] = k.R[i][e];
+#pragma unroll
+        for (int e = 0; e < 3; ++e) pp[e] = k.p[i][e];
+      }
+    mm3(Rp, m.frame_placement[frame], R);
+    double t[3];
+    mv3(Rp, &m.frame_placement[frame][9], t);
+    p[0] = pp[0] + t[0]; p[1] = pp[1] + t[1]; p[2] = pp[2] + t[2];
+  } else {
+#pragma unroll
+    for (int e = 0; e < 9; ++e) R[e] = m.frame_placement[frame][e];
+#pragma unroll
+    for (int e = 0; e < 3; ++e) p[e] = m.frame_placement[frame][9 + e];
+  }
+}
+
+// ------------------------------------------------------------ shooting node
+// Tile layout (AGX_TILE_DOUBLES): Fx | Fu | f | Lx | Lu | Lxx | Lxu | Luu | cost
+template <int NV>
+struct TileOff {
+  static constexpr int NX = 2 * NV, NU = NV;
+  static constexpr int Fx = 0, Fu = Fx + NX * NX, f = Fu + NX * NU, Lx = f + NX, Lu = Lx + NX, Lxx = Lu + NU,
+                       Lxu = Lxx + NX * NX, Luu = Lxu + NX * NU, cost = Luu + NU * NU, SIZE = cost + 1;
+};
+
+// Cost accumulators of one node.  Every supported residual depends on q only
+// through the frame placement, on v and u only diagonally, so the Hessian is
+// {dense qq block, diagonal vv, diagonal uu} and Lxu = 0.
+template <int NV>
+struct CostAcc {
+  double cost;
+  double Lq[NV], Lv[NV], Lu[NV];
+  double Lqq[NV][NV];
+  double Lvv[NV], Luu[NV];
+};
+
+// Evaluates the cost rows of one node.  DIFF = false: value only (line search).
+template <int NV, bool CHAIN, bool TERM, bool DIFF>
+AGX_DEV void node_costs(const DevModel &m, const DevRows &rows, const Kin<NV> &k, const double *x, const double *u,
+                        const double *ref, const int *frames, CostAcc<NV> &c) {
+  c.cost = 0.0;
+  if (DIFF) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      c.Lq[i] = 0.0; c.Lv[i] = 0.0; c.Lu[i] = 0.0; c.Lvv[i] = 0.0; c.Luu[i] = 0.0;
+#pragma unroll
+      for (int j = 0; j < NV; ++j) c.Lqq[i][j] = 0.0;
+    }
+  }
+  for (int r = 0; r < rows.n; ++r) {
+    if (!rows.active[r]) continue;
+    const double *tile = ref + rows.off[r];
+    const double wi = tile[0];
+    const double *rr = tile + 1;
+    const double *aw = rr + rows.nref[r];
+    const int kind = rows.kind[r];
+    if (kind == AGX_RES_STATE) {
+      double a = 0.0;
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        const double rq = x[i] - rr[i], rv = x[NV + i] - rr[NV + i];
+        a += 0.5 * (aw[i] * rq * rq + aw[NV + i] * rv * rv);
+        if (DIFF) {
+          c.Lq[i] += wi * aw[i] * rq;
+          c.Lv[i] += wi * aw[NV + i] * rv;
+          c.Lqq[i][i] += wi * aw[i];
+          c.Lvv[i] += wi * aw[NV + i];
+        }
+      }
+      c.cost += wi * a;
+    } else if (kind == AGX_RES_CONTROL) {
+      if (!TERM) {
+        double a = 0.0;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+          const double ru = u[i] - rr[i];
+          a += 0.5 * aw[i] * ru * ru;
+          if (DIFF) {
+            c.Lu[i] += wi * aw[i] * ru;
+            c.Luu[i] += wi * aw[i];
+          }
+        }
+        c.cost += wi * a;
+      }
+    } else if (kind == AGX_RES_FRAME_PLACEMENT || kind == AGX_RES_FRAME_TRANSLATION || kind == AGX_RES_FRAME_ROTATION) {
+      int frame = frames ? frames[r] : -1;
+      if (frame < 0) frame = rows.frame[r];
+      double RF[9], pF[3];
+      int jf;
+      frame_world<NV>(m, k, frame, RF, pF, &jf);
+      double res[6], J[6][NV];  // residual and its Jacobian wrt q
+      int nr;
+      if (kind == AGX_RES_FRAME_PLACEMENT) {
+        nr = 6;
+        double Rrel[9], d[3], prel[3], TL[9], TR[9];
+        mtm3(rr, RF, Rrel);
+        d[0] = pF[0] - rr[9]; d[1] = pF[1] - rr[10]; d[2] = pF[2] - rr[11];
+        mtv3(rr, d, prel);
+        log6<DIFF>(Rrel, prel, res, TL, TR);
+        if (DIFF) {
+#pragma unroll
+          for (int j = 0; j < NV; ++j) {
+            const bool on = (jf >= 0) && (CHAIN ? (j <= jf) : ((m.anc[jf >= 0 ? jf : 0] >> j) & 1u));
+            double lin[3], ang[3], dl[3], t[3];
+            dl[0] = pF[0] - k.p[j][0]; dl[1] = pF[1] - k.p[j][1]; dl[2] = pF[2] - k.p[j][2];
+            cross3(k.S[j] + 3, dl, t);  // z x (pF - pj)
+            mtv3(RF, t, lin);           // LOCAL frame Jacobian column
+            mtv3(RF, k.S[j] + 3, ang);
+#pragma unroll
+            for (int e = 0; e < 3; ++e) {
+              const double top = TL[3 * e] * lin[0] + TL[3 * e + 1] * lin[1] + TL[3 * e + 2] * lin[2] +
+                                 TR[3 * e] * ang[0] + TR[3 * e + 1] * ang[1] + TR[3 * e + 2] * ang[2];
+              const double bot = TL[3 * e] * ang[0] + TL[3 * e + 1] * ang[1] + TL[3 * e + 2] * ang[2];
+              J[e][j] = on ? top : 0.0;
+              J[3 + e][j] = on ? bot : 0.0;
+            }
+          }
+        }
+      } else if (kind == AGX_RES_FRAME_TRANSLATION) {
+        nr = 3;
+        res[0] = pF[0] - rr[0]; res[1] = pF[1] - rr[1]; res[2] = pF[2] - rr[2];
+        res[3] = res[4] = res[5] = 0.0;
+        if (DIFF) {
+#pragma unroll
+          for (int j = 0; j < NV; ++j) {
+            const bool on = (jf >= 0) && (CHAIN ? (j <= jf) : ((m.anc[jf >= 0 ? jf : 0] >> j) & 1u));
+            double dl[3], t[3];
+            dl[0] = pF[0] - k.p[j][0]; dl[1] = pF[1] - k.p[j][1]; dl[2] = pF[2] - k.p[j][2];
+            cross3(k.S[j] + 3, dl, t);
+#pragma unroll
+            for (int e = 0; e < 3; ++e) { J[e][j] = on ? t[e] : 0.0; J[3 + e][j] = 0.0; }
+          }
+        }
+      } else {
+        nr = 3;
+        double Rrel[9], TL[9];
+        mtm3(rr, RF, Rrel);
+        log3(Rrel, res);
+        res[3] = res[4] = res[5] = 0.0;
+        if (DIFF) {
+          jlog3(res, TL);
+#pragma unroll
+          for (int j = 0; j < NV; ++j) {
+            const bool on = (jf >= 0) && (CHAIN ? (j <= jf) : ((m.anc[jf >= 0 ? jf : 0] >> j) & 1u));
+            double ang[3];
+            mtv3(RF, k.S[j] + 3, ang);
+#pragma unroll
+            for (int e = 0; e < 3; ++e) {
+              const double bot = TL[3 * e] * ang[0] + TL[3 * e + 1] * ang[1] + TL[3 * e + 2] * ang[2];
+              J[e][j] = on ? bot : 0.0;
+              J[3 + e][j] = 0.0;
+            }
+          }
+        }
+      }
+      double a = 0.0;
+#pragma unroll
+      for (int e = 0; e < 6; ++e)
+        if (e < nr) a += 0.5 * aw[e] * res[e] * res[e];
+      c.cost += wi * a;
+      if (DIFF) {
+#pragma unroll
+        for (int e = 0; e < 6; ++e) {
+          if (e < nr) {
+            const double we = wi * aw[e];
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+              c.Lq[i] += we * res[e] * J[e][i];
+#pragma unroll
+              for (int j = 0; j <= i; ++j) c.Lqq[i][j] += we * J[e][i] * J[e][j];
+            }
+          }
+        }
+      }
+    }
+  }
+  if (DIFF) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+#pragma unroll
+      for (int j = i + 1; j < NV; ++j) c.Lqq[i][j] = c.Lqq[j][i];
+  }
+}
+
+// calc of a running node: forward dynamics + semi-implicit Euler + cost
+// (crocoddyl IntegratedActionModelEuler::calc).
+template <int NV, bool CHAIN>
+AGX_DEV void node_calc_running(const DevModel &m, const DevRows &rows, double dt, const double *x, const double *u,
+                               const double *ref, const int *frames, double *xnext, double *cost) {
+  Kin<NV> k;
+  kinematics<NV, CHAIN>(m, x, k);
+  Dyn<NV> d;
+  double nle[NV], M[NV][NV], Minv[NV][NV];
+  bias_and_inertia<NV, CHAIN>(m, k, x + NV, d, nle, M);
+  spd_inverse<NV>(M, Minv);
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    double a = 0.0;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) a += Minv[i][j] * (u[j] - nle[j]);
+    xnext[NV + i] = x[NV + i] + dt * a;
+    xnext[i] = x[i] + dt * x[NV + i] + dt * dt * a;
+  }
+  CostAcc<NV> c;
+  node_costs<NV, CHAIN, false, false>(m, rows, k, x, u, ref, frames, c);
+  *cost = dt * c.cost;
+}
+
+template <int NV, bool CHAIN>
+AGX_DEV void node_calc_terminal(const DevModel &m, const DevRows &rows, const double *x, const double *ref,
+                                const int *frames, double *cost) {
+  Kin<NV> k;
+  kinematics<NV, CHAIN>(m, x, k);
+  CostAcc<NV> c;
+  node_costs<NV, CHAIN, true, false>(m, rows, k, x, nullptr, ref, frames, c);
+  *cost = c.cost;
+}
+
+}  // namespace agx

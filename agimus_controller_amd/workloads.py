@@ -1,0 +1,135 @@
+"""Synthetic, seeded problem definitions shared by bench.py, smoke() and the tests
+(SURVEY.md section 8(d)).  Pure numpy: no solver code lives here."""
+
+from __future__ import annotations
+
+import numpy as np
+
+from . import _abi
+from .factory import robot_tables as rt
+
+# q0 of the reference's sine-wave test and pick-and-place example
+# (agimus_controller/tests/test_sin_wave_configuration_space.py:31-43).
+PANDA_Q0 = np.array(
+    [-0.3619834760502907, -1.3575006398318104, 0.969610481368033, -2.6028532848927295,
+     0.2040785081450368, 1.9436352693107668, 0.6423896937386857]
+)  # fmt: skip
+
+
+def goal_reaching_rows(frame: int):
+    """Row tables of agimus_controller/agimus_controller/ocp/ocp_goal_reaching.yaml."""
+    running = [
+        _abi.RowSpec(_abi.RES_CONTROL, name="control_reg"),
+        _abi.RowSpec(_abi.RES_STATE, name="state_reg"),
+        _abi.RowSpec(_abi.RES_FRAME_PLACEMENT, frame=frame, name="goal_tracking"),
+    ]
+    terminal = [
+        _abi.RowSpec(_abi.RES_STATE, name="state_reg"),
+        _abi.RowSpec(_abi.RES_FRAME_PLACEMENT, frame=frame, name="goal_tracking"),
+    ]
+    return running, terminal
+
+
+def regulation_rows():
+    """Row tables of the pick-and-place example's ocp_definition_file.yaml
+    (control_reg + state_reg; terminal state_reg)."""
+    running = [_abi.RowSpec(_abi.RES_CONTROL, name="control_reg"), _abi.RowSpec(_abi.RES_STATE, name="state_reg")]
+    terminal = [_abi.RowSpec(_abi.RES_STATE, name="state_reg")]
+    return running, terminal
+
+
+def golden_problem():
+    """The reference's only golden case, agimus_controller/tests/test_ocp_croco_base.py:14-155:
+    Panda, T = 9, Euler step 1e-3, stateReg 0.1 / ctrlReg 1e-4 / placement 1.0 to (1,1,1),
+    terminal stateReg 0.1 + placement 50, zero warm start, x0 = 0, 100 iterations."""
+    table = rt.panda_table(0.1)
+    tcp = table.frame_id("panda_hand_tcp")
+    running = [
+        _abi.RowSpec(_abi.RES_STATE, name="stateReg"),
+        _abi.RowSpec(_abi.RES_CONTROL, name="ctrlRegGrav"),
+        _abi.RowSpec(_abi.RES_FRAME_PLACEMENT, frame=tcp, name="gripperPoseRM"),
+    ]
+    terminal = [
+        _abi.RowSpec(_abi.RES_STATE, name="stateReg"),
+        _abi.RowSpec(_abi.RES_FRAME_PLACEMENT, frame=tcp, name="gripperPose"),
+    ]
+    T = 9
+    po = _abi.PackedOcp(7, [1e-3] * T, running, terminal)
+    ref = po.new_ref_tile(1)
+    target = np.concatenate([np.eye(3).reshape(9), [1.0, 1.0, 1.0]])
+    for terminal_flag, row, w in ((False, 0, 0.1), (False, 1, 1e-4), (False, 2, 1.0), (True, 0, 0.1), (True, 1, 50.0)):
+        wi, r, _ = po.row_view(ref, terminal_flag, row)
+        wi[...] = w
+        r[...] = 0.0
+        if r.shape[-1] == 12:
+            r[...] = target
+    x0 = np.zeros((1, 14))
+    xs0 = np.zeros((1, T + 1, 14))
+    us0 = np.zeros((1, T, 7))
+    return table, po, ref, x0, xs0, us0
+
+
+def random_goal_problem(table, T, dt, B, seed, frame=None, rows="goal", timesteps=None):
+    """Seeded random references / weights / warm start around a random posture."""
+    nv = table.nv
+    rng = np.random.default_rng(seed)
+    if frame is None:
+        frame = len(table.frame_names) - 1
+    running, terminal = goal_reaching_rows(frame) if rows == "goal" else regulation_rows()
+    ts = [dt] * T if timesteps is None else list(timesteps)
+    po = _abi.PackedOcp(nv, ts, running, terminal)
+    ref = po.new_ref_tile(B)
+    lo = np.maximum(table.lower_position_limit, -2.0)
+    hi = np.minimum(table.upper_position_limit, 2.0)
+    qc = rng.uniform(lo, hi, (B, 1, nv))
+    for term, rws in ((False, running), (True, terminal)):
+        n = 1 if term else T
+        for i, r in enumerate(rws):
+            wi, rr, aw = po.row_view(ref, term, i)
+            wi[...] = rng.uniform(0.5, 2.0, (B, n))
+            aw[...] = rng.uniform(0.1, 2.0, aw.shape)
+            if r.kind == _abi.RES_STATE:
+                rr[..., :nv] = qc + rng.normal(0, 0.05, (B, n, nv))
+                rr[..., nv:] = rng.normal(0, 0.1, (B, n, nv))
+            elif r.kind == _abi.RES_CONTROL:
+                rr[...] = rng.normal(0, 2.0, rr.shape)
+                aw[...] = rng.uniform(1e-3, 1e-2, aw.shape)
+            elif r.kind == _abi.RES_FRAME_PLACEMENT:
+                for b in range(B):
+                    for t in range(n):
+                        R = rt.rpy(*rng.uniform(-1.0, 1.0, 3))
+                        rr[b, t, :9] = R.reshape(9)
+                        rr[b, t, 9:] = rng.uniform(-0.5, 0.5, 3) + np.array([0.3, 0.0, 0.5])
+    x0 = np.concatenate([qc[:, 0, :] + rng.normal(0, 0.02, (B, nv)), rng.normal(0, 0.1, (B, nv))], axis=1)
+    xs = np.repeat(x0[:, None, :], T + 1, axis=1) + rng.normal(0, 0.01, (B, T + 1, 2 * nv))
+    us = rng.normal(0, 1.0, (B, T, nv))
+    return po, ref, x0, xs, us
+
+
+def sine_batch_params(B: int, nv: int = 7, seed0: int = 1234, q0=None, lower=None, upper=None):
+    """Per-instance sine-wave parameters: instance b draws from
+    default_rng(seed0 + b): A_j ~ U(0.05, 0.2), period_j ~ U(2, 6) s, t0 ~ U(0, 4) s,
+    q0 perturbed by N(0, 0.02^2) clipped to the joint limits.  Instance 0 is the
+    reference's own test case (A 0.1, period 4, t0 0, unperturbed q0)."""
+    q0 = PANDA_Q0 if q0 is None else np.asarray(q0, dtype=float)
+    out_q0 = np.empty((B, nv))
+    amp = np.empty((B, nv))
+    puls = np.empty((B, nv))
+    scale = np.full((B, nv), 0.2)
+    t0 = np.empty(B)
+    for b in range(B):
+        rng = np.random.default_rng(seed0 + b)
+        a = rng.uniform(0.05, 0.2, nv)
+        period = rng.uniform(2.0, 6.0, nv)
+        tt = rng.uniform(0.0, 4.0)
+        qq = q0 + rng.normal(0.0, 0.02, nv)
+        if b == 0:
+            a, period, tt, qq = np.full(nv, 0.1), np.full(nv, 4.0), 0.0, q0.copy()
+        if lower is not None:
+            qq = np.clip(qq, lower + a, upper - a)
+        out_q0[b], amp[b], puls[b], t0[b] = qq, a, 2.0 * np.pi / period, tt
+    return out_q0, amp, puls, scale, t0
+
+
+# Weights of the reference's sine-wave test (tests/test_sin_wave_configuration_space.py:138-144).
+SINE_WEIGHTS = dict(w_q=1.0, w_qdot=0.1, w_effort=3e-4, w_pose=0.1)

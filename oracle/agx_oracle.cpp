@@ -1002,14 +1002,18 @@ int orc_calc_diff(void *h, const double *ref, const int32_t *frames, const doubl
   return 0;
 }
 
-int orc_direction(void *h, const double *tiles, double *K, double *k, double *dx, double *du, double *kkt) {
+// One QP direction as the solver computes it: plain pass with (preg, dreg) gives k, dx, du
+// and the KKT residual; the sigma (ADMM) pass around that direction gives the reported gains K.
+int orc_direction(void *h, const double *tiles, double preg, double dreg, double *K, double *k, double *dx, double *du,
+                  double *kkt) {
   OrcOcp *p = static_cast<OrcOcp *>(h);
   const int nv = p->m.nv, nx = 2 * nv, nu = nv, T = p->o.T, TILE = AGX_TILE_DOUBLES(nv);
 #pragma omp parallel for schedule(dynamic)
   for (int b = 0; b < p->B; ++b) {
-    Direction d;
-    direction(nv, T, tiles + (size_t)b * (T + 1) * TILE, d);
-    if (K) std::memcpy(K + (size_t)b * T * nu * nx, d.K.data(), sizeof(double) * T * nu * nx);
+    Direction d, dk;
+    direction(nv, T, tiles + (size_t)b * (T + 1) * TILE, d, 0.0, preg, dreg);
+    direction(nv, T, tiles + (size_t)b * (T + 1) * TILE, dk, 1e-6, preg, dreg, d.dx.data(), d.du.data());
+    if (K) std::memcpy(K + (size_t)b * T * nu * nx, dk.K.data(), sizeof(double) * T * nu * nx);
     if (k) std::memcpy(k + (size_t)b * T * nu, d.k.data(), sizeof(double) * T * nu);
     if (dx) std::memcpy(dx + (size_t)b * (T + 1) * nx, d.dx.data(), sizeof(double) * (T + 1) * nx);
     if (du) std::memcpy(du + (size_t)b * T * nu, d.du.data(), sizeof(double) * T * nu);

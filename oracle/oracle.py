@@ -146,14 +146,14 @@ class Oracle:
         lib().orc_calc_diff(self._h, _p(ref), _p(fr), _p(xs), _p(us), _p(tiles))
         return tiles
 
-    def direction(self, tiles):
+    def direction(self, tiles, preg=1e-9, dreg=1e-9):
         tiles = _f8(tiles)
         K = np.empty((self.B, self.T, self.nu, self.nx))
         k = np.empty((self.B, self.T, self.nu))
         dx = np.empty((self.B, self.T + 1, self.nx))
         du = np.empty((self.B, self.T, self.nu))
         kkt = np.empty(self.B)
-        lib().orc_direction(self._h, _p(tiles), _p(K), _p(k), _p(dx), _p(du), _p(kkt))
+        lib().orc_direction(self._h, _p(tiles), C.c_double(preg), C.c_double(dreg), _p(K), _p(k), _p(dx), _p(du), _p(kkt))
         return K, k, dx, du, kkt
 
     def solve(self, ref, frames, x0, xs_ws, us_ws, max_iter, max_time=0.0, nthreads=1):
