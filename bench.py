@@ -1,0 +1,248 @@
+#!/usr/bin/env python3
+"""bench.py -- MPC steps/s of the MI355X-native OCP solve path.
+
+One "step" = one receding-horizon MPC step (MPC.run, agimus_controller/agimus_controller/mpc.py:32-66)
+of every instance of the batch, fully device resident: horizon window of the resident sine-wave
+reference, x0 <- previous xs[1], warm-start shift, SQP solve (CSQP semantics,
+max_iter / tol of the ROS defaults), then the download of what the controller publishes
+(us[0], K[0], x1 and the solver status).  Inputs sit in HBM before the timed region starts.
+
+  python bench.py [--gpus N --steps K --warmup W --batch B --horizon T --max-iter I]
+
+N > 1 is launched by the driver through torch.distributed.run (one rank per GPU).  Instances are
+independent, so ranks share nothing on the data path: the only collectives are the barriers and
+the MAX over ranks of the timed region.  Per-GPU work is fixed: scaling = "weak".
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import pathlib
+import sys
+import time
+
+import numpy as np
+
+ROOT = pathlib.Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+from agimus_controller_amd import _abi, backend, workloads  # noqa: E402
+from agimus_controller_amd.factory import robot_tables as rt  # noqa: E402
+
+HBM_PEAK = 8.0e12  # B/s, /opt/skills/guides/MI355X_MICROARCH.md "HBM3E peak BW"
+# Algorithmic doubles per node and launch (nv = 7): K1 read x,u + reference tile and
+# write the 673-double derivative tile; K2+K3 one Riccati backward + one linear forward; K4 one trial.
+ALGO_DOUBLES = {"calc_diff": 775, "direction": 778 + 448, "linesearch": 138}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=1024, help="MPC instances per GPU")
+    ap.add_argument("--horizon", type=int, default=100)
+    ap.add_argument("--max-iter", type=int, default=10, help="SQP iteration cap (ROS default 10)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-instances", type=int, default=0, help="instances of the CPU sample (0 = 2 per core)")
+    return ap.parse_args()
+
+
+def make_problem(T):
+    table = rt.panda_table(0.1)
+    tcp = table.frame_id("panda_hand_tcp")
+    running, terminal = workloads.goal_reaching_rows(tcp)
+    po = _abi.PackedOcp(7, [0.01] * T, running, terminal, termination_tolerance=1e-3, max_qp_iters=100)
+    return table, tcp, po
+
+
+def cpu_baseline(args, table, tcp, po, n_steps=3):
+    """The same MPC steps on the host cores with the CPU restatement under oracle/ ("port", OpenMP
+    over the instances): a bounded sample of the workload (first instances, first steps)."""
+    from oracle.oracle import Oracle  # test infrastructure: only this leg of bench.py uses it
+
+    cores = os.cpu_count() or 1
+    B = args.cpu_instances or 2 * cores
+    T, dt = args.horizon, 0.01
+    q0, amp, puls, scale, t0 = workloads.sine_batch_params(B, lower=table.lower_position_limit, upper=table.upper_position_limit)
+    o = Oracle(table, po, B)
+    w = workloads.SINE_WEIGHTS
+    running, terminal = po.running, po.terminal
+
+    def sample(k):
+        t = t0 + k * dt
+        s = np.clip(t[:, None] / scale, 0.0, 1.0)
+        ramp = 10 * s**3 - 15 * s**4 + 6 * s**5
+        dramp = np.where((s > 0) & (s < 1), (30 * s**2 - 60 * s**3 + 30 * s**4) / scale, 0.0)
+        ddramp = np.where((s > 0) & (s < 1), (60 * s - 180 * s**2 + 120 * s**3) / scale**2, 0.0)
+        sw, cw = np.sin(puls * t[:, None]), np.cos(puls * t[:, None])
+        q = q0 + amp * ramp * sw
+        dq = amp * (dramp * sw + ramp * puls * cw)
+        ddq = amp * (ddramp * sw + 2 * dramp * puls * cw - ramp * puls**2 * sw)
+        return q, dq, o.rnea(q, dq, ddq).reshape(B, 7), o.frame_placement(tcp, q)
+
+    pts = [sample(k) for k in range(T + 1 + n_steps)]
+
+    def window(k0):
+        ref = po.new_ref_tile(B)
+        for t in range(T + 1):
+            q, dq, u, pose = pts[k0 + t]
+            rows, offs = (terminal, po.terminal_offsets) if t == T else (running, po.running_offsets)
+            for r, off in zip(rows, offs):
+                seg = ref[:, t, off:]
+                seg[:, 0] = 1.0
+                if r.kind == _abi.RES_STATE:
+                    seg[:, 1:15] = np.concatenate([q, dq], 1)
+                    seg[:, 15:22], seg[:, 22:29] = w["w_q"], w["w_qdot"]
+                elif r.kind == _abi.RES_CONTROL:
+                    seg[:, 1:8], seg[:, 8:15] = u, w["w_effort"]
+                else:
+                    seg[:, 1:13], seg[:, 13:19] = pose, w["w_pose"]
+        return ref
+
+    refs = [window(k) for k in range(n_steps)]
+    xs = np.stack([np.concatenate([p[0], p[1]], 1) for p in pts[: T + 1]], 1)
+    us = np.stack([p[2] for p in pts[:T]], 1)
+    x0 = xs[:, 0].copy()
+    o.solve(refs[0][:, :, :], None, x0, xs, us, 1, nthreads=cores)  # thread pool / page warm-up
+    t_start = time.perf_counter()
+    iters = []
+    for k in range(n_steps):
+        if k > 0:
+            x0 = xs[:, 1].copy()
+            xs, us = o.shift_warmstart(xs, us)
+        xs, us, K, st = o.solve(refs[k], None, x0, xs, us, args.max_iter, nthreads=cores)
+        iters.append(float(st["iter"].mean()))
+    el = time.perf_counter() - t_start
+    return {
+        "value": B * n_steps / el,
+        "unit": "MPC steps/s",
+        "cores": cores,
+        "kind": "port",
+        "sample": f"{B} instances x {n_steps} steps of the same workload (T={T}), OpenMP over instances; "
+                  f"CPU restatement (oracle/), not the Crocoddyl/mim_solvers binaries; mean SQP iters {np.mean(iters):.2f}",
+        "seconds": el,
+    }
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    B, T, dt = args.batch, args.horizon, 0.01
+    table, tcp, po = make_problem(T)
+    hip = backend.HipOcp(table, po, B, device=local_rank)
+    n_points = args.warmup + args.steps + T + 2
+    # per-instance seeds follow the GLOBAL instance index so every rank works on different instances
+    q0, amp, puls, scale, t0 = workloads.sine_batch_params(B, seed0=1234 + rank * B, lower=table.lower_position_limit,
+                                                           upper=table.upper_position_limit)
+    w = workloads.SINE_WEIGHTS
+    hip.sine_trajectory(n_points, dt, q0, amp, puls, scale, t0, w["w_q"], w["w_qdot"], w["w_effort"], w["w_pose"], tcp)
+
+    def step(k):
+        hip.mpc_step(k, args.max_iter, first=(k == 0))
+        return hip.download_first()
+
+    def sync_all():
+        if dist is not None:
+            import torch
+
+            dist.barrier()
+            torch.cuda.synchronize()
+        hip.sync()
+
+    iters = []
+    for k in range(args.warmup):
+        st = step(k)[3]
+    sync_all()
+    t_start = time.perf_counter()
+    for k in range(args.warmup, args.warmup + args.steps):
+        st = step(k)[3]
+        iters.append(float(st["iter"].mean()))
+    sync_all()
+    elapsed = time.perf_counter() - t_start
+    solved_frac = float(st["solved"].mean())
+    if dist is not None:
+        import torch
+
+        tt = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    # per-kernel device time, measured live with HIP events on the solver's stream
+    kernels = {}
+    if rank == 0:
+        nodes = {"calc_diff": B * T, "direction": B * (T + 1), "linesearch": B * (T + 1)}
+        for name, which in (("calc_diff", 3), ("direction", 1), ("linesearch", 2)):
+            ms = hip.time_kernel(which, 10)
+            algo = ALGO_DOUBLES[name] * 8 * nodes[name]
+            kernels[name] = {"ms": ms, "algorithmic_bytes": algo, "GBps": algo / (ms * 1e-3) / 1e9,
+                             "frac_hbm": algo / (ms * 1e-3) / HBM_PEAK}
+
+    result = None
+    if rank == 0:
+        k1 = kernels["calc_diff"]
+        result = {
+            "metric": "MPC steps/sec (horizon=100, Panda 7-DoF)",
+            "value": world * B * args.steps / elapsed,
+            "unit": "MPC steps/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {
+                "workload": f"Panda 7-DoF sine_wave_configuration_space, ocp_goal_reaching.yaml costs, horizon={T}, "
+                            f"dt=0.01, batch={B} independent MPC instances per GPU (seed 1234+b), closed loop on own prediction",
+                "horizon": T,
+                "batch_per_gpu": B,
+                "global_batch": world * B,
+                "max_iter": args.max_iter,
+                "termination_tolerance": 1e-3,
+                "parallelism": f"batch-sharded x{world}, no data-path collective",
+                "mean_sqp_iters_per_step": float(np.mean(iters)),
+                "solved_fraction_last_step": solved_frac,
+                "step_includes": "window select, x0<-xs[1], warm-start shift, SQP solve, D2H of us[0],K[0],x1,status",
+            },
+            "roofline": {
+                "kernel": "k_calc_diff (node-parallel derivative pass, running nodes)",
+                "bound": "hbm",
+                "achieved": k1["GBps"],
+                "peak": HBM_PEAK / 1e9,
+                "unit": "GB/s",
+                "frac": k1["frac_hbm"],
+                "traffic": None,
+                "avg_launch_ms": k1["ms"],
+                "algorithmic_bytes_per_launch": k1["algorithmic_bytes"],
+            },
+            "kernels": kernels,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            try:
+                result["cpu_baseline"] = cpu_baseline(args, table, tcp, po)
+            except Exception as e:  # the GPU numbers stand on their own
+                result["cpu_baseline"] = {"value": None, "unit": "MPC steps/s", "cores": os.cpu_count(), "kind": "port",
+                                          "sample": f"failed: {e!r}"}
+        print(json.dumps(result), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    hip.close()
+
+
+if __name__ == "__main__":
+    main()

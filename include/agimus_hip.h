@@ -206,7 +206,8 @@ int agx_ocp_direction(agx_ocp *ocp, double *K, double *k, double *dx, double *du
 int agx_ocp_upload_tiles(agx_ocp *ocp, const double *tiles);
 /* Average device time in milliseconds of `reps` launches of one kernel,
  * measured with hipEvents on the problem's stream.
- * which: 0 = derivative pass, 1 = direction (Riccati+forward), 2 = line search. */
+ * which: 0 = derivative pass (running + terminal launches), 1 = direction (Riccati + forward),
+ * 2 = line search, 3 = derivative pass over the running nodes only (one launch).       */
 int agx_ocp_time_kernel(agx_ocp *ocp, int which, int reps, double *avg_ms);
 
 /* ---- device-resident reference trajectory --------------- */

@@ -159,7 +159,8 @@ template <class S> void joint_rotation(const Model &m, int i, const S &q, S *R) 
 template <class S>
 void rnea(const Model &m, const S *q, const S *v, const S *a, S *tau, bool with_gravity) {
   const int n = m.nv;
-  std::vector<S> R(9 * n), vl(3 * n), vw(3 * n), al(3 * n), aw(3 * n), fl(3 * n), fw(3 * n);
+  static thread_local std::vector<S> R, vl, vw, al, aw, fl, fw;  // reused: no heap traffic per call
+  R.resize(9 * n); vl.resize(3 * n); vw.resize(3 * n); al.resize(3 * n); aw.resize(3 * n); fl.resize(3 * n); fw.resize(3 * n);
   for (int i = 0; i < n; ++i) {
     S *Ri = &R[9 * i];
     joint_rotation(m, i, q[i], Ri);
@@ -239,7 +240,8 @@ void rnea(const Model &m, const S *q, const S *v, const S *a, S *tau, bool with_
 // DifferentialActionModelFreeFwdDynamics factorises.
 template <class S> void mass_matrix(const Model &m, const S *q, S *M) {
   const int n = m.nv;
-  std::vector<S> zero(n, S(0.0)), e(n, S(0.0)), col(n);
+  static thread_local std::vector<S> zero, e, col;
+  zero.assign(n, S(0.0)); e.assign(n, S(0.0)); col.resize(n);
   for (int j = 0; j < n; ++j) {
     e[j] = S(1.0);
     rnea(m, q, zero.data(), e.data(), col.data(), false);
@@ -279,7 +281,8 @@ template <class S> void chol_solve(int n, const S *L, S *b) {
 // a = (M + diag(armature))^-1 (u - nle(q, v))     
 template <class S> void forward_dynamics(const Model &m, const S *q, const S *v, const S *u, S *a) {
   const int n = m.nv;
-  std::vector<S> M(n * n), nle(n), zero(n, S(0.0));
+  static thread_local std::vector<S> M, nle, zero;
+  M.resize(n * n); nle.resize(n); zero.assign(n, S(0.0));
   mass_matrix(m, q, M.data());
   rnea(m, q, v, zero.data(), nle.data(), true);
   for (int i = 0; i < n; ++i) a[i] = u[i] - nle[i];
@@ -307,7 +310,8 @@ template <class S> void joint_placements(const Model &m, const S *q, S *Rw, S *p
   }
 }
 template <class S> void frame_placement(const Model &m, int frame, const S *q, S *R, S *p) {
-  std::vector<S> Rw(9 * m.nv), pw(3 * m.nv);
+  static thread_local std::vector<S> Rw, pw;
+  Rw.resize(9 * m.nv); pw.resize(3 * m.nv);
   joint_placements(m, q, Rw.data(), pw.data());
   const double *fp = &m.frame_placement[12 * frame];
   int par = m.frame_parent[frame];
@@ -544,7 +548,8 @@ void node_eval(const Model &m, const Ocp &o, bool terminal, double dt, const S *
   const int nv = m.nv;
   const S *q = x, *v = x + nv;
   if (!terminal) {
-    std::vector<S> a(nv);
+    static thread_local std::vector<S> a;
+    a.resize(nv);
     forward_dynamics(m, q, v, u, a.data());
     // semi-implicit Euler, crocoddyl IntegratedActionModelEuler::calc (App. A.2)
     for (int i = 0; i < nv; ++i) {
@@ -569,7 +574,8 @@ void node_eval(const Model &m, const Ocp &o, bool terminal, double dt, const S *
     const double *aw = rref + nref;
     int frame = frames ? frames[ri] : row.frame;
     if (frame < 0) frame = row.frame;
-    std::vector<S> r(nr);
+    static thread_local std::vector<S> r;
+    r.resize(nr);
     switch (row.kind) {
       case AGX_RES_STATE:
         for (int i = 0; i < 2 * nv; ++i) r[i] = x[i] - rref[i];
@@ -635,12 +641,12 @@ void node_calc_diff_n(const Model &m, const Ocp &o, bool terminal, double dt, co
                       const double *u, const double *ref, const int32_t *frames, NodeOut &out) {
   typedef Dual<N> D;
   const int nv = m.nv, nx = 2 * nv, nu = nv;
-  std::vector<D> xd(nx), ud(nu), xn(nx);
+  static thread_local std::vector<D> xd, ud, xn, res;
+  static thread_local std::vector<double> ar, arr, rw;
+  static thread_local std::vector<int> rnr;
+  xd.resize(nx); ud.resize(nu); xn.resize(nx); res.reserve(64);
   for (int i = 0; i < nx; ++i) { xd[i] = D(x[i]); xd[i].d[i] = 1.0; }
   for (int i = 0; i < nu; ++i) { ud[i] = D(terminal ? 0.0 : u[i]); ud[i].d[nx + i] = 1.0; }
-  std::vector<D> res;
-  std::vector<double> ar, arr, rw;
-  std::vector<int> rnr;
   double cost;
   node_eval<D>(m, o, terminal, dt, xd.data(), ud.data(), ref, frames, xn.data(), res, ar, arr, rw, rnr, cost);
   out.cost = cost;
@@ -685,9 +691,9 @@ void node_calc_diff(const Model &m, const Ocp &o, bool terminal, double dt, cons
 void node_calc(const Model &m, const Ocp &o, bool terminal, double dt, const double *x, const double *u,
                const double *ref, const int32_t *frames, double *xnext, double &cost,
                std::vector<double> *residuals = nullptr) {
-  std::vector<double> res, ar, arr, rw;
-  std::vector<int> rnr;
-  std::vector<double> uz(m.nv, 0.0);
+  static thread_local std::vector<double> res, ar, arr, rw, uz;
+  static thread_local std::vector<int> rnr;
+  uz.assign(m.nv, 0.0);
   node_eval<double>(m, o, terminal, dt, x, terminal ? uz.data() : u, ref, frames, xnext, res, ar, arr, rw, rnr, cost);
   if (residuals) *residuals = res;
 }

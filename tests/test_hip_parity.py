@@ -1,0 +1,261 @@
+"""Parity of the HIP path against the oracle and the golden fixture (needs an MI355X).
+
+Everything goes through the C ABI of libagimus_hip.so.  Tolerances: fp64, relative 1e-9 on
+kernel outputs and on xs/us after a full multi-iteration solve, 1e-7 on the Riccati gains K
+(they amplify round-off through Quu^-1), identical iteration counts."""
+import numpy as np
+import pytest
+
+from agimus_controller_amd import _abi, workloads
+from agimus_controller_amd.factory import robot_tables as rt
+from oracle.oracle import Oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(a, b):
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-300))
+
+
+MODELS = {
+    "panda": lambda: rt.panda_table(),
+    "chain4": lambda: rt.chain_table(4, seed=7),
+    "chain6": lambda: rt.chain_table(6, seed=8),
+    "pendulum": lambda: rt.pendulum_table(),
+}
+
+
+@pytest.mark.parametrize("name", list(MODELS))
+def test_rigid_body_primitives(hip_backend, name):
+    table = MODELS[name]()
+    nv = table.nv
+    frame = len(table.frame_names) - 1
+    po, ref, x0, xs, us = workloads.random_goal_problem(table, 4, 0.01, 2, seed=1, frame=frame)
+    h, o = hip_backend.HipOcp(table, po, 2), Oracle(table, po, 2)
+    rng = np.random.default_rng(0)
+    q, v, a = rng.uniform(-1.5, 1.5, (3, 33, nv))
+    assert rel(h.rnea(q, v, a), o.rnea(q, v, a).reshape(33, nv)) < 1e-12
+    assert rel(h.frame_placement(frame, q), o.frame_placement(frame, q)) < 1e-12
+    x = np.concatenate([q, v], axis=1)
+    assert rel(h.integrate(x, 3 * a), o.integrate(x, 3 * a).reshape(33, 2 * nv)) < 1e-11
+
+
+@pytest.mark.parametrize("name,rows", [("panda", "goal"), ("panda", "reg"), ("chain4", "goal"), ("chain6", "goal"), ("pendulum", "goal")])
+def test_derivative_tiles(hip_backend, name, rows):
+    table = MODELS[name]()
+    frame = len(table.frame_names) - 1
+    B, T = 6, 11
+    po, ref, x0, xs, us = workloads.random_goal_problem(table, T, 0.01, B, seed=3, frame=frame, rows=rows,
+                                                        timesteps=[0.01] * 6 + [0.02] * 3 + [0.04] * 2)
+    h, o = hip_backend.HipOcp(table, po, B), Oracle(table, po, B)
+    h.set_refs(ref)
+    h.upload_warmstart(xs, us)
+    got, want = h.calc_diff(), o.calc_diff(ref, None, xs, us)
+    for field, s in _abi.tile_slices(table.nv).items():
+        scale = max(np.abs(want[..., s]).max(), 1e-300)
+        assert np.abs(got[..., s] - want[..., s]).max() <= 1e-11 * scale + 1e-14, field
+
+
+def test_frame_id_override_per_node(hip_backend, panda):
+    """obj.id = get_frame_id(...) at every update (ocp_croco_generic.py:208): per-node frame ids."""
+    tcp, l5 = panda.frame_id("panda_hand_tcp"), panda.frame_id("panda_link5")
+    B, T = 2, 5
+    po, ref, x0, xs, us = workloads.random_goal_problem(panda, T, 0.01, B, seed=5, frame=tcp)
+    frames = po.default_frames(B)
+    frames[:, ::2, 2] = l5  # running row 2 = placement
+    frames[:, T, 1] = l5  # terminal row 1 = placement
+    h, o = hip_backend.HipOcp(panda, po, B), Oracle(panda, po, B)
+    h.set_refs(ref, frames)
+    h.upload_warmstart(xs, us)
+    got, want = h.calc_diff(), o.calc_diff(ref, frames, xs, us)
+    assert rel(got, want) < 1e-11
+    h.set_refs(ref)
+    assert rel(h.calc_diff(), want) > 1e-3  # and it matters
+
+
+def test_direction_kernel_on_oracle_tiles(hip_backend, panda):
+    tcp = panda.frame_id("panda_hand_tcp")
+    B, T = 5, 30
+    po, ref, x0, xs, us = workloads.random_goal_problem(panda, T, 0.01, B, seed=6, frame=tcp)
+    h, o = hip_backend.HipOcp(panda, po, B), Oracle(panda, po, B)
+    xs[:, 0] = x0
+    tiles = o.calc_diff(ref, None, xs, us)
+    h.upload_tiles(tiles)
+    K, k, dx, du, kkt = h.direction()
+    Ko, ko, dxo, duo, kkto = o.direction(tiles)
+    assert rel(dx, dxo) < 1e-9 and rel(du, duo) < 1e-9 and rel(k, ko) < 1e-9
+    assert rel(K, Ko) < 1e-8
+    np.testing.assert_allclose(kkt, kkto, rtol=1e-7)
+
+
+@pytest.mark.parametrize("name,rows,T,seed", [("panda", "goal", 25, 10), ("panda", "reg", 40, 11), ("chain4", "goal", 12, 12), ("chain6", "goal", 15, 13)])
+def test_full_solve_matches_oracle(hip_backend, name, rows, T, seed):
+    table = MODELS[name]()
+    frame = len(table.frame_names) - 1
+    B = 7
+    po, ref, x0, xs, us = workloads.random_goal_problem(table, T, 0.01, B, seed=seed, frame=frame, rows=rows)
+    h, o = hip_backend.HipOcp(table, po, B), Oracle(table, po, B)
+    h.set_refs(ref)
+    xs_h, us_h, K_h, st_h = h.solve(x0, xs, us, 12)
+    xs_o, us_o, K_o, st_o = o.solve(ref, None, x0, xs, us, 12, nthreads=8)
+    np.testing.assert_array_equal(st_h["iter"], st_o["iter"])
+    np.testing.assert_array_equal(st_h["solved"], st_o["solved"])
+    assert rel(xs_h, xs_o) < 1e-9 and rel(us_h, us_o) < 1e-9
+    assert rel(K_h, K_o) < 1e-7
+    np.testing.assert_allclose(st_h["kkt"], st_o["kkt"], rtol=1e-6, atol=1e-12)
+    np.testing.assert_allclose(st_h["cost"], st_o["cost"], rtol=1e-10)
+    np.testing.assert_array_equal(xs_h[:, 0], x0)  # the solver pins xs[0] = x0
+
+
+def test_iteration_cap_and_unsolved_status(hip_backend, panda):
+    tcp = panda.frame_id("panda_hand_tcp")
+    po, ref, x0, xs, us = workloads.random_goal_problem(panda, 20, 0.01, 3, seed=14, frame=tcp)
+    h, o = hip_backend.HipOcp(panda, po, 3), Oracle(panda, po, 3)
+    h.set_refs(ref)
+    xs_h, us_h, K_h, st_h = h.solve(x0, xs, us, 1)
+    xs_o, us_o, K_o, st_o = o.solve(ref, None, x0, xs, us, 1)
+    assert list(st_h["iter"]) == [1, 1, 1] and not st_h["solved"].any()
+    assert rel(xs_h, xs_o) < 1e-10 and rel(K_h, K_o) < 1e-8
+
+
+def test_golden_fixture_through_the_c_abi(hip_backend, golden):
+    """The reference's golden case (tests/test_ocp_croco_base.py:175-204, 6 decimals upstream)."""
+    table, po, ref, x0, xs0, us0 = workloads.golden_problem()
+    h = hip_backend.HipOcp(table, po, 1)
+    h.set_refs(ref)
+    xs, us, K, st = h.solve(x0, xs0, us0, 100)
+    assert st["solved"][0] == 1
+    np.testing.assert_allclose(xs[0], golden["states"], rtol=0, atol=1e-8)
+    np.testing.assert_allclose(us[0], golden["feed_forward_terms"], rtol=0, atol=1e-7)
+    np.testing.assert_allclose(K[0], golden["ricatti_gains"], rtol=0, atol=1e-7)
+
+
+def test_warm_start_shift_on_device(hip_backend):
+    table = rt.chain_table(3, seed=9)
+    rows = [_abi.RowSpec(_abi.RES_STATE)]
+    ts = [0.1, 0.1, 0.2, 0.2, 0.4]
+    po = _abi.PackedOcp(3, ts, rows, rows)
+    B = 4
+    rng = np.random.default_rng(2)
+    xs, us = rng.normal(size=(B, 6, 6)), rng.normal(size=(B, 5, 3))
+    h, o = hip_backend.HipOcp(table, po, B), Oracle(table, po, B)
+    h.upload_warmstart(xs, us)
+    h.shift_warmstart()
+    xs_h, us_h, _, _ = h.download(want_K=False)
+    xs_o, us_o = o.shift_warmstart(xs, us)
+    np.testing.assert_array_equal(xs_h[:, :2], xs_o[:, :2])  # pure copies are bit exact
+    np.testing.assert_array_equal(us_h, us_o)
+    assert rel(xs_h, xs_o) < 1e-13
+    np.testing.assert_array_equal(xs_h[:, -1], xs[:, -1])
+
+
+def test_residual_readback(hip_backend, panda):
+    tcp = panda.frame_id("panda_hand_tcp")
+    B, T = 2, 6
+    po, ref, x0, xs, us = workloads.random_goal_problem(panda, T, 0.01, B, seed=15, frame=tcp)
+    h, o = hip_backend.HipOcp(panda, po, B), Oracle(panda, po, B)
+    h.set_refs(ref)
+    h.upload_warmstart(xs, us)
+    offs = np.cumsum([0] + [_abi.row_nr(r.kind, 7) for r in po.running])
+    for row in range(3):
+        got = h.residuals(row)
+        for b in range(B):
+            for t in range(T):
+                _, _, res = o.node_calc(False, 0.01, xs[b, t], us[b, t], ref[b, t])
+                np.testing.assert_allclose(got[b, t], res[offs[row]:offs[row + 1]], rtol=1e-11, atol=1e-13)
+
+
+def test_resident_sine_trajectory_and_mpc_steps(hip_backend, panda):
+    """Device-resident reference generator + receding-horizon steps vs a host restatement built on the oracle."""
+    tcp = panda.frame_id("panda_hand_tcp")
+    B, T, dt, NP = 3, 16, 0.01, 24
+    running, terminal = workloads.goal_reaching_rows(tcp)
+    po = _abi.PackedOcp(7, [dt] * T, running, terminal)
+    h, o = hip_backend.HipOcp(panda, po, B), Oracle(panda, po, B)
+    q0, amp, puls, scale, t0 = workloads.sine_batch_params(B)
+    w = workloads.SINE_WEIGHTS
+    h.sine_trajectory(NP, dt, q0, amp, puls, scale, t0, w["w_q"], w["w_qdot"], w["w_effort"], w["w_pose"], tcp)
+    # host restatement of sine_wave_configuration_space.py:41-72 with oracle RNEA / FK
+    def sample(k):
+        t = t0 + k * dt
+        s = np.clip(t[:, None] / scale, 0.0, 1.0)
+        ramp = 10 * s**3 - 15 * s**4 + 6 * s**5
+        dramp = np.where((s > 0) & (s < 1), (30 * s**2 - 60 * s**3 + 30 * s**4) / scale, 0.0)
+        ddramp = np.where((s > 0) & (s < 1), (60 * s - 180 * s**2 + 120 * s**3) / scale**2, 0.0)
+        sw, cw = np.sin(puls * t[:, None]), np.cos(puls * t[:, None])
+        q = q0 + amp * ramp * sw
+        dq = amp * (dramp * sw + ramp * puls * cw)
+        ddq = amp * (ddramp * sw + 2 * dramp * puls * cw - ramp * puls**2 * sw)
+        return q, dq, ddq, o.rnea(q, dq, ddq).reshape(B, 7), o.frame_placement(tcp, q)
+    for k in (0, 5, NP - 1):
+        got = h.traj_point(k)
+        for g, wnt in zip(got, sample(k)):
+            np.testing.assert_allclose(g, wnt, rtol=1e-11, atol=1e-12)
+    def window_tile(k0):
+        ref = po.new_ref_tile(B)
+        for t in range(T + 1):
+            q, dq, ddq, u, pose = sample(k0 + t)
+            term = t == T
+            rows = terminal if term else running
+            offs = po.terminal_offsets if term else po.running_offsets
+            for r, off in zip(rows, offs):
+                nref, nr = _abi.row_nref(r.kind, 7), _abi.row_nr(r.kind, 7)
+                seg = ref[:, t, off:off + 1 + nref + nr]
+                seg[:, 0] = 1.0
+                if r.kind == _abi.RES_STATE:
+                    seg[:, 1:15] = np.concatenate([q, dq], 1)
+                    seg[:, 15:22], seg[:, 22:29] = w["w_q"], w["w_qdot"]
+                elif r.kind == _abi.RES_CONTROL:
+                    seg[:, 1:8], seg[:, 8:15] = u, w["w_effort"]
+                else:
+                    seg[:, 1:13], seg[:, 13:19] = pose, w["w_pose"]
+        return ref
+    # three receding-horizon steps, closed on the own prediction
+    xs_o = us_o = None
+    for step in range(3):
+        h.mpc_step(step, 10, first=(step == 0))
+        xs_h, us_h, K_h, st_h = h.download()
+        ref = window_tile(step)
+        if step == 0:
+            pts = [sample(t) for t in range(T + 1)]
+            xs_ws = np.stack([np.concatenate([p[0], p[1]], 1) for p in pts], 1)
+            us_ws = np.stack([p[3] for p in pts[:T]], 1)
+            x0 = xs_ws[:, 0].copy()
+        else:
+            x0 = xs_o[:, 1].copy()
+            xs_ws, us_ws = o.shift_warmstart(xs_o, us_o)
+        xs_o, us_o, K_o, st_o = o.solve(ref, None, x0, xs_ws, us_ws, 10)
+        np.testing.assert_array_equal(st_h["iter"], st_o["iter"])
+        assert rel(xs_h, xs_o) < 1e-9 and rel(us_h, us_o) < 1e-8 and rel(K_h, K_o) < 1e-7
+    us0, K0, x1, st = h.download_first()
+    np.testing.assert_array_equal(us0, us_h[:, 0])
+    np.testing.assert_array_equal(K0, K_h[:, 0])
+    np.testing.assert_array_equal(x1, xs_h[:, 1])
+
+
+def test_full_size_properties(hip_backend, panda):
+    """BASELINE.json sizes (T = 100, B = 1024): size-independent properties instead of an oracle run:
+    replicated instances give bit-identical results (no cross-instance coupling, no races), the
+    result is a KKT point of its own linearisation (direction ~ 0 after convergence), xs[0] = x0."""
+    tcp = panda.frame_id("panda_hand_tcp")
+    B, T, R = 1024, 100, 4
+    po, ref, x0, xs, us = workloads.random_goal_problem(panda, T, 0.01, R, seed=20, frame=tcp)
+    rep = B // R
+    h = hip_backend.HipOcp(panda, po, B)
+    h.set_refs(np.tile(ref, (rep, 1, 1)))
+    xs_h, us_h, K_h, st = h.solve(np.tile(x0, (rep, 1)), np.tile(xs, (rep, 1, 1)), np.tile(us, (rep, 1, 1)), 30)
+    assert st["solved"].all() and np.isfinite(K_h).all()
+    for r in range(R):
+        np.testing.assert_array_equal(xs_h[r::R], np.broadcast_to(xs_h[r], (rep,) + xs_h[r].shape))
+        np.testing.assert_array_equal(K_h[r::R], np.broadcast_to(K_h[r], (rep,) + K_h[r].shape))
+        np.testing.assert_array_equal(st["iter"][r::R], st["iter"][r])
+    np.testing.assert_array_equal(xs_h[:, 0], np.tile(x0, (rep, 1)))
+    # the first R instances agree with the oracle
+    xs_o, us_o, K_o, st_o = Oracle(panda, po, R).solve(ref, None, x0, xs, us, 30, nthreads=4)
+    np.testing.assert_array_equal(st["iter"][:R], st_o["iter"])
+    assert rel(xs_h[:R], xs_o) < 1e-9 and rel(K_h[:R], K_o) < 1e-7
+    # re-solving from the solution returns immediately with the same gains
+    xs2, us2, K2, st2 = h.solve(np.tile(x0, (rep, 1)), xs_h, us_h, 30)
+    assert (st2["iter"] == 0).all() and st2["solved"].all()
+    np.testing.assert_array_equal(xs2, xs_h)
+    assert rel(K2, K_h) < 1e-12
