@@ -1,0 +1,282 @@
+"""Host-side mirror of the reference interface (CPU only): parameters, buffers, trajectory
+points, YAML schema, SE3 helpers, batch sharding incl. a 2-rank gloo scatter/gather."""
+import json
+import os
+import pathlib
+import subprocess
+import sys
+import textwrap
+
+import numpy as np
+import pytest
+import yaml
+
+from agimus_controller_amd import _abi, batched, se3
+from agimus_controller_amd.factory.robot_model import RobotModelParameters, RobotModels, panda_robot_models
+from agimus_controller_amd.factory import robot_tables as rt
+from agimus_controller_amd.mpc_data import MPCDebugData, OCPDebugData, OCPResults
+from agimus_controller_amd.ocp import ocp_croco_generic as gen
+from agimus_controller_amd.ocp_param_base import DTFactorsNSeq, OCPParamsBaseCroco
+from agimus_controller_amd.trajectories.quintic_trajectory import QuinticTrajectory
+from agimus_controller_amd.trajectories.sine_wave_params import SinWaveParams
+from agimus_controller_amd.trajectory import (TrajectoryBuffer, TrajectoryPoint, TrajectoryPointWeights,
+                                              WeightedTrajectoryPoint, interpolate_weights)
+
+ROOT = pathlib.Path(__file__).resolve().parents[1]
+FIX = json.loads((ROOT / "tests" / "golden" / "host_fixtures.json").read_text())
+
+
+@pytest.mark.parametrize("case", FIX["params"])
+def test_params_match_reference_outputs(case):
+    p = OCPParamsBaseCroco(dt=case["dt"], solver_iters=10, horizon_size=sum(case["n_steps"]),
+                           dt_factor_n_seq=DTFactorsNSeq(factors=case["factors"], n_steps=case["n_steps"]))
+    assert list(p.timesteps) == case["timesteps"]
+    assert p.total_time == case["total_time"] and p.n_controls == case["n_controls"]
+    for k in ("qp_iters", "termination_tolerance", "eps_abs", "eps_rel", "n_threads", "use_filter_line_search"):
+        assert getattr(p, k) == case[k]
+
+
+def test_params_horizon_check():
+    with pytest.raises(AssertionError):
+        OCPParamsBaseCroco(dt=0.1, solver_iters=1, horizon_size=4, dt_factor_n_seq=DTFactorsNSeq(factors=[1], n_steps=[3]))
+
+
+def test_quintic_and_sine_params_match_reference_outputs():
+    q = QuinticTrajectory([0.2, 0.5, 1.0])
+    for row in FIX["quintic"]:
+        p, v, a = q.get_value_at_t(row["t"])
+        np.testing.assert_allclose(p, row["p"], rtol=1e-13, atol=1e-15)
+        np.testing.assert_allclose(v, row["v"], rtol=1e-13, atol=1e-13)
+        np.testing.assert_allclose(a, row["a"], rtol=1e-13, atol=1e-12)
+    s = SinWaveParams(amplitude=[0.1, 0.2], period=[4.0, 0.0], scale_duration=[0.2, 0.2])
+    np.testing.assert_allclose(s.frequency, FIX["sine"][0]["frequency"])
+    np.testing.assert_allclose(s.pulsation, FIX["sine"][0]["pulsation"])
+
+
+def test_buffer_horizon_indexes_known_answer():
+    """agimus_controller/tests/test_buffer.py:82-93."""
+    buf = TrajectoryBuffer(DTFactorsNSeq(factors=[1, 2, 3, 4, 5], n_steps=[2, 2, 2, 2, 2]))
+    assert buf.compute_horizon_indexes() == [0, 1, 2, 4, 6, 9, 12, 16, 20, 25, 30]
+    for i in range(31):
+        buf.append(i)
+    assert buf.horizon == [0, 1, 2, 4, 6, 9, 12, 16, 20, 25, 30]
+    buf.clear_past()
+    assert len(buf) == 30 and buf[0] == 1
+    with pytest.raises(AssertionError):  # one point short of the last horizon index
+        buf.horizon
+    buf.append(31)
+    assert buf.horizon[0] == 1 and buf.horizon[-1] == 31
+
+
+def _wpt(seed):
+    rng = np.random.default_rng(seed)
+    pt = TrajectoryPoint(time_ns=seed, robot_configuration=rng.random(7), robot_velocity=rng.random(7),
+                         robot_acceleration=rng.random(7), robot_effort=rng.random(7),
+                         end_effector_poses={"tcp": se3.SE3.Random(rng)})
+    w = TrajectoryPointWeights(w_robot_configuration=rng.random(7), w_robot_velocity=rng.random(7),
+                               w_robot_acceleration=rng.random(7), w_robot_effort=rng.random(7),
+                               w_end_effector_poses={"tcp": rng.random(6)}, w_collision_avoidance=1.5)
+    return WeightedTrajectoryPoint(pt, w)
+
+
+def test_trajectory_point_equality_and_state():
+    a, b, c = _wpt(1), _wpt(1), _wpt(2)
+    assert a == b and a != c and a.point != c.point and a.weights != c.weights
+    np.testing.assert_array_equal(a.point.robot_state, np.concatenate([a.point.robot_configuration, a.point.robot_velocity]))
+    np.testing.assert_array_equal(a.weights.w_robot_state, np.concatenate([a.weights.w_robot_configuration, a.weights.w_robot_velocity]))
+    assert TrajectoryPoint() == TrajectoryPoint() and TrajectoryPoint(robot_effort=np.ones(2)) != TrajectoryPoint()
+
+
+def test_interpolate_weights():
+    a, c = _wpt(1).weights, _wpt(2).weights
+    mid = interpolate_weights(a, c, 0.25)
+    np.testing.assert_allclose(mid.w_robot_effort, 0.75 * a.w_robot_effort + 0.25 * c.w_robot_effort)
+    np.testing.assert_allclose(mid.w_end_effector_poses["tcp"], 0.75 * a.w_end_effector_poses["tcp"] + 0.25 * c.w_end_effector_poses["tcp"])
+    assert interpolate_weights(a, c, 7.0) == interpolate_weights(a, c, 1.0)
+
+
+def test_data_containers_defaults():
+    assert OCPResults().states == [] and OCPDebugData().problem_solved is False and MPCDebugData().reference_id == -1
+
+
+def test_se3_helpers():
+    rng = np.random.default_rng(3)
+    A, B = se3.SE3.Random(rng), se3.SE3.Random(rng)
+    np.testing.assert_allclose((A * A.inverse()).homogeneous, np.eye(4), atol=1e-14)
+    np.testing.assert_allclose((A * B).homogeneous, A.homogeneous @ B.homogeneous, atol=1e-14)
+    v = se3.SE3ToXYZQUAT(A)
+    np.testing.assert_allclose(se3.XYZQUATToSE3(v).homogeneous, A.homogeneous, atol=1e-14)
+    np.testing.assert_allclose(se3.as_se3_12(v), se3.as_se3_12(A), atol=1e-14)
+    np.testing.assert_allclose(se3.as_se3_12(A.homogeneous), se3.as_se3_12(A))
+    assert se3.SE3.Identity().isIdentity() and not A.isIdentity()
+
+
+REFERENCE_STYLE_YAML = textwrap.dedent("""
+    running_model:
+      class: IntegratedActionModelEuler
+      differential:
+        class: DifferentialActionModelFreeFwdDynamics
+        costs:
+        - name: control_reg
+          update: true
+          weight: 1.0
+          cost:
+            class: CostModelResidual
+            activation:
+              class: ActivationModelWeightedQuad
+              weights: 1.0
+            residual:
+              class: ResidualModelControl
+        - name: goal_tracking
+          update: true
+          weight: 2.5
+          publish_residual: true
+          cost:
+            class: CostModelResidual
+            activation:
+              class: ActivationModelWeightedQuad
+              weights: 1.0
+            residual:
+              class: ResidualModelFramePlacement
+              id: panda_hand_tcp
+        - name: ee_z
+          active: false
+          cost:
+            class: CostModelResidual
+            residual:
+              class: ResidualModelFrameTranslationStatic
+              frame_id: panda_link5
+              pref: [0.1, 0.2, 0.3, 0, 0, 0, 1]
+    terminal_model:
+      class: IntegratedActionModelEuler
+      differential:
+        class: DifferentialActionModelFreeFwdDynamics
+        costs:
+        - name: state_reg
+          update: true
+          weight: 1.0
+          cost:
+            class: CostModelResidual
+            activation:
+              class: ActivationModelWeightedQuad
+              weights: [1, 1, 1, 1, 1, 1, 1, 2, 2, 2, 2, 2, 2, 2]
+            residual:
+              class: ResidualModelState
+    """)
+
+
+def test_yaml_schema_lowers_to_row_tables():
+    sp = gen.ShootingProblem(**yaml.safe_load(REFERENCE_STYLE_YAML))
+    rm = panda_robot_models()
+    bd = gen.BuildData(rm.robot_model, 7)
+    rows = sp.running_model.differential.lower(bd)
+    assert [r.kind for r in rows] == [_abi.RES_CONTROL, _abi.RES_FRAME_PLACEMENT, _abi.RES_FRAME_TRANSLATION]
+    assert rows[1].frame == rm.robot_model.getFrameId("panda_hand_tcp") and rows[2].frame == rm.robot_model.getFrameId("panda_link5")
+    assert [r.active for r in rows] == [True, True, False]
+    item = sp.running_model.differential.costs[2]
+    assert isinstance(item, gen.CostModelSumItem) and item.weight == 1.0 and item.update is False
+    np.testing.assert_array_equal(item.cost.residual.reference(bd), [0.1, 0.2, 0.3])
+    term = sp.terminal_model.differential
+    np.testing.assert_array_equal(term.costs[0].cost.activation.initial_weights(14), [1] * 7 + [2] * 7)
+    assert not sp.needs_colmpc_state()
+    assert gen.as_dict(term.costs[0].cost.residual)["class"] == "ResidualModelState"
+
+
+def test_yaml_unknown_class_and_unsupported_components():
+    with pytest.raises(KeyError):
+        gen.create_croco_dataclasses({"class": "NoSuchThing"})
+    bad = yaml.safe_load(REFERENCE_STYLE_YAML)
+    bad["running_model"]["differential"]["constraints"] = [
+        {"name": "torque", "constraint": {"class": "ConstraintModelControlLimit"}}]
+    sp = gen.ShootingProblem(**bad)
+    assert isinstance(sp.running_model.differential.constraints[0].constraint.residual, gen.ResidualModelControl)
+    with pytest.raises(NotImplementedError, match="constraints"):
+        sp.running_model.differential.lower(gen.BuildData(panda_robot_models().robot_model, 7))
+    coll = yaml.safe_load(REFERENCE_STYLE_YAML)
+    coll["running_model"]["differential"]["costs"].append(
+        {"name": "col", "cost": {"class": "CostModelResidual", "residual": {"class": "ResidualDistanceCollision2", "collision_pair": ["a", "b"]},
+                                 "activation": {"class": "ActivationModelQuadExp", "alpha": 1e-4}}})
+    sp = gen.ShootingProblem(**coll)
+    assert sp.needs_colmpc_state()
+    with pytest.raises(NotImplementedError, match="ResidualDistanceCollision2"):
+        sp.running_model.differential.lower(gen.BuildData(panda_robot_models().robot_model, 7))
+
+
+def test_add_modules_extends_the_schema():
+    import dataclasses
+
+    @dataclasses.dataclass
+    class MyState(gen.ResidualModelState):
+        pass
+
+    gen.add_modules({"MyState": MyState})
+    obj = gen.create_croco_dataclasses({"class": "MyState", "xref": [0.0] * 14})
+    assert isinstance(obj, MyState)
+
+
+def test_robot_models_surface():
+    rm = panda_robot_models(armature=0.2)
+    m = rm.robot_model
+    assert m.nq == m.nv == 7 and m.existFrame("panda_hand_tcp") and not m.existFrame("nope")
+    assert m.getFrameId("nope") == m.nframes
+    np.testing.assert_array_equal(rm.armature, np.full(7, 0.2))
+    np.testing.assert_array_equal(rm.table.armature, np.full(7, 0.2))
+    with pytest.raises(ValueError, match="Armature"):
+        RobotModelParameters(table=rt.panda_table(), armature=np.ones(3))
+    with pytest.raises(ValueError, match="free-flyer"):
+        RobotModelParameters(table=rt.panda_table(), free_flyer=True)
+    assert RobotModels(RobotModelParameters(table=rt.chain_table(4))).robot_model.nv == 4
+
+
+def test_shard_bounds_cover_the_batch():
+    for n, w in [(1024, 8), (10, 3), (3, 8), (1, 1)]:
+        spans = [batched.shard_bounds(n, r, w) for r in range(w)]
+        assert spans[0][0] == 0 and spans[-1][1] == n
+        assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+        sizes = [b - a for a, b in spans]
+        assert max(sizes) - min(sizes) <= 1
+
+
+WORKER = textwrap.dedent("""
+    import os, sys
+    import numpy as np
+    import torch.distributed as dist
+    sys.path.insert(0, {root!r})
+    from agimus_controller_amd import batched, workloads, _abi
+    from agimus_controller_amd.factory import robot_tables as rt
+    from oracle.oracle import Oracle
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    table = rt.chain_table(3, seed=1)
+    B, T = 5, 6
+    po, ref, x0, xs, us = workloads.random_goal_problem(table, T, 0.02, B, seed=4)
+    # root scatters the inputs, every rank solves its shard (the CPU checker stands in for the GPU), root gathers
+    parts = [batched.scatter_rows(a if rank == 0 else None, B) for a in (ref, x0, xs, us)]
+    lo, hi = batched.shard_bounds(B, rank, world)
+    assert parts[0].shape[0] == hi - lo
+    np.testing.assert_array_equal(parts[1], x0[lo:hi])
+    o = Oracle(table, po, hi - lo)
+    xs_l, us_l, K_l, st_l = o.solve(parts[0], None, parts[1], parts[2], parts[3], 6)
+    xs_all = batched.gather_rows(xs_l, B)
+    K_all = batched.gather_rows(K_l, B)
+    it_all = batched.gather_rows(st_l["iter"].astype(np.int64), B)
+    if rank == 0:
+        xs_ref, us_ref, K_ref, st_ref = Oracle(table, po, B).solve(ref, None, x0, xs, us, 6)
+        np.testing.assert_array_equal(xs_all, xs_ref)
+        np.testing.assert_array_equal(K_all, K_ref)
+        np.testing.assert_array_equal(it_all, st_ref["iter"])
+        print("SHARD_OK")
+    dist.destroy_process_group()
+    """)
+
+
+def test_two_rank_scatter_solve_gather_gloo(tmp_path):
+    """N > 1 path on CPU: world_size 2, gloo, shard -> solve -> gather equals the unsharded solve."""
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER.format(root=str(ROOT)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", "29731", str(script)]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
+    assert "SHARD_OK" in res.stdout
