@@ -28,7 +28,7 @@ EXPORTED_SYMBOLS = [
     "agx_ocp_upload_warmstart", "agx_ocp_solve_resident", "agx_ocp_download", "agx_ocp_download_first",
     "agx_ocp_shift_warmstart", "agx_ocp_x0_from_prediction", "agx_ocp_integrate", "agx_model_rnea",
     "agx_model_frame_placement", "agx_ocp_get_residuals", "agx_ocp_calc_diff", "agx_ocp_direction",
-    "agx_ocp_upload_tiles", "agx_ocp_time_kernel", "agx_traj_sine_create", "agx_traj_set_window",
+    "agx_ocp_time_kernel", "agx_traj_sine_create", "agx_traj_set_window",
     "agx_traj_get_point", "agx_traj_warmstart_from_reference", "agx_ocp_mpc_step",
 ]  # fmt: skip
 
@@ -217,9 +217,6 @@ class HipOcp:
         tiles = np.empty((self.B, self.T + 1, self.tile)) if want_tiles else None
         _chk(lib().agx_ocp_calc_diff(self._h, _p(tiles)))
         return tiles
-
-    def upload_tiles(self, tiles):
-        _chk(lib().agx_ocp_upload_tiles(self._h, _p(_f8(tiles, (self.B, self.T + 1, self.tile)))))
 
     def direction(self):
         K = np.empty((self.B, self.T, self.nu, self.nx))

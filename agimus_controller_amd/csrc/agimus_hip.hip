@@ -9,6 +9,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -47,6 +48,9 @@ struct agx_ocp {
   DevOcp *d_ocp = nullptr;
   double *d_dt = nullptr, *d_xs = nullptr, *d_us = nullptr, *d_x0 = nullptr, *d_tiles = nullptr;
   double *d_Kws = nullptr, *d_kws = nullptr, *d_Kout = nullptr, *d_dx = nullptr, *d_du = nullptr;
+  double *d_qt = nullptr, *d_aux = nullptr, *d_w = nullptr;  // QP tiles, aux tiles, acceleration steps
+  int qt_size = 0, aux_size = 0;
+  bool k1_lanes = true;  // AGX_K1_LANES=0 selects the one-lane-per-node derivative kernel
   double *d_ref = nullptr;  // owned tile [B][T+1][stride]
   int *d_frames = nullptr;  // owned [B][T+1][AGX_MAX_ROWS]
   bool frames_set = false;
@@ -114,7 +118,14 @@ int dispatch(int nv, bool chain, F &&f) {
   return fail("no kernel instantiation for nv = " + std::to_string(nv) + " (compiled: 1,2,3,4,6,7)");
 }
 
+int ensure_canonical_tiles(agx_ocp *o) {
+  if (o->d_tiles) return 0;
+  HIPCHK(hipMalloc((void **)&o->d_tiles, sizeof(double) * (size_t)o->B * (o->T + 1) * o->tile));
+  return 0;
+}
+
 int launch_calc_diff(agx_ocp *o, bool masked, bool running_only = false) {
+  if (ensure_canonical_tiles(o)) return -1;
   return dispatch(o->nv, o->chain, [&](auto NVc, auto CHc) -> int {
     constexpr int NV = decltype(NVc)::value;
     constexpr bool CH = decltype(CHc)::value;
@@ -130,23 +141,65 @@ int launch_calc_diff(agx_ocp *o, bool masked, bool running_only = false) {
   });
 }
 
-int launch_direction(agx_ocp *o, int iter, int mode) {
+// K1 production: QP tiles in acceleration-input form.  Serial chains use the 8-lanes-per-node
+// kernel (agx_k1_lanes.hpp); trees fall back to one lane per node.
+int launch_calc_qp(agx_ocp *o, bool running_only = false) {
   return dispatch(o->nv, o->chain, [&](auto NVc, auto CHc) -> int {
     constexpr int NV = decltype(NVc)::value;
-    hipLaunchKernelGGL((agx::k_direction<NV>), dim3(o->B), dim3(64), 0, o->stream, o->d_ocp, o->d_tiles, o->d_Kws, o->d_kws,
-                       o->d_Kout, o->d_dx, o->d_du, o->d_state, iter, mode, o->d_ndone);
+    constexpr bool CH = decltype(CHc)::value;
+    const long long units = (long long)o->B * o->T;
+    if (CH && o->k1_lanes) {
+      hipLaunchKernelGGL((agx::k_calc_qp_lj<NV, false>), dim3((int)((units * 8 + 127) / 128)), dim3(128), 0, o->stream, o->d_model,
+                         o->d_ocp, o->d_dt, o->d_xs, o->d_us, o->rv, o->d_qt, o->d_aux, o->d_state);
+      if (!running_only)
+        hipLaunchKernelGGL((agx::k_calc_qp_lj<NV, true>), dim3((int)(((long long)o->B * 8 + 127) / 128)), dim3(128), 0, o->stream,
+                           o->d_model, o->d_ocp, o->d_dt, o->d_xs, o->d_us, o->rv, o->d_qt, o->d_aux, o->d_state);
+    } else {
+      hipLaunchKernelGGL((agx::k_calc_qp<NV, CH>), dim3((int)((units + 63) / 64)), dim3(64), 0, o->stream, o->d_model, o->d_ocp,
+                         o->d_dt, o->d_xs, o->d_us, o->rv, o->d_qt, o->d_aux, o->d_state);
+      if (!running_only)
+        hipLaunchKernelGGL((agx::k_calc_qp_term<NV, CH>), dim3((o->B + 63) / 64), dim3(64), 0, o->stream, o->d_model, o->d_ocp,
+                           o->d_xs, o->rv, o->d_qt, o->d_aux, o->d_state);
+    }
     HIPCHK(hipGetLastError());
     return 0;
   });
 }
 
-int launch_linesearch(agx_ocp *o, int iter, int max_iter) {
-  if (o->T + 1 > 512) return fail("line search kernel supports horizons up to 511 nodes");
+int launch_riccati(agx_ocp *o, int forward, int gains_pass) {
+  return dispatch(o->nv, o->chain, [&](auto NVc, auto CHc) -> int {
+    constexpr int NV = decltype(NVc)::value;
+    hipLaunchKernelGGL((agx::k_riccati<NV>), dim3(o->B), dim3(64), 0, o->stream, o->d_ocp, o->d_dt, o->d_qt, o->d_Kws, o->d_kws,
+                       o->d_dx, o->d_w, o->d_state, forward, gains_pass);
+    HIPCHK(hipGetLastError());
+    return 0;
+  });
+}
+
+int launch_step(agx_ocp *o, int iter, int max_iter, int mode) {
+  if (o->T + 1 > 512) return fail("step kernel supports horizons up to 511 nodes");
   return dispatch(o->nv, o->chain, [&](auto NVc, auto CHc) -> int {
     constexpr int NV = decltype(NVc)::value;
     constexpr bool CH = decltype(CHc)::value;
-    hipLaunchKernelGGL((agx::k_linesearch<NV, CH>), dim3(o->B), dim3(128), 0, o->stream, o->d_model, o->d_ocp, o->d_dt, o->d_xs,
-                       o->d_us, o->rv, o->d_dx, o->d_du, o->d_state, iter, max_iter, o->d_ndone);
+    hipLaunchKernelGGL((agx::k_step<NV, CH>), dim3(o->B), dim3(128), 0, o->stream, o->d_model, o->d_ocp, o->d_dt, o->d_xs, o->d_us,
+                       o->rv, o->d_qt, o->d_aux, o->d_dx, o->d_w, o->d_du, o->d_state, iter, max_iter, mode, o->d_ndone);
+    HIPCHK(hipGetLastError());
+    return 0;
+  });
+}
+
+// exit path: sigma tiles -> Riccati backward -> gains in u-space
+int launch_gains(agx_ocp *o) {
+  return dispatch(o->nv, o->chain, [&](auto NVc, auto CHc) -> int {
+    constexpr int NV = decltype(NVc)::value;
+    const long long nodes = (long long)o->B * (o->T + 1);
+    hipLaunchKernelGGL((agx::k_sigma_tile<NV>), dim3((int)((nodes + 63) / 64)), dim3(64), 0, o->stream, o->d_ocp, o->d_qt, o->d_aux,
+                       o->d_dx, o->d_du);
+    hipLaunchKernelGGL((agx::k_riccati<NV>), dim3(o->B), dim3(64), 0, o->stream, o->d_ocp, o->d_dt, o->d_qt, o->d_Kws, o->d_kws,
+                       o->d_dx, o->d_w, o->d_state, 0, 1);
+    const long long rows = (long long)o->B * o->T * NV;
+    hipLaunchKernelGGL((agx::k_gains_to_u<NV>), dim3((int)((rows + 127) / 128)), dim3(128), 0, o->stream, o->d_ocp, o->d_aux, o->d_Kws,
+                       o->d_Kout);
     HIPCHK(hipGetLastError());
     return 0;
   });
@@ -166,25 +219,20 @@ int solve_resident(agx_ocp *o, int max_iter, double max_time) {
   if (reset_state(o)) return -1;
   hipLaunchKernelGGL(agx::k_pin_x0, dim3((o->B * o->nx + 255) / 256), dim3(256), 0, o->stream, o->d_xs, o->d_x0, o->B, o->T, o->nx);
   for (int it = 0; it < max_iter; ++it) {
-    if (launch_calc_diff(o, true)) return -1;
-    const bool last = (it + 1 == max_iter);
-    if (launch_direction(o, it, last ? 3 : 1)) return -1;
-    if (launch_linesearch(o, it, max_iter)) return -1;
-    if (last) break;
+    if (launch_calc_qp(o)) return -1;
+    if (launch_riccati(o, 1, 0)) return -1;
+    if (launch_step(o, it, max_iter, 1)) return -1;
+    if (it + 1 == max_iter) break;
     // early exit once every instance has finished (one 4-byte read back)
     HIPCHK(hipMemcpyAsync(o->h_ndone, o->d_ndone, sizeof(int), hipMemcpyDeviceToHost, o->stream));
     HIPCHK(hipStreamSynchronize(o->stream));
     if (*o->h_ndone >= o->B) break;
     if (max_time > 0.0) {
       const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-      if (el > max_time) {
-        // gains of the last direction for the instances still running, then stop
-        if (launch_direction(o, it, 2)) return -1;
-        break;
-      }
+      if (el > max_time) break;
     }
   }
-  return 0;
+  return launch_gains(o);
 }
 
 }  // namespace
@@ -290,8 +338,11 @@ int agx_ocp_create(const agx_model *m, const agx_ocp_desc *d, int batch, int dev
   o->hm = m->h;
   o->nv = m->h.nv; o->nx = 2 * o->nv; o->nu = o->nv;
   o->chain = m->h.is_chain != 0;
+  if (const char *e = getenv("AGX_K1_LANES")) o->k1_lanes = (e[0] != '0');
   o->T = d->horizon; o->B = batch; o->device = device;
   o->tile = AGX_TILE_DOUBLES(o->nv);
+  o->qt_size = 6 * o->nv * o->nv + 5 * o->nv + 2;
+  o->aux_size = 4 * o->nv * o->nv + 3 * o->nv + (o->nv & 1);
   o->stride = agx_ref_stride(d, o->nv);
   o->dt.assign(d->dt, d->dt + d->horizon);
   std::memset(&o->ho, 0, sizeof(o->ho));
@@ -317,12 +368,14 @@ int agx_ocp_create(const agx_model *m, const agx_ocp_desc *d, int batch, int dev
   ALLOC(o->d_xs, 2 * B * (T + 1) * nx);  // second half: shift staging
   ALLOC(o->d_us, 2 * B * T * nu);
   ALLOC(o->d_x0, B * nx);
-  ALLOC(o->d_tiles, B * (T + 1) * (size_t)o->tile);
   ALLOC(o->d_Kws, B * T * nu * nx);
   ALLOC(o->d_kws, B * T * nu);
   ALLOC(o->d_Kout, B * T * nu * nx);
   ALLOC(o->d_dx, B * (T + 1) * nx);
   ALLOC(o->d_du, B * T * nu);
+  ALLOC(o->d_w, B * T * nu);
+  ALLOC(o->d_qt, B * (T + 1) * (size_t)o->qt_size);
+  ALLOC(o->d_aux, B * (T + 1) * (size_t)o->aux_size);
   ALLOC(o->d_ref, B * (T + 1) * (size_t)o->stride);
   ALLOC(o->d_frames, B * (T + 1) * AGX_MAX_ROWS);
   ALLOC(o->d_state, B);
@@ -354,7 +407,7 @@ void agx_ocp_destroy(agx_ocp *o) {
   (void)hipSetDevice(o->device);
   if (o->stream) (void)hipStreamSynchronize(o->stream);
   void *ptrs[] = {o->d_model, o->d_ocp, o->d_dt, o->d_xs, o->d_us, o->d_x0, o->d_tiles, o->d_Kws, o->d_kws, o->d_Kout, o->d_dx,
-                  o->d_du, o->d_ref, o->d_frames, o->d_state, o->d_ndone, o->d_scratch, o->d_traj, o->d_pts, o->d_sine};
+                  o->d_du, o->d_ref, o->d_frames, o->d_state, o->d_ndone, o->d_scratch, o->d_traj, o->d_pts, o->d_sine, o->d_qt, o->d_aux, o->d_w};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
   if (o->h_ndone) (void)hipHostFree(o->h_ndone);
@@ -603,19 +656,16 @@ int agx_ocp_calc_diff(agx_ocp *o, double *tiles) {
   return 0;
 }
 
-int agx_ocp_upload_tiles(agx_ocp *o, const double *tiles) {
-  if (!o || !tiles) return fail("agx_ocp_upload_tiles: null argument");
-  if (set_device(o)) return -1;
-  HIPCHK(hipMemcpyAsync(o->d_tiles, tiles, sizeof(double) * o->B * (o->T + 1) * (size_t)o->tile, hipMemcpyHostToDevice, o->stream));
-  HIPCHK(hipStreamSynchronize(o->stream));
-  return 0;
-}
-
+// One QP direction at the resident (xs, us) through the production kernels: K1 (QP tiles),
+// K2 (Riccati + forward), the prologue of K4 (du, KKT) and the exit path (reported gains).
 int agx_ocp_direction(agx_ocp *o, double *K, double *k, double *dx, double *du, double *kkt) {
   if (!o) return fail("null handle");
   if (set_device(o)) return -1;
   if (reset_state(o)) return -1;
-  if (launch_direction(o, 0, 3)) return -1;
+  if (launch_calc_qp(o)) return -1;
+  if (launch_riccati(o, 1, 0)) return -1;
+  if (launch_step(o, 0, 1, 0)) return -1;
+  if (launch_gains(o)) return -1;
   const size_t B = o->B, T = o->T, nx = o->nx, nu = o->nu;
   if (K) HIPCHK(hipMemcpyAsync(K, o->d_Kout, sizeof(double) * B * T * nu * nx, hipMemcpyDeviceToHost, o->stream));
   if (k) HIPCHK(hipMemcpyAsync(k, o->d_kws, sizeof(double) * B * T * nu, hipMemcpyDeviceToHost, o->stream));
@@ -631,16 +681,21 @@ int agx_ocp_direction(agx_ocp *o, double *K, double *k, double *dx, double *du, 
 int agx_ocp_time_kernel(agx_ocp *o, int which, int reps, double *avg_ms) {
   if (!o || !avg_ms || reps < 1) return fail("agx_ocp_time_kernel: bad argument");
   if (set_device(o)) return -1;
+  // state for the timed kernel: fresh solver state, QP tiles and a direction at the resident point
+  if (reset_state(o)) return -1;
+  if (which == 1 || which == 2) { if (launch_calc_qp(o)) return -1; }
+  if (which == 2) { if (launch_riccati(o, 1, 0)) return -1; }
   // warm-up launch, then `reps` timed launches bracketed by events on the problem's stream
   for (int pass = 0; pass < 2; ++pass) {
     const int n = pass == 0 ? 1 : reps;
     if (pass == 1) HIPCHK(hipEventRecord(o->ev0, o->stream));
     for (int r = 0; r < n; ++r) {
       int rc = 0;
-      if (which == 0) rc = launch_calc_diff(o, false);
-      else if (which == 1) { if (reset_state(o)) return -1; rc = launch_direction(o, 0, 1); }
-      else if (which == 2) rc = launch_linesearch(o, 0, 1000000);
-      else if (which == 3) rc = launch_calc_diff(o, false, true);
+      if (which == 0) rc = launch_calc_qp(o, false);
+      else if (which == 1) rc = launch_riccati(o, 1, 0);
+      else if (which == 2) rc = launch_step(o, 0, 1 << 30, 1 | 4);
+      else if (which == 3) rc = launch_calc_qp(o, true);
+      else if (which == 4) rc = launch_calc_diff(o, false, true);
       else return fail("agx_ocp_time_kernel: unknown kernel");
       if (rc) return rc;
     }

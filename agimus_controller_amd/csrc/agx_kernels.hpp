@@ -1,8 +1,10 @@
 // agx_kernels.hpp -- gfx950 kernels of the SQP solve path.
 //
-//   K1  k_calc_diff / k_calc_diff_term   node-parallel calc + calcDiff (one lane per node)
-//   K2  k_direction                      Riccati backward + linear forward + KKT (one wave per instance)
-//   K4  k_linesearch                     merit line search, calc only (one workgroup per instance)
+//   K1  k_calc_qp / k_calc_qp_term       node-parallel calc + calcDiff -> QP tile in acceleration-input form
+//       k_calc_diff / k_calc_diff_term   same, canonical Fx|Fu|L* tile (test / introspection entry point)
+//   K2  k_riccati                        Riccati backward + linear forward (one wave per instance)
+//   K4  k_step                           du, KKT, convergence test, merit line search (one workgroup per instance)
+//   exit: k_sigma_tile, k_riccati (gains pass), k_gains_to_u -> the gains the solver reports
 //   plus warm-start shift, reference generators and small batch utilities.
 //
 // Replaces mim_solvers::SolverCSQP::solve as called at
@@ -17,7 +19,8 @@ struct DevState {
   double preg, dreg;             // crocoddyl regularisation (reg_min 1e-9)
   int iter, qp_iters, solved, flags;
   int done;                      // 1: instance finished (solved, or regularisation saturated)
-  int pad;
+  int need_gains;
+  double gains_preg, gains_dreg; // regularisation the last direction was computed with
 };
 
 // Addressing of the reference tiles (host tile or a window of the resident trajectory).
@@ -184,24 +187,189 @@ __global__ void __launch_bounds__(64) k_calc_diff_term(const DevModel *__restric
 }
 
 // ---------------------------------------------------------------------------
-// K2: QP direction for one instance per wave.
-//   plain pass  (preg, dreg):  K, k -> forward dx, du, KKT          [every iteration]
-//   sigma pass  (ADMM form):   K_out, the gains the solver reports   [on exit only]
-// LDS holds V, [Fx|Fu], V[Fx|Fu], Q and the gains of the current node.
+// Production path: QP tiles in acceleration-input form.
+//
+// With a = Minv (u - nle) the Euler node reads  x+ = Phi x + G a,  Phi = [[I, hI],[0, I]],
+// G = [h^2 I; h I].  Linearised:  dx+ = Phi dx + G w + f  with  w = da = -Minv taux dx + Minv du,
+// i.e.  du = M w + taux dx  (M = mass matrix + armature, taux = [dtau/dq dtau/dv] from RNEA).
+// Substituting du into the node's quadratic model gives a QP in (dx, w) whose dynamics are the
+// same trivially structured (Phi, G) at every node, so the sequential Riccati recursion only
+// needs O(n^2) block combinations per node plus one nu x nu Cholesky and the Schur complement;
+// every dense product involving M and taux is done here, in the node-parallel kernel:
+//   Hww = M D M,  Hxw = taux' D M,  Hxx = Lxx + taux' D taux,  gw = M Lu,  gx = Lx + taux' Lu
+// (D = Luu + preg: crocoddyl's control regularisation lives in u-space and is folded in).
+// The gains are mapped back with  K = M Kw - taux,  k = M kw.
+//
+// QP tile (QT):  Hqq | Hqv | Hvv | Hqw | Hvw | Hww (NV x NV each) | gx (NX) | gw (NV) | f (NX) | cost
+// aux tile (AUX): M | tauq | tauv | Lqq (NV x NV each) | Lvv | Luu | Lu (NV each)
 // ---------------------------------------------------------------------------
 template <int NV>
-struct DirLds {
-  static constexpr int NX = 2 * NV, NU = NV, NXU = 3 * NV;
-  double A[NX * NXU];
-  double W[NX * NXU];
-  double Q[NXU * NXU];
-  double V[NX * NX];
-  double Kl[NU * NX];
-  double q[NXU];
-  double Vx[NX], Vp[NX], f[NX], kl[NU];
-  double dx[NX], du[NU], dxn[NX];
-  double H[NXU * NXU];  // forward pass: [Lxx Lxu; Lxu^T Luu]
+struct QT {
+  static constexpr int NX = 2 * NV, B2 = NV * NV;
+  static constexpr int Hqq = 0, Hqv = B2, Hvv = 2 * B2, Hqw = 3 * B2, Hvw = 4 * B2, Hww = 5 * B2, gx = 6 * B2, gw = gx + NX,
+                       f = gw + NV, cost = f + NX, SIZE = cost + 2;  // padded to an even count
 };
+template <int NV>
+struct AUX {
+  static constexpr int B2 = NV * NV;
+  static constexpr int M = 0, tq = B2, tv = 2 * B2, Lqq = 3 * B2, Lvv = 4 * B2, Luu = Lvv + NV, Lu = Luu + NV, SIZE = Lu + NV + (NV & 1);
+};
+
+template <int NV, bool CHAIN>
+__global__ void __launch_bounds__(64) k_calc_qp(const DevModel *__restrict__ mp, const DevOcp *__restrict__ op,
+                                                const double *__restrict__ dts, const double *__restrict__ xs,
+                                                const double *__restrict__ us, RefView rv, double *__restrict__ qts,
+                                                double *__restrict__ auxs, const DevState *__restrict__ st) {
+  constexpr int NX = 2 * NV, NU = NV;
+  typedef QT<NV> Q;
+  typedef AUX<NV> A;
+  const DevModel &m = *mp;
+  const DevOcp &o = *op;
+  const int T = o.T;
+  const long long unit = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (unit >= (long long)o.B * T) return;
+  const int b = (int)(unit / T), t = (int)(unit % T);
+  if (st[b].done) return;
+  const double preg = st[b].preg;
+  const double dt = dts[t];
+  double x[NX], u[NU];
+  const double *xp = xs + ((long long)b * (T + 1) + t) * NX;
+#pragma unroll
+  for (int i = 0; i < NX; ++i) x[i] = xp[i];
+  const double *up = us + ((long long)b * T + t) * NU;
+#pragma unroll
+  for (int i = 0; i < NU; ++i) u[i] = up[i];
+  double *qt = qts + ((long long)b * (T + 1) + t) * Q::SIZE;
+  double *ax = auxs + ((long long)b * (T + 1) + t) * A::SIZE;
+
+  Kin<NV> k;
+  kinematics<NV, CHAIN>(m, x, k);
+  Dyn<NV> d;
+  double nle[NV], M[NV][NV], L[NV][NV], Minv[NV][NV], qdd[NV];
+  bias_and_inertia<NV, CHAIN>(m, k, x + NV, d, nle, M);
+#pragma unroll
+  for (int i = 0; i < NV; ++i)
+#pragma unroll
+    for (int j = 0; j < NV; ++j) { L[i][j] = M[i][j]; ax[A::M + i * NV + j] = M[i][j]; }
+  spd_inverse<NV>(L, Minv);
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    double a = 0.0;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) a += Minv[i][j] * (u[j] - nle[j]);
+    qdd[i] = a;
+  }
+  {
+    const double *xn = xp + NX;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      qt[Q::f + i] = x[i] + dt * x[NV + i] + dt * dt * qdd[i] - xn[i];
+      qt[Q::f + NV + i] = x[NV + i] + dt * qdd[i] - xn[NV + i];
+    }
+  }
+  double tq[NV][NV], tv[NV][NV];
+  rnea_derivatives<NV, CHAIN>(m, k, d, x + NV, qdd, tq, tv);
+  CostAcc<NV> c;
+  node_costs<NV, CHAIN, false, true>(m, o.rows[0], k, x, u, ref_at(rv, b, t, T), frames_at(rv, b, t, T), c);
+  qt[Q::cost] = dt * c.cost;
+  double D[NV], lu[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    D[i] = dt * c.Luu[i] + preg;
+    lu[i] = dt * c.Lu[i];
+    ax[A::Lvv + i] = dt * c.Lvv[i];
+    ax[A::Luu + i] = dt * c.Luu[i];
+    ax[A::Lu + i] = lu[i];
+  }
+  // DM = D M (row scaling), then the five transformed blocks
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    double gwi = 0.0, gq = dt * c.Lq[i], gv = dt * c.Lv[i];
+#pragma unroll
+    for (int l = 0; l < NV; ++l) {
+      gwi += M[i][l] * lu[l];
+      gq += tq[l][i] * lu[l];
+      gv += tv[l][i] * lu[l];
+    }
+    qt[Q::gw + i] = gwi;
+    qt[Q::gx + i] = gq;
+    qt[Q::gx + NV + i] = gv;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      double hww = 0.0, hqw = 0.0, hvw = 0.0, hqq = dt * c.Lqq[i][j], hqv = 0.0, hvv = (i == j) ? dt * c.Lvv[i] : 0.0;
+#pragma unroll
+      for (int l = 0; l < NV; ++l) {
+        const double dm = D[l] * M[l][j];
+        hww += M[i][l] * dm;
+        hqw += tq[l][i] * dm;
+        hvw += tv[l][i] * dm;
+        const double dtq = D[l] * tq[l][j], dtv = D[l] * tv[l][j];
+        hqq += tq[l][i] * dtq;
+        hqv += tq[l][i] * dtv;
+        hvv += tv[l][i] * dtv;
+      }
+      qt[Q::Hww + i * NV + j] = hww;
+      qt[Q::Hqw + i * NV + j] = hqw;
+      qt[Q::Hvw + i * NV + j] = hvw;
+      qt[Q::Hqq + i * NV + j] = hqq;
+      qt[Q::Hqv + i * NV + j] = hqv;
+      qt[Q::Hvv + i * NV + j] = hvv;
+      ax[A::tq + i * NV + j] = tq[i][j];
+      ax[A::tv + i * NV + j] = tv[i][j];
+      ax[A::Lqq + i * NV + j] = dt * c.Lqq[i][j];
+    }
+  }
+}
+
+template <int NV, bool CHAIN>
+__global__ void __launch_bounds__(64) k_calc_qp_term(const DevModel *__restrict__ mp, const DevOcp *__restrict__ op,
+                                                     const double *__restrict__ xs, RefView rv, double *__restrict__ qts,
+                                                     double *__restrict__ auxs, const DevState *__restrict__ st) {
+  constexpr int NX = 2 * NV;
+  typedef QT<NV> Q;
+  typedef AUX<NV> A;
+  const DevModel &m = *mp;
+  const DevOcp &o = *op;
+  const int T = o.T;
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= o.B) return;
+  if (st[b].done) return;
+  double x[NX];
+  const double *xp = xs + ((long long)b * (T + 1) + T) * NX;
+#pragma unroll
+  for (int i = 0; i < NX; ++i) x[i] = xp[i];
+  double *qt = qts + ((long long)b * (T + 1) + T) * Q::SIZE;
+  double *ax = auxs + ((long long)b * (T + 1) + T) * A::SIZE;
+  Kin<NV> k;
+  kinematics<NV, CHAIN>(m, x, k);
+  CostAcc<NV> c;
+  node_costs<NV, CHAIN, true, true>(m, o.rows[1], k, x, nullptr, ref_at(rv, b, T, T), frames_at(rv, b, T, T), c);
+  qt[Q::cost] = c.cost;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    qt[Q::gx + i] = c.Lq[i];
+    qt[Q::gx + NV + i] = c.Lv[i];
+    qt[Q::gw + i] = 0.0;
+    qt[Q::f + i] = 0.0;
+    qt[Q::f + NV + i] = 0.0;
+    ax[A::Lvv + i] = c.Lvv[i];
+    ax[A::Luu + i] = 0.0;
+    ax[A::Lu + i] = 0.0;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      qt[Q::Hqq + i * NV + j] = c.Lqq[i][j];
+      qt[Q::Hqv + i * NV + j] = 0.0;
+      qt[Q::Hvv + i * NV + j] = (i == j) ? c.Lvv[i] : 0.0;
+      qt[Q::Hqw + i * NV + j] = 0.0;
+      qt[Q::Hvw + i * NV + j] = 0.0;
+      qt[Q::Hww + i * NV + j] = 0.0;
+      ax[A::M + i * NV + j] = 0.0;
+      ax[A::tq + i * NV + j] = 0.0;
+      ax[A::tv + i * NV + j] = 0.0;
+      ax[A::Lqq + i * NV + j] = c.Lqq[i][j];
+    }
+  }
+}
 
 __device__ __forceinline__ double wave_max(double v) {
 #pragma unroll
@@ -214,88 +382,135 @@ __device__ __forceinline__ double wave_sum(double v) {
   return v;
 }
 
-// one backward sweep; SIGMA selects the proximal form.  Gains go to Kdst/kdst.
-template <int NV, bool SIGMA>
-__device__ void riccati_backward(DirLds<NV> &s, const double *__restrict__ tiles_b, int T, double preg, double dreg,
-                                 const double *__restrict__ cx, const double *__restrict__ cu,
-                                 double *__restrict__ Kdst, double *__restrict__ kdst, double *cost_sum, double *gap_sum) {
-  constexpr int NX = 2 * NV, NU = NV, NXU = 3 * NV;
-  typedef TileOff<NV> TO;
-  const int lane = threadIdx.x;
-  const double sig = SIGMA ? kSigma : 0.0;
-  // terminal value function
+// ---------------------------------------------------------------------------
+// K2: Riccati backward + linear forward in (dx, w) coordinates, one wave per instance.
+// LDS: value function, double-buffered QP tile, Q blocks, gains of the current node.
+// ---------------------------------------------------------------------------
+template <int NV>
+struct RicLds {
+  static constexpr int NX = 2 * NV;
+  double V[NX * NX];
+  double tile[2][QT<NV>::SIZE];
+  double Qxx[NX * NX];
+  double Qxw[NX * NV];
+  double Qww[NV * NV];
+  double Kw[NV * NX];
+  double vx[NX], vp[NX], qw[NV], kw[NV];
+};
+
+// forward: 1 = also run the linear forward pass (dx, w)
+template <int NV>
+__global__ void __launch_bounds__(64) k_riccati(const DevOcp *__restrict__ op, const double *__restrict__ dts,
+                                                const double *__restrict__ qts, double *__restrict__ Kws,
+                                                double *__restrict__ kws, double *__restrict__ dxs,
+                                                double *__restrict__ wss, const DevState *__restrict__ st, int forward,
+                                                int gains_pass) {
+  constexpr int NX = 2 * NV, TS = QT<NV>::SIZE;
+  constexpr int NLD = (TS + 63) / 64;
+  typedef QT<NV> Q;
+  __shared__ RicLds<NV> s;
+  const DevOcp &o = *op;
+  const int T = o.T, b = blockIdx.x, lane = threadIdx.x;
+  const DevState &S = st[b];
+  // gains pass (on exit): every instance, with the regularisation its last direction was computed with
+  if (!gains_pass && S.done) return;
+  const double dreg = gains_pass ? (S.solved ? S.dreg : S.gains_dreg) : S.dreg;
+  const double *qb = qts + (long long)b * (T + 1) * TS;
+  double *Kw = Kws + (long long)b * T * NV * NX, *kw = kws + (long long)b * T * NV;
+  // terminal value function and the first tile
   {
-    const double *tt = tiles_b + (long long)T * TO::SIZE;
-    for (int e = lane; e < NX * NX; e += 64) s.V[e] = tt[TO::Lxx + e] + ((e / NX == e % NX) ? (sig + dreg) : 0.0);
-    if (lane < NX) s.Vx[lane] = tt[TO::Lx + lane] - (SIGMA ? sig * cx[(long long)T * NX + lane] : 0.0);
-    if (cost_sum && lane == 0) *cost_sum += tt[TO::cost];
+    const double *tt = qb + (long long)T * TS;
+    for (int e = lane; e < NX * NX; e += 64) {
+      const int i = e / NX, j = e % NX;
+      double v;
+      if (i < NV && j < NV) v = tt[Q::Hqq + i * NV + j];
+      else if (i < NV) v = tt[Q::Hqv + i * NV + (j - NV)];
+      else if (j < NV) v = tt[Q::Hqv + j * NV + (i - NV)];
+      else v = tt[Q::Hvv + (i - NV) * NV + (j - NV)];
+      s.V[e] = v + (i == j ? dreg : 0.0);
+    }
+    if (lane < NX) s.vx[lane] = tt[Q::gx + lane];
+    const double *t0 = qb + (long long)(T - 1) * TS;
+    for (int e = lane; e < TS; e += 64) s.tile[(T - 1) & 1][e] = t0[e];
   }
   __syncthreads();
   for (int t = T - 1; t >= 0; --t) {
-    const double *tl = tiles_b + (long long)t * TO::SIZE;
-    for (int e = lane; e < NX * NX; e += 64) s.A[(e / NX) * NXU + (e % NX)] = tl[TO::Fx + e];
-    for (int e = lane; e < NX * NU; e += 64) s.A[(e / NU) * NXU + NX + (e % NU)] = tl[TO::Fu + e];
+    const double *tl = s.tile[t & 1];
+    const double h = dts[t], h2 = h * h;
+    // prefetch the next tile into registers: its latency hides behind this step
+    double pre[NLD];
+    if (t > 0) {
+      const double *tn = qb + (long long)(t - 1) * TS;
+#pragma unroll
+      for (int r = 0; r < NLD; ++r) {
+        const int e = lane + 64 * r;
+        pre[r] = (e < TS) ? tn[e] : 0.0;
+      }
+    }
+    // ---- phase A: vp = vx + V f ; Qxx = Hxx + Phi' V Phi ; Qxw = Hxw + (G' V Phi)' ; Qww = Hww + G' V G
     if (lane < NX) {
-      const double fv = tl[TO::f + lane];
-      s.f[lane] = fv;
-      if (gap_sum) *gap_sum += fabs(fv);
+      double acc = s.vx[lane];
+#pragma unroll
+      for (int j = 0; j < NX; ++j) acc += s.V[lane * NX + j] * tl[Q::f + j];
+      s.vp[lane] = acc;
     }
-    if (cost_sum && lane == 0) *cost_sum += tl[TO::cost];
+    for (int e = lane; e < NX * NX; e += 64) {
+      const int i = e / NX, j = e % NX;
+      const int iq = i < NV ? i : i - NV, jq = j < NV ? j : j - NV;
+      double v, hx;
+      if (i < NV && j < NV) {
+        v = s.V[i * NX + j];
+        hx = tl[Q::Hqq + i * NV + j];
+      } else if (i < NV) {
+        v = h * s.V[i * NX + jq] + s.V[i * NX + j];
+        hx = tl[Q::Hqv + i * NV + jq];
+      } else if (j < NV) {
+        v = h * s.V[iq * NX + j] + s.V[i * NX + j];
+        hx = tl[Q::Hqv + j * NV + iq];
+      } else {
+        v = h2 * s.V[iq * NX + jq] + h * (s.V[iq * NX + j] + s.V[i * NX + jq]) + s.V[i * NX + j];
+        hx = tl[Q::Hvv + iq * NV + jq];
+      }
+      s.Qxx[e] = hx + v;
+    }
+    for (int e = lane; e < NX * NV; e += 64) {
+      const int i = e / NV, a = e % NV;  // Qxw[i][a] = Hxw[i][a] + R[a][i],  R = Y Phi,  Y = G' V
+      double r, hx;
+      if (i < NV) {
+        r = h2 * s.V[a * NX + i] + h * s.V[(NV + a) * NX + i];
+        hx = tl[Q::Hqw + i * NV + a];
+      } else {
+        const int iq = i - NV;
+        const double yq = h2 * s.V[a * NX + iq] + h * s.V[(NV + a) * NX + iq];
+        const double yv = h2 * s.V[a * NX + i] + h * s.V[(NV + a) * NX + i];
+        r = h * yq + yv;
+        hx = tl[Q::Hvw + iq * NV + a];
+      }
+      s.Qxw[e] = hx + r;
+    }
+    for (int e = lane; e < NV * NV; e += 64) {
+      const int a = e / NV, c = e % NV;  // S = Y G
+      const double yq = h2 * s.V[a * NX + c] + h * s.V[(NV + a) * NX + c];
+      const double yv = h2 * s.V[a * NX + NV + c] + h * s.V[(NV + a) * NX + NV + c];
+      s.Qww[e] = tl[Q::Hww + e] + h2 * yq + h * yv;
+    }
     __syncthreads();
-    // Vp = Vx + V f ;  W = V A
-    if (lane < NX) {
-      double acc = s.Vx[lane];
-#pragma unroll
-      for (int j = 0; j < NX; ++j) acc += s.V[lane * NX + j] * s.f[j];
-      s.Vp[lane] = acc;
-    }
-    for (int e = lane; e < NX * NXU; e += 64) {
-      const int i = e / NXU, j = e % NXU;
-      double acc = 0.0;
-#pragma unroll
-      for (int l = 0; l < NX; ++l) acc += s.V[i * NX + l] * s.A[l * NXU + j];
-      s.W[e] = acc;
-    }
-    __syncthreads();
-    // Q = L + A^T W (upper triangle, mirrored) ; q = l + A^T Vp
-    for (int e = lane; e < NXU * NXU; e += 64) {
-      const int a = e / NXU, bq = e % NXU;
-      if (bq < a) continue;
-      double acc;
-      if (bq < NX) acc = tl[TO::Lxx + a * NX + bq];
-      else if (a < NX) acc = tl[TO::Lxu + a * NU + (bq - NX)];
-      else acc = tl[TO::Luu + (a - NX) * NU + (bq - NX)];
-#pragma unroll
-      for (int l = 0; l < NX; ++l) acc += s.A[l * NXU + a] * s.W[l * NXU + bq];
-      if (a == bq) acc += (a < NX) ? sig : (sig + preg);
-      s.Q[a * NXU + bq] = acc;
-      s.Q[bq * NXU + a] = acc;
-    }
-    if (lane < NXU) {
-      double acc = (lane < NX) ? tl[TO::Lx + lane] : tl[TO::Lu + lane - NX];
-#pragma unroll
-      for (int l = 0; l < NX; ++l) acc += s.A[l * NXU + lane] * s.Vp[l];
-      if (SIGMA) acc -= sig * ((lane < NX) ? cx[(long long)t * NX + lane] : cu[(long long)t * NU + lane - NX]);
-      s.q[lane] = acc;
-    }
-    __syncthreads();
-    // Cholesky of Quu in registers (every lane, broadcast LDS reads), then lane j
-    // solves column j of Qux, lane NX solves Qu.
+    // ---- phase B: Cholesky of Qww in registers (every lane), lane j solves column j, lane NX solves kw
     {
-      double L[NU][NU];
+      double L[NV][NV];
 #pragma unroll
-      for (int i = 0; i < NU; ++i)
+      for (int i = 0; i < NV; ++i)
 #pragma unroll
-        for (int j = 0; j <= i; ++j) L[i][j] = s.Q[(NX + i) * NXU + NX + j];
+        for (int j = 0; j <= i; ++j) L[i][j] = 0.5 * (s.Qww[i * NV + j] + s.Qww[j * NV + i]);
 #pragma unroll
-      for (int j = 0; j < NU; ++j) {
+      for (int j = 0; j < NV; ++j) {
         double dd = L[j][j];
 #pragma unroll
         for (int l = 0; l < j; ++l) dd -= L[j][l] * L[j][l];
-        const double ll = sqrt(dd), il = 1.0 / ll;
-        L[j][j] = il;  // store the reciprocal of the pivot
+        const double il = 1.0 / sqrt(dd);
+        L[j][j] = il;
 #pragma unroll
-        for (int i = j + 1; i < NU; ++i) {
+        for (int i = j + 1; i < NV; ++i) {
           double sacc = L[i][j];
 #pragma unroll
           for (int l = 0; l < j; ++l) sacc -= L[i][l] * L[j][l];
@@ -303,205 +518,204 @@ __device__ void riccati_backward(DirLds<NV> &s, const double *__restrict__ tiles
         }
       }
       if (lane <= NX) {
-        double rhs[NU];
+        double rhs[NV];
+        if (lane < NX) {
 #pragma unroll
-        for (int i = 0; i < NU; ++i) rhs[i] = (lane < NX) ? s.Q[(NX + i) * NXU + lane] : s.q[NX + i];
+          for (int a = 0; a < NV; ++a) rhs[a] = s.Qxw[lane * NV + a];
+        } else {
 #pragma unroll
-        for (int i = 0; i < NU; ++i) {
+          for (int a = 0; a < NV; ++a) {
+            rhs[a] = tl[Q::gw + a] + h2 * s.vp[a] + h * s.vp[NV + a];
+            s.qw[a] = rhs[a];
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
           double sacc = rhs[i];
 #pragma unroll
           for (int l = 0; l < i; ++l) sacc -= L[i][l] * rhs[l];
           rhs[i] = sacc * L[i][i];
         }
 #pragma unroll
-        for (int i = NU - 1; i >= 0; --i) {
+        for (int i = NV - 1; i >= 0; --i) {
           double sacc = rhs[i];
 #pragma unroll
-          for (int l = i + 1; l < NU; ++l) sacc -= L[l][i] * rhs[l];
+          for (int l = i + 1; l < NV; ++l) sacc -= L[l][i] * rhs[l];
           rhs[i] = sacc * L[i][i];
         }
         if (lane < NX) {
 #pragma unroll
-          for (int i = 0; i < NU; ++i) {
-            s.Kl[i * NX + lane] = rhs[i];
-            Kdst[(long long)t * NU * NX + i * NX + lane] = rhs[i];
+          for (int a = 0; a < NV; ++a) {
+            s.Kw[a * NX + lane] = rhs[a];
+            Kw[(long long)t * NV * NX + a * NX + lane] = rhs[a];
           }
         } else {
 #pragma unroll
-          for (int i = 0; i < NU; ++i) {
-            s.kl[i] = rhs[i];
-            if (kdst) kdst[(long long)t * NU + i] = rhs[i];
+          for (int a = 0; a < NV; ++a) {
+            s.kw[a] = rhs[a];
+            kw[(long long)t * NV + a] = rhs[a];
           }
         }
       }
     }
     __syncthreads();
-    // V = sym(Qxx - Qxu K) + dreg ; Vx = Qx - K^T Qu
+    // ---- phase C: V = sym(Qxx - Qxw Kw) + dreg ; vx = qx - Kw' qw ; publish the prefetched tile
     for (int e = lane; e < NX * NX; e += 64) {
-      const int a = e / NX, bq = e % NX;
-      if (bq < a) continue;
-      double v1 = s.Q[a * NXU + bq], v2 = s.Q[bq * NXU + a];
+      const int i = e / NX, j = e % NX;
+      if (j < i) continue;
+      double v1 = s.Qxx[i * NX + j], v2 = s.Qxx[j * NX + i];
 #pragma unroll
-      for (int i = 0; i < NU; ++i) {
-        v1 -= s.Q[a * NXU + NX + i] * s.Kl[i * NX + bq];
-        v2 -= s.Q[bq * NXU + NX + i] * s.Kl[i * NX + a];
+      for (int a = 0; a < NV; ++a) {
+        v1 -= s.Qxw[i * NV + a] * s.Kw[a * NX + j];
+        v2 -= s.Qxw[j * NV + a] * s.Kw[a * NX + i];
       }
-      const double v = 0.5 * (v1 + v2) + (a == bq ? dreg : 0.0);
-      s.V[a * NX + bq] = v;
-      s.V[bq * NX + a] = v;
+      const double v = 0.5 * (v1 + v2) + (i == j ? dreg : 0.0);
+      s.V[i * NX + j] = v;
+      s.V[j * NX + i] = v;
     }
     if (lane < NX) {
-      double acc = s.q[lane];
+      double acc = tl[Q::gx + lane] + s.vp[lane] + (lane >= NV ? h * s.vp[lane - NV] : 0.0);
 #pragma unroll
-      for (int i = 0; i < NU; ++i) acc -= s.Kl[i * NX + lane] * s.q[NX + i];
-      s.Vx[lane] = acc;
+      for (int a = 0; a < NV; ++a) acc -= s.Kw[a * NX + lane] * s.qw[a];
+      s.vx[lane] = acc;
+    }
+    if (t > 0) {
+      double *dst = s.tile[(t - 1) & 1];
+#pragma unroll
+      for (int r = 0; r < NLD; ++r) {
+        const int e = lane + 64 * r;
+        if (e < TS) dst[e] = pre[r];
+      }
     }
     __syncthreads();
   }
-}
-
-// mode bit0: plain pass + forward + KKT;  bit1: force the sigma pass (last iteration / timeout)
-template <int NV>
-__global__ void __launch_bounds__(64) k_direction(const DevOcp *__restrict__ op, const double *__restrict__ tiles,
-                                                  double *__restrict__ Kws, double *__restrict__ kws,
-                                                  double *__restrict__ Kout, double *__restrict__ dxs,
-                                                  double *__restrict__ dus, DevState *__restrict__ st, int iter, int mode,
-                                                  int *__restrict__ n_done) {
-  constexpr int NX = 2 * NV, NU = NV, NXU = 3 * NV;
-  typedef TileOff<NV> TO;
-  __shared__ DirLds<NV> s;
-  const DevOcp &o = *op;
-  const int T = o.T, b = blockIdx.x, lane = threadIdx.x;
-  DevState &S = st[b];
-  if (S.done) return;
-  const double *tiles_b = tiles + (long long)b * (T + 1) * TO::SIZE;
-  double *Kw = Kws + (long long)b * T * NU * NX, *kw = kws + (long long)b * T * NU;
-  double *dx = dxs + (long long)b * (T + 1) * NX, *du = dus + (long long)b * T * NU;
-  const double preg = S.preg, dreg = S.dreg;
-  bool converged = false;
-  if (mode & 1) {
-    double cost = 0.0, gap = 0.0;
-    riccati_backward<NV, false>(s, tiles_b, T, preg, dreg, nullptr, nullptr, Kw, kw, &cost, &gap);
-    gap = wave_sum(gap);
-    cost = __shfl(cost, 0, 64);
-    // forward pass, dx_0 = 0
-    if (lane < NX) { s.dx[lane] = 0.0; dx[lane] = 0.0; }
-    double kkt = 0.0;
-    for (int t = 0; t < T; ++t) {
-      const double *tl = tiles_b + (long long)t * TO::SIZE;
-      for (int e = lane; e < NX * NX; e += 64) {
-        s.A[(e / NX) * NXU + (e % NX)] = tl[TO::Fx + e];
-        s.H[(e / NX) * NXU + (e % NX)] = tl[TO::Lxx + e];
-      }
-      for (int e = lane; e < NX * NU; e += 64) {
-        s.A[(e / NU) * NXU + NX + (e % NU)] = tl[TO::Fu + e];
-        const double l = tl[TO::Lxu + e];
-        s.H[(e / NU) * NXU + NX + (e % NU)] = l;
-        s.H[(NX + (e % NU)) * NXU + (e / NU)] = l;
-        s.Kl[e] = Kw[(long long)t * NU * NX + e];
-      }
-      for (int e = lane; e < NU * NU; e += 64) s.H[(NX + e / NU) * NXU + NX + (e % NU)] = tl[TO::Luu + e];
-      if (lane < NX) {
-        const double fv = tl[TO::f + lane];
-        s.f[lane] = fv;
-        kkt = fmax(kkt, fabs(fv));
-      }
-      if (lane < NU) s.kl[lane] = kw[(long long)t * NU + lane];
-      __syncthreads();
-      if (lane < NU) {
-        double acc = -s.kl[lane];
+  if (!forward) return;
+  // ---- forward pass, shuffle only: lane j < NX holds dx_j, lane a < NV computes w_a
+  double *dx = dxs + (long long)b * (T + 1) * NX, *ws = wss + (long long)b * T * NV;
+  double dxv = 0.0;
+  if (lane < NX) dx[lane] = 0.0;
+  for (int t = 0; t < T; ++t) {
+    const double h = dts[t], h2 = h * h;
+    double krow[NX], kwa = 0.0, fv = 0.0;
+    if (lane < NV) {
 #pragma unroll
-        for (int j = 0; j < NX; ++j) acc -= s.Kl[lane * NX + j] * s.dx[j];
-        s.du[lane] = acc;
-        du[(long long)t * NU + lane] = acc;
-      }
-      __syncthreads();
-      if (lane < NX) {
-        double acc = s.f[lane];
-#pragma unroll
-        for (int j = 0; j < NX; ++j) acc += s.A[lane * NXU + j] * s.dx[j];
-#pragma unroll
-        for (int j = 0; j < NU; ++j) acc += s.A[lane * NXU + NX + j] * s.du[j];
-        s.dxn[lane] = acc;
-        dx[(long long)(t + 1) * NX + lane] = acc;
-      }
-      // stationarity through the QP optimality identity (incl. the regularisation terms):
-      //   Lx + Fx' lam' - lam = -(Lxx dx + Lxu du + dreg dx),  Lu + Fu' lam' = -(Lxu' dx + (Luu + preg) du)
-      if (lane < NXU) {
-        double acc = 0.0;
-#pragma unroll
-        for (int j = 0; j < NX; ++j) acc += s.H[lane * NXU + j] * s.dx[j];
-#pragma unroll
-        for (int j = 0; j < NU; ++j) acc += s.H[lane * NXU + NX + j] * s.du[j];
-        if (lane < NX) {
-          acc += dreg * s.dx[lane];
-          if (t > 0) kkt = fmax(kkt, fabs(acc));
-        } else {
-          acc += preg * s.du[lane - NX];
-          kkt = fmax(kkt, fabs(acc));
-        }
-      }
-      __syncthreads();
-      if (lane < NX) s.dx[lane] = s.dxn[lane];
-      __syncthreads();
+      for (int j = 0; j < NX; ++j) krow[j] = Kw[(long long)t * NV * NX + lane * NX + j];
+      kwa = kw[(long long)t * NV + lane];
     }
-    {
-      const double *tt = tiles_b + (long long)T * TO::SIZE;
-      if (lane < NX) {
-        double acc = dreg * s.dx[lane];
+    if (lane < NX) fv = qb[(long long)t * TS + Q::f + lane];
+    double wv = -kwa;
 #pragma unroll
-        for (int j = 0; j < NX; ++j) acc += tt[TO::Lxx + lane * NX + j] * s.dx[j];
-        kkt = fmax(kkt, fabs(acc));
-      }
+    for (int j = 0; j < NX; ++j) {
+      const double dj = __shfl(dxv, j, 64);
+      if (lane < NV) wv -= krow[j] * dj;
     }
-    kkt = wave_max(kkt);
-    converged = (kkt <= o.tol);
-    if (lane == 0) {
-      S.kkt = kkt;
-      S.cost = cost;
-      S.gap = gap;
-      S.merit = cost + o.mu_dyn * gap;
-      S.qp_iters = 1;
-      if (!(kkt == kkt)) S.flags |= 1;
-    }
-  }
-  if (converged || (mode & 2)) {
-    __syncthreads();
-    riccati_backward<NV, true>(s, tiles_b, T, preg, dreg, dx, du, Kout + (long long)b * T * NU * NX, nullptr, nullptr, nullptr);
-  }
-  if (converged && lane == 0) {
-    S.solved = 1;
-    S.done = 1;
-    S.iter = iter;
-    atomicAdd(n_done, 1);
+    if (lane >= NV) wv = 0.0;
+    const double dx_up = __shfl(dxv, (lane + NV) & 63, 64);    // dx_v partner for the q rows
+    const double w_dn = __shfl(wv, lane >= NV ? lane - NV : lane, 64);  // w of the matching joint
+    double nxt;
+    if (lane < NV) nxt = dxv + h * dx_up + h2 * wv + fv;
+    else nxt = dxv + h * w_dn + fv;
+    if (lane < NV) ws[(long long)t * NV + lane] = wv;
+    dxv = (lane < NX) ? nxt : 0.0;
+    if (lane < NX) dx[(long long)(t + 1) * NX + lane] = dxv;
   }
 }
 
 // ---------------------------------------------------------------------------
-// K4: merit line search, one workgroup per instance, lanes over
-// nodes.  alpha = 2^-n, n = 0..9, accept the first merit_try < merit.
+// K4: step kernel, one workgroup per instance, lanes over nodes.
+//   prologue: du = M w + taux dx per node, KKT residual, cost and gap sums -> convergence test
+//   then the merit line search: alpha = 2^-n, accept the first merit_try < merit.
+// mode bit0: run the line search / state update; without it only the prologue runs (test hook).
+// mode bit2: timing mode (no convergence exit, nothing committed) so that launches are repeatable.
 // ---------------------------------------------------------------------------
 template <int NV, bool CHAIN>
-__global__ void __launch_bounds__(128) k_linesearch(const DevModel *__restrict__ mp, const DevOcp *__restrict__ op,
-                                                    const double *__restrict__ dts, double *__restrict__ xs,
-                                                    double *__restrict__ us, RefView rv, const double *__restrict__ dxs,
-                                                    const double *__restrict__ dus, DevState *__restrict__ st, int iter,
-                                                    int max_iter, int *__restrict__ n_done) {
+__global__ void __launch_bounds__(128) k_step(const DevModel *__restrict__ mp, const DevOcp *__restrict__ op,
+                                              const double *__restrict__ dts, double *__restrict__ xs,
+                                              double *__restrict__ us, RefView rv, const double *__restrict__ qts,
+                                              const double *__restrict__ auxs, const double *__restrict__ dxs,
+                                              const double *__restrict__ wss, double *__restrict__ dus,
+                                              DevState *__restrict__ st, int iter, int max_iter, int mode,
+                                              int *__restrict__ n_done) {
   constexpr int NX = 2 * NV, NU = NV;
-  __shared__ double red[4];
-  __shared__ int accept;
+  typedef QT<NV> Q;
+  typedef AUX<NV> A;
+  __shared__ double red[8];
+  __shared__ int flag;
   const DevModel &m = *mp;
   const DevOcp &o = *op;
-  const int T = o.T, b = blockIdx.x, tid = threadIdx.x;
+  const int T = o.T, b = blockIdx.x, tid = threadIdx.x, nw = blockDim.x >> 6;
   DevState &S = st[b];
   if (S.done) return;
   double *X = xs + (long long)b * (T + 1) * NX, *U = us + (long long)b * T * NU;
-  const double *DX = dxs + (long long)b * (T + 1) * NX, *DU = dus + (long long)b * T * NU;
-  const double merit = S.merit;
+  const double *DX = dxs + (long long)b * (T + 1) * NX, *W = wss + (long long)b * T * NV;
+  double *DU = dus + (long long)b * T * NU;
+  const double preg = S.preg, dreg = S.dreg;
+  constexpr int NPT = 4;  // nodes per thread: supports T + 1 <= 4 * blockDim
+  // ---- prologue
+  double kkt = 0.0, msum = 0.0, csum = 0.0, gsum = 0.0;
+  for (int r = 0; r < NPT; ++r) {
+    const int t = tid + r * blockDim.x;
+    if (t > T) break;
+    const double *qt = qts + ((long long)b * (T + 1) + t) * Q::SIZE;
+    const double *ax = auxs + ((long long)b * (T + 1) + t) * A::SIZE;
+    double dx[NX];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) dx[i] = DX[(long long)t * NX + i];
+    csum += qt[Q::cost];
+    if (t < T) {
+      double w[NV];
+#pragma unroll
+      for (int i = 0; i < NV; ++i) w[i] = W[(long long)t * NV + i];
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        double du = 0.0;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) du += ax[A::M + i * NV + j] * w[j] + ax[A::tq + i * NV + j] * dx[j] + ax[A::tv + i * NV + j] * dx[NV + j];
+        DU[(long long)t * NU + i] = du;
+        // Lu + Fu' lam' = -(Lxu' dx + (Luu + preg) du)
+        kkt = fmax(kkt, fabs((ax[A::Luu + i] + preg) * du));
+      }
+#pragma unroll
+      for (int i = 0; i < NX; ++i) {
+        const double fv = qt[Q::f + i];
+        kkt = fmax(kkt, fabs(fv));
+        gsum += fabs(fv);
+      }
+    }
+    if (t > 0) {
+      // Lx + Fx' lam' - lam = -(Lxx dx + Lxu du + dreg dx)
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        double hq = dreg * dx[i];
+#pragma unroll
+        for (int j = 0; j < NV; ++j) hq += ax[A::Lqq + i * NV + j] * dx[j];
+        kkt = fmax(kkt, fabs(hq));
+        kkt = fmax(kkt, fabs((ax[A::Lvv + i] + dreg) * dx[NV + i]));
+      }
+    }
+  }
+  kkt = wave_max(kkt);
+  csum = wave_sum(csum);
+  gsum = wave_sum(gsum);
+  if ((tid & 63) == 0) { red[tid >> 6] = kkt; red[2 + (tid >> 6)] = csum; red[4 + (tid >> 6)] = gsum; }
+  __syncthreads();
+  if (tid == 0) {
+    double kk = 0.0, cc = 0.0, gg = 0.0;
+    for (int w = 0; w < nw; ++w) { kk = fmax(kk, red[w]); cc += red[2 + w]; gg += red[4 + w]; }
+    S.kkt = kk; S.cost = cc; S.gap = gg; S.merit = cc + o.mu_dyn * gg; S.qp_iters = 1;
+    if (!(kk == kk)) S.flags |= 1;
+    const bool conv = (kk <= o.tol) && (mode & 1) && !(mode & 4);
+    if (conv) { S.solved = 1; S.done = 1; S.iter = iter; atomicAdd(n_done, 1); }
+    flag = conv ? 1 : 0;
+    red[6] = S.merit;
+  }
+  __syncthreads();
+  if (flag || !(mode & 1)) return;
+  const double merit = red[6];
+  __syncthreads();
+  // ---- line search
   double alpha = 1.0, used = 1.0;
   bool ok = false;
-  // this kernel supports T + 1 <= blockDim * NPT nodes
-  constexpr int NPT = 4;
   for (int n = 0; n < 10; ++n, alpha *= 0.5) {
     used = alpha;
     double part = 0.0;
@@ -532,14 +746,15 @@ __global__ void __launch_bounds__(128) k_linesearch(const DevModel *__restrict__
     __syncthreads();
     if (tid == 0) {
       double tot = 0.0;
-      for (int w = 0; w < (int)(blockDim.x >> 6); ++w) tot += red[w];
-      accept = (merit > tot) ? 1 : 0;
+      for (int w = 0; w < nw; ++w) tot += red[w];
+      flag = (merit > tot) ? 1 : 0;
     }
     __syncthreads();
-    ok = accept != 0;
+    ok = flag != 0;
     if (ok) break;
     __syncthreads();
   }
+  if (mode & 4) return;  // timing mode: leave the iterate and the solver state untouched
   if (ok) {
     for (int r = 0; r < NPT; ++r) {
       const int t = tid + r * blockDim.x;
@@ -554,17 +769,21 @@ __global__ void __launch_bounds__(128) k_linesearch(const DevModel *__restrict__
   }
   if (tid == 0) {
     if (!ok) S.flags |= 2;
-    double preg = S.preg, dreg = S.dreg;
+    double pr = S.preg, dr = S.dreg;
     // crocoddyl/mim_solvers regularisation schedule (th_stepdec 0.5, th_stepinc 0.01, factor 10)
-    if (used > 0.5) { preg = fmax(preg / 10.0, kRegMin); dreg = fmax(dreg / 10.0, kRegMin); }
+    if (used > 0.5) { pr = fmax(pr / 10.0, kRegMin); dr = fmax(dr / 10.0, kRegMin); }
     bool stop = false;
     if (used <= 0.01) {
-      preg = fmin(preg * 10.0, kRegMax);
-      dreg = fmin(dreg * 10.0, kRegMax);
-      if (preg == kRegMax) stop = true;
+      pr = fmin(pr * 10.0, kRegMax);
+      dr = fmin(dr * 10.0, kRegMax);
+      if (pr == kRegMax) stop = true;
     }
-    S.preg = preg;
-    S.dreg = dreg;
+    // the gains on exit belong to the point this direction was computed at, with the regularisation
+    // that was in force then: keep it in gains_preg / gains_dreg
+    S.gains_preg = preg;
+    S.gains_dreg = dreg;
+    S.preg = pr;
+    S.dreg = dr;
     if (stop) {
       S.done = 1;
       S.iter = iter + 1;
@@ -572,6 +791,97 @@ __global__ void __launch_bounds__(128) k_linesearch(const DevModel *__restrict__
     } else if (iter + 1 == max_iter) {
       S.iter = max_iter;
     }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Exit path: gains reported by the solver = CSQP's proximal (sigma) backward pass around the
+// last direction.  k_sigma_tile rewrites the QP tiles in place with the sigma terms, k_riccati
+// (backward only) gives Kw, k_gains_to_u maps them to u-space: K = M Kw - taux.
+// ---------------------------------------------------------------------------
+template <int NV>
+__global__ void k_sigma_tile(const DevOcp *__restrict__ op, double *__restrict__ qts, const double *__restrict__ auxs,
+                             const double *__restrict__ dxs, const double *__restrict__ dus) {
+  constexpr int NX = 2 * NV;
+  typedef QT<NV> Q;
+  typedef AUX<NV> A;
+  const DevOcp &o = *op;
+  const int T = o.T;
+  const long long unit = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (unit >= (long long)o.B * (T + 1)) return;
+  const int b = (int)(unit / (T + 1)), t = (int)(unit % (T + 1));
+  double *qt = qts + unit * Q::SIZE;
+  const double *ax = auxs + unit * A::SIZE;
+  const double *dx = dxs + unit * NX;
+  const double sig = kSigma;  // (preg is already folded into the tile by k_calc_qp)
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    qt[Q::Hqq + i * NV + i] += sig;
+    qt[Q::Hvv + i * NV + i] += sig;
+    qt[Q::gx + i] -= sig * dx[i];
+    qt[Q::gx + NV + i] -= sig * dx[NV + i];
+  }
+  if (t == T) return;
+  const double *du = dus + ((long long)b * T + t) * NV;
+  double Mm[NV][NV], tq[NV][NV], tv[NV][NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i)
+#pragma unroll
+    for (int j = 0; j < NV; ++j) { Mm[i][j] = ax[A::M + i * NV + j]; tq[i][j] = ax[A::tq + i * NV + j]; tv[i][j] = ax[A::tv + i * NV + j]; }
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    double gwi = 0.0, gq = 0.0, gv = 0.0;
+#pragma unroll
+    for (int l = 0; l < NV; ++l) { gwi += Mm[i][l] * du[l]; gq += tq[l][i] * du[l]; gv += tv[l][i] * du[l]; }
+    qt[Q::gw + i] -= sig * gwi;
+    qt[Q::gx + i] -= sig * gq;
+    qt[Q::gx + NV + i] -= sig * gv;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      double hww = 0.0, hqw = 0.0, hvw = 0.0, hqq = 0.0, hqv = 0.0, hvv = 0.0;
+#pragma unroll
+      for (int l = 0; l < NV; ++l) {
+        hww += Mm[i][l] * Mm[l][j];
+        hqw += tq[l][i] * Mm[l][j];
+        hvw += tv[l][i] * Mm[l][j];
+        hqq += tq[l][i] * tq[l][j];
+        hqv += tq[l][i] * tv[l][j];
+        hvv += tv[l][i] * tv[l][j];
+      }
+      qt[Q::Hww + i * NV + j] += sig * hww;
+      qt[Q::Hqw + i * NV + j] += sig * hqw;
+      qt[Q::Hvw + i * NV + j] += sig * hvw;
+      qt[Q::Hqq + i * NV + j] += sig * hqq;
+      qt[Q::Hqv + i * NV + j] += sig * hqv;
+      qt[Q::Hvv + i * NV + j] += sig * hvv;
+    }
+  }
+}
+
+template <int NV>
+__global__ void k_gains_to_u(const DevOcp *__restrict__ op, const double *__restrict__ auxs, const double *__restrict__ Kws,
+                             double *__restrict__ Kout) {
+  constexpr int NX = 2 * NV;
+  typedef AUX<NV> A;
+  const DevOcp &o = *op;
+  const int T = o.T;
+  const long long unit = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (unit >= (long long)o.B * T * NV) return;
+  const int i = (int)(unit % NV);
+  const long long node = unit / NV;  // b*T + t
+  const int b = (int)(node / T), t = (int)(node % T);
+  const double *ax = auxs + ((long long)b * (T + 1) + t) * A::SIZE;
+  const double *Kw = Kws + node * NV * NX;
+  double *K = Kout + node * NV * NX + (long long)i * NX;
+  double Mi[NV];
+#pragma unroll
+  for (int l = 0; l < NV; ++l) Mi[l] = ax[A::M + i * NV + l];
+#pragma unroll
+  for (int j = 0; j < NX; ++j) {
+    double acc = (j < NV) ? -ax[A::tq + i * NV + j] : -ax[A::tv + i * NV + (j - NV)];
+#pragma unroll
+    for (int l = 0; l < NV; ++l) acc += Mi[l] * Kw[l * NX + j];
+    K[j] = acc;
   }
 }
 
@@ -585,7 +895,8 @@ __global__ void k_reset_state(DevState *st, int B, int *n_done) {
   DevState s;
   s.kkt = 0.0; s.cost = 0.0; s.merit = 0.0; s.gap = 0.0;
   s.preg = kRegMin; s.dreg = kRegMin;
-  s.iter = 0; s.qp_iters = 0; s.solved = 0; s.flags = 0; s.done = 0; s.pad = 0;
+  s.iter = 0; s.qp_iters = 0; s.solved = 0; s.flags = 0; s.done = 0; s.need_gains = 0;
+  s.gains_preg = kRegMin; s.gains_dreg = kRegMin;
   st[b] = s;
 }
 
@@ -867,3 +1178,5 @@ __global__ void k_ws_from_ref(double *xs, double *us, double *x0, const double *
 }
 
 }  // namespace agx
+
+#include "agx_k1_lanes.hpp"

@@ -199,15 +199,15 @@ int agx_ocp_get_residuals(agx_ocp *ocp, int row, double *out);
 /* Node-parallel derivative pass at the resident (xs, us): writes the tiles to
  * the workspace and optionally copies them out, tiles [B][T+1][AGX_TILE_DOUBLES]. */
 int agx_ocp_calc_diff(agx_ocp *ocp, double *tiles);
-/* One QP direction (Riccati backward + linear forward + KKT) from the tiles in
- * the workspace: K [B][T][nu][ndx], k [B][T][nu], dx [B][T+1][ndx], du [B][T][nu]. */
+/* One QP direction at the resident (xs, us) exactly as the solver computes it (derivative pass,
+ * Riccati backward + linear forward, KKT, reported gains): K [B][T][nu][ndx], k = acceleration-space
+ * feed-forward [B][T][nu], dx [B][T+1][ndx], du [B][T][nu], kkt [B].                                */
 int agx_ocp_direction(agx_ocp *ocp, double *K, double *k, double *dx, double *du, double *kkt);
-/* Upload tiles into the workspace (to test the Riccati kernel in isolation).   */
-int agx_ocp_upload_tiles(agx_ocp *ocp, const double *tiles);
 /* Average device time in milliseconds of `reps` launches of one kernel,
  * measured with hipEvents on the problem's stream.
- * which: 0 = derivative pass (running + terminal launches), 1 = direction (Riccati + forward),
- * 2 = line search, 3 = derivative pass over the running nodes only (one launch).       */
+ * which: 0 = derivative pass (running + terminal launches), 1 = Riccati backward + forward,
+ * 2 = step kernel (du, KKT, line search; nothing committed), 3 = derivative pass over the running
+ * nodes only (one launch), 4 = canonical-tile derivative pass (running nodes).            */
 int agx_ocp_time_kernel(agx_ocp *ocp, int which, int reps, double *avg_ms);
 
 /* ---- device-resident reference trajectory --------------- */

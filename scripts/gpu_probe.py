@@ -28,11 +28,12 @@ t_o = o.calc_diff(ref, None, xs, us)
 sl = _abi.tile_slices(7)
 for name, s in sl.items():
     print("tile", name, rel(t_h[..., s], t_o[..., s]), float(np.abs(t_o[..., s]).max()))
-# 3. direction from oracle tiles
-h.upload_tiles(t_o)
+# 3. direction
+xs[:, 0] = x0
+h.upload_warmstart(xs, us)
 K, k, dx, du, kkt = h.direction()
-Ko, ko, dxo, duo, kkto = o.direction(t_o)
-print("dir dx", rel(dx, dxo), "du", rel(du, duo), "k", rel(k, ko), "kkt", kkt, kkto)
+Ko, ko, dxo, duo, kkto = o.direction(o.calc_diff(ref, None, xs, us))
+print("dir dx", rel(dx, dxo), "du", rel(du, duo), "K", rel(K, Ko), "kkt", kkt, kkto)
 # 4. full solve
 xs_h, us_h, K_h, st_h = h.solve(x0, xs, us, 20)
 xs_o, us_o, K_o, st_o = o.solve(ref, None, x0, xs, us, 20)

