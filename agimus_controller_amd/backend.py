@@ -17,7 +17,7 @@ import numpy as np
 from . import _abi
 
 _CSRC = pathlib.Path(__file__).resolve().parent / "csrc"
-LIB_PATH = _CSRC / "libagimus_hip.so"
+LIB_PATH = pathlib.Path(os.environ.get("AGX_LIB", _CSRC / "libagimus_hip.so"))  # AGX_LIB: development override
 _LIB = None
 
 # Every symbol include/agimus_hip.h declares (checked by the CPU test-suite).

@@ -103,7 +103,11 @@ void fill_rows(const agx_cost_row *rows, int n, int nv, DevRows &d) {
 }
 
 // ---- dispatch over the compiled (NV, CHAIN) instantiations --------------------
+#ifdef AGX_ONLY_NV7  // development builds: one instantiation, short compile
+#define AGX_FOR_NV(MACRO) MACRO(7)
+#else
 #define AGX_FOR_NV(MACRO) MACRO(1) MACRO(2) MACRO(3) MACRO(4) MACRO(6) MACRO(7)
+#endif
 
 template <typename F>
 int dispatch(int nv, bool chain, F &&f) {

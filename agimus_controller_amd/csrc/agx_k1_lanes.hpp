@@ -66,8 +66,11 @@ struct LjNode {
   double pad[2];     // node stride 314 doubles: spreads the 8 nodes of a wave over the banks
 };
 
+#ifndef AGX_K1_WAVES
+#define AGX_K1_WAVES 2
+#endif
 template <int NV, bool TERM>
-__global__ void __launch_bounds__(128) k_calc_qp_lj(const DevModel *__restrict__ mp, const DevOcp *__restrict__ op,
+__global__ void __launch_bounds__(128, AGX_K1_WAVES) k_calc_qp_lj(const DevModel *__restrict__ mp, const DevOcp *__restrict__ op,
                                                     const double *__restrict__ dts, const double *__restrict__ xs,
                                                     const double *__restrict__ us, RefView rv, double *__restrict__ qts,
                                                     double *__restrict__ auxs, const DevState *__restrict__ st) {

@@ -383,32 +383,40 @@ __device__ __forceinline__ double wave_sum(double v) {
 }
 
 // ---------------------------------------------------------------------------
-// K2: Riccati backward + linear forward in (dx, w) coordinates, one wave per instance.
-// LDS: value function, double-buffered QP tile, Q blocks, gains of the current node.
+// K2: Riccati backward + linear forward in (dx, w) coordinates, one wave per instance,
+// REGISTER RESIDENT: no LDS, no barriers.
+//
+// The 64 lanes form an 8 x 8 grid, lane = 8 r + c.  Lane (r, c) holds element [r][c] of every
+// NV x NV block of the symmetric 3 x 3 block matrix
+//        [ Qww Qwq Qwv ]          [ qw ]
+//    M = [ Qqw Qqq Qqv ] ,   g =  [ qq ]   (g_*[r], replicated over c)
+//        [ Qvw Qvq Qvv ]          [ qv ]
+// Phase A builds M and g from the node's QP tile and the value function of node t+1; thanks to
+// the (Phi, G) structure every entry is a local combination of the lane's own V elements
+// (Vqq, Vqv, Vvq = Vqv', Vvv at [r][c]) -- only V f needs a row reduction (3 xor shuffles).
+// Phase B eliminates the NV acceleration variables by Gauss-Jordan pivots inside the ww block,
+// applied to the whole matrix: afterwards the x-x blocks ARE the Schur complement
+// Qxx - Qxw Qww^-1 Qwx (= the new value Hessian, bitwise symmetric by construction), the w-x
+// blocks divided by the pivots are the gains Kw, g_x is the new value gradient and g_w / pivot
+// the feed-forward kw.  Per pivot: 6 cross-lane fetches (column k of the lane's row, row k of
+// the lane's column), 12 FMAs.
 // ---------------------------------------------------------------------------
-template <int NV>
-struct RicLds {
-  static constexpr int NX = 2 * NV;
-  double V[NX * NX];
-  double tile[2][QT<NV>::SIZE];
-  double Qxx[NX * NX];
-  double Qxw[NX * NV];
-  double Qww[NV * NV];
-  double Kw[NV * NX];
-  double vx[NX], vp[NX], qw[NV], kw[NV];
-};
+__device__ __forceinline__ double fast_rcp(double x) {
+  double y = __builtin_amdgcn_rcp(x);
+  y = y * (2.0 - x * y);
+  y = y * (2.0 - x * y);
+  return y;
+}
 
-// forward: 1 = also run the linear forward pass (dx, w)
 template <int NV>
 __global__ void __launch_bounds__(64) k_riccati(const DevOcp *__restrict__ op, const double *__restrict__ dts,
                                                 const double *__restrict__ qts, double *__restrict__ Kws,
                                                 double *__restrict__ kws, double *__restrict__ dxs,
                                                 double *__restrict__ wss, const DevState *__restrict__ st, int forward,
                                                 int gains_pass) {
+  static_assert(NV <= 8, "the register-resident Riccati kernel maps an NV x NV block onto an 8 x 8 lane grid");
   constexpr int NX = 2 * NV, TS = QT<NV>::SIZE;
-  constexpr int NLD = (TS + 63) / 64;
   typedef QT<NV> Q;
-  __shared__ RicLds<NV> s;
   const DevOcp &o = *op;
   const int T = o.T, b = blockIdx.x, lane = threadIdx.x;
   const DevState &S = st[b];
@@ -417,204 +425,128 @@ __global__ void __launch_bounds__(64) k_riccati(const DevOcp *__restrict__ op, c
   const double dreg = gains_pass ? (S.solved ? S.dreg : S.gains_dreg) : S.dreg;
   const double *qb = qts + (long long)b * (T + 1) * TS;
   double *Kw = Kws + (long long)b * T * NV * NX, *kw = kws + (long long)b * T * NV;
-  // terminal value function and the first tile
+  const int r = lane >> 3, c = lane & 7;
+  const bool in = (r < NV) && (c < NV);
+  const int rc = in ? r * NV + c : 0, cr = in ? c * NV + r : 0;  // [r][c] and [c][r] of an NV x NV block
+  const int rr = r < NV ? r : 0, cc = c < NV ? c : 0;
+  const double diag = (r == c) ? 1.0 : 0.0;
+  const int row_base = lane & 56, col_lane = c;
+  // value function of node t+1 (starts as the terminal cost + dreg)
+  double Vqq, Vqv, Vvq, Vvv, vxq, vxv;
   {
     const double *tt = qb + (long long)T * TS;
-    for (int e = lane; e < NX * NX; e += 64) {
-      const int i = e / NX, j = e % NX;
-      double v;
-      if (i < NV && j < NV) v = tt[Q::Hqq + i * NV + j];
-      else if (i < NV) v = tt[Q::Hqv + i * NV + (j - NV)];
-      else if (j < NV) v = tt[Q::Hqv + j * NV + (i - NV)];
-      else v = tt[Q::Hvv + (i - NV) * NV + (j - NV)];
-      s.V[e] = v + (i == j ? dreg : 0.0);
-    }
-    if (lane < NX) s.vx[lane] = tt[Q::gx + lane];
-    const double *t0 = qb + (long long)(T - 1) * TS;
-    for (int e = lane; e < TS; e += 64) s.tile[(T - 1) & 1][e] = t0[e];
+    Vqq = in ? tt[Q::Hqq + rc] + dreg * diag : 0.0;
+    Vqv = in ? tt[Q::Hqv + rc] : 0.0;
+    Vvq = in ? tt[Q::Hqv + cr] : 0.0;
+    Vvv = in ? tt[Q::Hvv + rc] + dreg * diag : 0.0;
+    vxq = (r < NV) ? tt[Q::gx + rr] : 0.0;
+    vxv = (r < NV) ? tt[Q::gx + NV + rr] : 0.0;
   }
-  __syncthreads();
+  // tile elements of the current node, prefetched one node ahead
+  double hqq, hqv, hvq, hvv, hqw, hvw, hwq, hwv, hww, gq, gv, gwr, fq, fv;
+  auto load_tile = [&](int t) {
+    const double *tl = qb + (long long)t * TS;
+    hqq = tl[Q::Hqq + rc]; hqv = tl[Q::Hqv + rc]; hvq = tl[Q::Hqv + cr]; hvv = tl[Q::Hvv + rc];
+    hqw = tl[Q::Hqw + rc]; hvw = tl[Q::Hvw + rc]; hwq = tl[Q::Hqw + cr]; hwv = tl[Q::Hvw + cr];
+    hww = tl[Q::Hww + rc];
+    gq = tl[Q::gx + rr]; gv = tl[Q::gx + NV + rr]; gwr = tl[Q::gw + rr];
+    fq = tl[Q::f + cc]; fv = tl[Q::f + NV + cc];
+  };
+  load_tile(T - 1);
   for (int t = T - 1; t >= 0; --t) {
-    const double *tl = s.tile[t & 1];
     const double h = dts[t], h2 = h * h;
-    // prefetch the next tile into registers: its latency hides behind this step
-    double pre[NLD];
-    if (t > 0) {
-      const double *tn = qb + (long long)(t - 1) * TS;
+    // current tile -> working copies, then start fetching the next one
+    const double Hqq_ = hqq, Hqv_ = hqv, Hvq_ = hvq, Hvv_ = hvv, Hqw_ = hqw, Hvw_ = hvw, Hwq_ = hwq, Hwv_ = hwv, Hww_ = hww;
+    const double gq_ = gq, gv_ = gv, gw_ = gwr, fq_ = (c < NV) ? fq : 0.0, fv_ = (c < NV) ? fv : 0.0;
+    if (t > 0) load_tile(t - 1);
+    // ---- phase A
+    // vp = vx + V f  (row reduction over c)
+    double pq = Vqq * fq_ + Vqv * fv_, pv = Vvq * fq_ + Vvv * fv_;
 #pragma unroll
-      for (int r = 0; r < NLD; ++r) {
-        const int e = lane + 64 * r;
-        pre[r] = (e < TS) ? tn[e] : 0.0;
-      }
+    for (int off = 1; off < 8; off <<= 1) {
+      pq += __shfl_xor(pq, off, 64);
+      pv += __shfl_xor(pv, off, 64);
     }
-    // ---- phase A: vp = vx + V f ; Qxx = Hxx + Phi' V Phi ; Qxw = Hxw + (G' V Phi)' ; Qww = Hww + G' V G
-    if (lane < NX) {
-      double acc = s.vx[lane];
+    const double vpq = vxq + pq, vpv = vxv + pv;
+    // Y = G' V  (rows indexed by the acceleration variable):  Yq = h^2 Vqq + h Vvq, Yv = h^2 Vqv + h Vvv
+    const double Yq = h2 * Vqq + h * Vvq, Yv = h2 * Vqv + h * Vvv;
+    // Y' at [r][c]: Yq'[r][c] = Yq[c][r] = h^2 Vqq + h Vqv ; Yv'[r][c] = Yv[c][r] = h^2 Vvq + h Vvv
+    const double YqT = h2 * Vqq + h * Vqv, YvT = h2 * Vvq + h * Vvv;
+    double Mww = Hww_ + h2 * Yq + h * Yv;            // Hww + G' V G
+    double Mwq = Hwq_ + Yq, Mwv = Hwv_ + h * Yq + Yv;  // (G' V Phi)
+    double Mqw = Hqw_ + YqT, Mvw = Hvw_ + h * YqT + YvT;
+    double Mqq = Hqq_ + Vqq;
+    double Mqv = Hqv_ + h * Vqq + Vqv;
+    double Mvq = Hvq_ + h * Vqq + Vvq;
+    double Mvv = Hvv_ + h2 * Vqq + h * (Vqv + Vvq) + Vvv;
+    double gW = gw_ + h2 * vpq + h * vpv;   // qw[r]
+    double gQ = gq_ + vpq;                  // qx = gx + Phi' vp
+    double gV = gv_ + h * vpq + vpv;
+    if (!in) { Mww = diag; Mwq = 0.0; Mwv = 0.0; Mqw = 0.0; Mvw = 0.0; Mqq = 0.0; Mqv = 0.0; Mvq = 0.0; Mvv = 0.0; }
+    if (r >= NV) { gW = 0.0; gQ = 0.0; gV = 0.0; }
+    // ---- phase B: Gauss-Jordan pivots k = 0..NV-1 in the ww block
+    double rp_row = 1.0;
 #pragma unroll
-      for (int j = 0; j < NX; ++j) acc += s.V[lane * NX + j] * tl[Q::f + j];
-      s.vp[lane] = acc;
+    for (int k = 0; k < NV; ++k) {
+      const double piv = __shfl(Mww, 9 * k, 64);
+      const double rp = fast_rcp(piv);
+      const double gk = __shfl(gW, 8 * k, 64);
+      // column k of my row (three row blocks), row k of my column (three column blocks)
+      const double cw = __shfl(Mww, row_base | k, 64), cq = __shfl(Mqw, row_base | k, 64), cv = __shfl(Mvw, row_base | k, 64);
+      const double rw = __shfl(Mww, 8 * k + col_lane, 64), rq = __shfl(Mwq, 8 * k + col_lane, 64), rv2 = __shfl(Mwv, 8 * k + col_lane, 64);
+      const double fw = (r == k) ? 0.0 : cw * rp;  // the pivot row itself is left untouched
+      const double fqx = cq * rp, fvx = cv * rp;
+      Mww -= fw * rw; Mwq -= fw * rq; Mwv -= fw * rv2; gW -= fw * gk;
+      Mqw -= fqx * rw; Mqq -= fqx * rq; Mqv -= fqx * rv2; gQ -= fqx * gk;
+      Mvw -= fvx * rw; Mvq -= fvx * rq; Mvv -= fvx * rv2; gV -= fvx * gk;
+      if (r == k) rp_row = rp;
     }
-    for (int e = lane; e < NX * NX; e += 64) {
-      const int i = e / NX, j = e % NX;
-      const int iq = i < NV ? i : i - NV, jq = j < NV ? j : j - NV;
-      double v, hx;
-      if (i < NV && j < NV) {
-        v = s.V[i * NX + j];
-        hx = tl[Q::Hqq + i * NV + j];
-      } else if (i < NV) {
-        v = h * s.V[i * NX + jq] + s.V[i * NX + j];
-        hx = tl[Q::Hqv + i * NV + jq];
-      } else if (j < NV) {
-        v = h * s.V[iq * NX + j] + s.V[i * NX + j];
-        hx = tl[Q::Hqv + j * NV + iq];
-      } else {
-        v = h2 * s.V[iq * NX + jq] + h * (s.V[iq * NX + j] + s.V[i * NX + jq]) + s.V[i * NX + j];
-        hx = tl[Q::Hvv + iq * NV + jq];
-      }
-      s.Qxx[e] = hx + v;
+    // gains of this node: Kw = D^-1 [Mwq Mwv], kw = D^-1 gW
+    if (in) {
+      Kw[(long long)t * NV * NX + r * NX + c] = Mwq * rp_row;
+      Kw[(long long)t * NV * NX + r * NX + NV + c] = Mwv * rp_row;
     }
-    for (int e = lane; e < NX * NV; e += 64) {
-      const int i = e / NV, a = e % NV;  // Qxw[i][a] = Hxw[i][a] + R[a][i],  R = Y Phi,  Y = G' V
-      double r, hx;
-      if (i < NV) {
-        r = h2 * s.V[a * NX + i] + h * s.V[(NV + a) * NX + i];
-        hx = tl[Q::Hqw + i * NV + a];
-      } else {
-        const int iq = i - NV;
-        const double yq = h2 * s.V[a * NX + iq] + h * s.V[(NV + a) * NX + iq];
-        const double yv = h2 * s.V[a * NX + i] + h * s.V[(NV + a) * NX + i];
-        r = h * yq + yv;
-        hx = tl[Q::Hvw + iq * NV + a];
-      }
-      s.Qxw[e] = hx + r;
-    }
-    for (int e = lane; e < NV * NV; e += 64) {
-      const int a = e / NV, c = e % NV;  // S = Y G
-      const double yq = h2 * s.V[a * NX + c] + h * s.V[(NV + a) * NX + c];
-      const double yv = h2 * s.V[a * NX + NV + c] + h * s.V[(NV + a) * NX + NV + c];
-      s.Qww[e] = tl[Q::Hww + e] + h2 * yq + h * yv;
-    }
-    __syncthreads();
-    // ---- phase B: Cholesky of Qww in registers (every lane), lane j solves column j, lane NX solves kw
-    {
-      double L[NV][NV];
-#pragma unroll
-      for (int i = 0; i < NV; ++i)
-#pragma unroll
-        for (int j = 0; j <= i; ++j) L[i][j] = 0.5 * (s.Qww[i * NV + j] + s.Qww[j * NV + i]);
-#pragma unroll
-      for (int j = 0; j < NV; ++j) {
-        double dd = L[j][j];
-#pragma unroll
-        for (int l = 0; l < j; ++l) dd -= L[j][l] * L[j][l];
-        const double il = 1.0 / sqrt(dd);
-        L[j][j] = il;
-#pragma unroll
-        for (int i = j + 1; i < NV; ++i) {
-          double sacc = L[i][j];
-#pragma unroll
-          for (int l = 0; l < j; ++l) sacc -= L[i][l] * L[j][l];
-          L[i][j] = sacc * il;
-        }
-      }
-      if (lane <= NX) {
-        double rhs[NV];
-        if (lane < NX) {
-#pragma unroll
-          for (int a = 0; a < NV; ++a) rhs[a] = s.Qxw[lane * NV + a];
-        } else {
-#pragma unroll
-          for (int a = 0; a < NV; ++a) {
-            rhs[a] = tl[Q::gw + a] + h2 * s.vp[a] + h * s.vp[NV + a];
-            s.qw[a] = rhs[a];
-          }
-        }
-#pragma unroll
-        for (int i = 0; i < NV; ++i) {
-          double sacc = rhs[i];
-#pragma unroll
-          for (int l = 0; l < i; ++l) sacc -= L[i][l] * rhs[l];
-          rhs[i] = sacc * L[i][i];
-        }
-#pragma unroll
-        for (int i = NV - 1; i >= 0; --i) {
-          double sacc = rhs[i];
-#pragma unroll
-          for (int l = i + 1; l < NV; ++l) sacc -= L[l][i] * rhs[l];
-          rhs[i] = sacc * L[i][i];
-        }
-        if (lane < NX) {
-#pragma unroll
-          for (int a = 0; a < NV; ++a) {
-            s.Kw[a * NX + lane] = rhs[a];
-            Kw[(long long)t * NV * NX + a * NX + lane] = rhs[a];
-          }
-        } else {
-#pragma unroll
-          for (int a = 0; a < NV; ++a) {
-            s.kw[a] = rhs[a];
-            kw[(long long)t * NV + a] = rhs[a];
-          }
-        }
-      }
-    }
-    __syncthreads();
-    // ---- phase C: V = sym(Qxx - Qxw Kw) + dreg ; vx = qx - Kw' qw ; publish the prefetched tile
-    for (int e = lane; e < NX * NX; e += 64) {
-      const int i = e / NX, j = e % NX;
-      if (j < i) continue;
-      double v1 = s.Qxx[i * NX + j], v2 = s.Qxx[j * NX + i];
-#pragma unroll
-      for (int a = 0; a < NV; ++a) {
-        v1 -= s.Qxw[i * NV + a] * s.Kw[a * NX + j];
-        v2 -= s.Qxw[j * NV + a] * s.Kw[a * NX + i];
-      }
-      const double v = 0.5 * (v1 + v2) + (i == j ? dreg : 0.0);
-      s.V[i * NX + j] = v;
-      s.V[j * NX + i] = v;
-    }
-    if (lane < NX) {
-      double acc = tl[Q::gx + lane] + s.vp[lane] + (lane >= NV ? h * s.vp[lane - NV] : 0.0);
-#pragma unroll
-      for (int a = 0; a < NV; ++a) acc -= s.Kw[a * NX + lane] * s.qw[a];
-      s.vx[lane] = acc;
-    }
-    if (t > 0) {
-      double *dst = s.tile[(t - 1) & 1];
-#pragma unroll
-      for (int r = 0; r < NLD; ++r) {
-        const int e = lane + 64 * r;
-        if (e < TS) dst[e] = pre[r];
-      }
-    }
-    __syncthreads();
+    if (c == 0 && r < NV) kw[(long long)t * NV + r] = gW * rp_row;
+    // value function of node t
+    Vqq = Mqq + dreg * diag; Vqv = Mqv; Vvq = Mvq; Vvv = Mvv + dreg * diag;
+    if (!in) { Vqq = 0.0; Vqv = 0.0; Vvq = 0.0; Vvv = 0.0; }
+    vxq = gQ; vxv = gV;
   }
   if (!forward) return;
   // ---- forward pass, shuffle only: lane j < NX holds dx_j, lane a < NV computes w_a
   double *dx = dxs + (long long)b * (T + 1) * NX, *ws = wss + (long long)b * T * NV;
   double dxv = 0.0;
   if (lane < NX) dx[lane] = 0.0;
-  for (int t = 0; t < T; ++t) {
-    const double h = dts[t], h2 = h * h;
-    double krow[NX], kwa = 0.0, fv = 0.0;
+  __threadfence_block();  // the gains written above are read back by other lanes below
+  double krow[NX], kwa = 0.0, fvv = 0.0;
+  auto load_gain = [&](int t) {
     if (lane < NV) {
 #pragma unroll
       for (int j = 0; j < NX; ++j) krow[j] = Kw[(long long)t * NV * NX + lane * NX + j];
       kwa = kw[(long long)t * NV + lane];
     }
-    if (lane < NX) fv = qb[(long long)t * TS + Q::f + lane];
-    double wv = -kwa;
+    if (lane < NX) fvv = qb[(long long)t * TS + Q::f + lane];
+  };
+  load_gain(0);
+  for (int t = 0; t < T; ++t) {
+    const double h = dts[t], h2 = h * h;
+    double kr[NX];
+#pragma unroll
+    for (int j = 0; j < NX; ++j) kr[j] = krow[j];
+    const double kwc = kwa, fc = fvv;
+    if (t + 1 < T) load_gain(t + 1);
+    double wv = -kwc;
 #pragma unroll
     for (int j = 0; j < NX; ++j) {
       const double dj = __shfl(dxv, j, 64);
-      if (lane < NV) wv -= krow[j] * dj;
+      wv -= kr[j] * dj;
     }
     if (lane >= NV) wv = 0.0;
-    const double dx_up = __shfl(dxv, (lane + NV) & 63, 64);    // dx_v partner for the q rows
-    const double w_dn = __shfl(wv, lane >= NV ? lane - NV : lane, 64);  // w of the matching joint
+    const double dx_up = __shfl(dxv, (lane + NV) & 63, 64);
+    const double w_dn = __shfl(wv, lane >= NV ? lane - NV : lane, 64);
     double nxt;
-    if (lane < NV) nxt = dxv + h * dx_up + h2 * wv + fv;
-    else nxt = dxv + h * w_dn + fv;
+    if (lane < NV) nxt = dxv + h * dx_up + h2 * wv + fc;
+    else nxt = dxv + h * w_dn + fc;
     if (lane < NV) ws[(long long)t * NV + lane] = wv;
     dxv = (lane < NX) ? nxt : 0.0;
     if (lane < NX) dx[(long long)(t + 1) * NX + lane] = dxv;
