@@ -51,6 +51,7 @@ struct agx_ocp {
   double *d_qt = nullptr, *d_aux = nullptr, *d_w = nullptr;  // QP tiles, aux tiles, acceleration steps
   int qt_size = 0, aux_size = 0;
   bool k1_lanes = true;  // AGX_K1_LANES=0 selects the one-lane-per-node derivative kernel
+  bool lanes_ok = true;  // problem fits the LDS staging of the 8-lanes-per-node kernel
   double *d_ref = nullptr;  // owned tile [B][T+1][stride]
   int *d_frames = nullptr;  // owned [B][T+1][AGX_MAX_ROWS]
   bool frames_set = false;
@@ -152,11 +153,11 @@ int launch_calc_qp(agx_ocp *o, bool running_only = false) {
     constexpr int NV = decltype(NVc)::value;
     constexpr bool CH = decltype(CHc)::value;
     const long long units = (long long)o->B * o->T;
-    if (CH && o->k1_lanes) {
-      hipLaunchKernelGGL((agx::k_calc_qp_lj<NV, false>), dim3((int)((units * 8 + 127) / 128)), dim3(128), 0, o->stream, o->d_model,
+    if (CH && o->k1_lanes && o->lanes_ok) {
+      hipLaunchKernelGGL((agx::k_calc_qp_lj<NV, false>), dim3((int)((units * 8 + 63) / 64)), dim3(64), 0, o->stream, o->d_model,
                          o->d_ocp, o->d_dt, o->d_xs, o->d_us, o->rv, o->d_qt, o->d_aux, o->d_state);
       if (!running_only)
-        hipLaunchKernelGGL((agx::k_calc_qp_lj<NV, true>), dim3((int)(((long long)o->B * 8 + 127) / 128)), dim3(128), 0, o->stream,
+        hipLaunchKernelGGL((agx::k_calc_qp_lj<NV, true>), dim3((int)(((long long)o->B * 8 + 63) / 64)), dim3(64), 0, o->stream,
                            o->d_model, o->d_ocp, o->d_dt, o->d_xs, o->d_us, o->rv, o->d_qt, o->d_aux, o->d_state);
     } else {
       hipLaunchKernelGGL((agx::k_calc_qp<NV, CH>), dim3((int)((units + 63) / 64)), dim3(64), 0, o->stream, o->d_model, o->d_ocp,
@@ -197,12 +198,12 @@ int launch_gains(agx_ocp *o) {
   return dispatch(o->nv, o->chain, [&](auto NVc, auto CHc) -> int {
     constexpr int NV = decltype(NVc)::value;
     const long long nodes = (long long)o->B * (o->T + 1);
-    hipLaunchKernelGGL((agx::k_sigma_tile<NV>), dim3((int)((nodes + 63) / 64)), dim3(64), 0, o->stream, o->d_ocp, o->d_qt, o->d_aux,
+    hipLaunchKernelGGL((agx::k_sigma_tile<NV>), dim3((int)((nodes * 8 + 127) / 128)), dim3(128), 0, o->stream, o->d_ocp, o->d_qt, o->d_aux,
                        o->d_dx, o->d_du);
     hipLaunchKernelGGL((agx::k_riccati<NV>), dim3(o->B), dim3(64), 0, o->stream, o->d_ocp, o->d_dt, o->d_qt, o->d_Kws, o->d_kws,
                        o->d_dx, o->d_w, o->d_state, 0, 1);
-    const long long rows = (long long)o->B * o->T * NV;
-    hipLaunchKernelGGL((agx::k_gains_to_u<NV>), dim3((int)((rows + 127) / 128)), dim3(128), 0, o->stream, o->d_ocp, o->d_aux, o->d_Kws,
+    const long long rows = (long long)o->B * o->T * 16;
+    hipLaunchKernelGGL((agx::k_gains_to_u<NV>), dim3((int)((rows + 255) / 256)), dim3(256), 0, o->stream, o->d_ocp, o->d_aux, o->d_Kws,
                        o->d_Kout);
     HIPCHK(hipGetLastError());
     return 0;
@@ -345,8 +346,8 @@ int agx_ocp_create(const agx_model *m, const agx_ocp_desc *d, int batch, int dev
   if (const char *e = getenv("AGX_K1_LANES")) o->k1_lanes = (e[0] != '0');
   o->T = d->horizon; o->B = batch; o->device = device;
   o->tile = AGX_TILE_DOUBLES(o->nv);
-  o->qt_size = 6 * o->nv * o->nv + 5 * o->nv + 2;
-  o->aux_size = 4 * o->nv * o->nv + 3 * o->nv + (o->nv & 1);
+  o->qt_size = 6 * o->nv * 8 + 48;   // QT<NV>::SIZE
+  o->aux_size = 4 * o->nv * 8 + 24;  // AUX<NV>::SIZE
   o->stride = agx_ref_stride(d, o->nv);
   o->dt.assign(d->dt, d->dt + d->horizon);
   std::memset(&o->ho, 0, sizeof(o->ho));
@@ -356,6 +357,15 @@ int agx_ocp_create(const agx_model *m, const agx_ocp_desc *d, int batch, int dev
   o->ho.tol = d->termination_tolerance;
   o->ho.mu_dyn = d->mu_dynamic;
   o->ho.mu_con = d->mu_constraint;
+  {
+    auto n_frame_rows = [](const DevRows &r) {
+      int n = 0;
+      for (int i = 0; i < r.n; ++i)
+        n += (r.kind[i] == AGX_RES_FRAME_PLACEMENT || r.kind[i] == AGX_RES_FRAME_TRANSLATION || r.kind[i] == AGX_RES_FRAME_ROTATION);
+      return n;
+    };
+    o->lanes_ok = o->stride <= agx::kLjRef && n_frame_rows(o->ho.rows[0]) <= 2 && n_frame_rows(o->ho.rows[1]) <= 2;
+  }
   // probe that a kernel instantiation exists
   if (dispatch(o->nv, o->chain, [](auto, auto) -> int { return 0; })) { delete o; return -1; }
   if (set_device(o)) { delete o; return -1; }

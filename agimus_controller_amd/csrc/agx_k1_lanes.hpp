@@ -11,40 +11,75 @@
 // Same mathematics as agx_device.hpp (see the derivation there); results agree to round-off.
 #pragma once
 
+#include <type_traits>
+
 #include "agx_device.hpp"
 
 namespace agx {
 
-__device__ __forceinline__ double g_up(double x, int off) { return __shfl_up(x, off, 8); }
-__device__ __forceinline__ double g_dn(double x, int off) { return __shfl_down(x, off, 8); }
+#ifdef AGX_K1_NOSTORE  // experiment: fold every tile store into one checksum store per lane
+#define K1ST(ptr, val) chk += (val)
+#else
+#define K1ST(ptr, val) (ptr) = (val)
+#endif
+
+// Shifts inside the 8-lane group as DPP row shifts (VALU, no LDS traffic): a row is 16 lanes = two
+// groups; values that cross from one group into the next land only in lanes the callers mask out
+// (l8 < off for shift-up, l8 + off >= 8 for shift-down).  The LDS pipe of the CU is the scarce
+// resource of this kernel -- ds_bpermute-based __shfl would put ~400 more instructions on it.
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov(double x) {
+  const int lo = __double2loint(x), hi = __double2hiint(x);
+  const int lo2 = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, true);
+  const int hi2 = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, true);
+  return __hiloint2double(hi2, lo2);
+}
+template <int OFF>
+__device__ __forceinline__ double g_up(double x) { return dpp_mov<0x110 + OFF>(x); }  // row_shr:OFF -> lane i reads lane i-OFF
+template <int OFF>
+__device__ __forceinline__ double g_dn(double x) { return dpp_mov<0x100 + OFF>(x); }  // row_shl:OFF -> lane i reads lane i+OFF
 __device__ __forceinline__ double g_bc(double x, int src) { return __shfl(x, src, 8); }
 
 // inclusive prefix / suffix sums of N doubles over the 8-lane group
+template <int N, int OFF>
+__device__ __forceinline__ void g_prefix_step(double *x, int l8) {
+  double y[N];
+#pragma unroll
+  for (int e = 0; e < N; ++e) y[e] = g_up<OFF>(x[e]);
+  if (l8 >= OFF) {
+#pragma unroll
+    for (int e = 0; e < N; ++e) x[e] += y[e];
+  }
+}
 template <int N>
 __device__ __forceinline__ void g_prefix_sum(double *x, int l8) {
+  g_prefix_step<N, 1>(x, l8);
+  g_prefix_step<N, 2>(x, l8);
+  g_prefix_step<N, 4>(x, l8);
+}
+template <int N, int OFF>
+__device__ __forceinline__ void g_suffix_step(double *x, int l8) {
+  double y[N];
 #pragma unroll
-  for (int off = 1; off < 8; off <<= 1) {
-    double y[N];
+  for (int e = 0; e < N; ++e) y[e] = g_dn<OFF>(x[e]);
+  if (l8 + OFF < 8) {
 #pragma unroll
-    for (int e = 0; e < N; ++e) y[e] = g_up(x[e], off);
-    if (l8 >= off) {
-#pragma unroll
-      for (int e = 0; e < N; ++e) x[e] += y[e];
-    }
+    for (int e = 0; e < N; ++e) x[e] += y[e];
   }
 }
 template <int N>
 __device__ __forceinline__ void g_suffix_sum(double *x, int l8) {
-#pragma unroll
-  for (int off = 1; off < 8; off <<= 1) {
-    double y[N];
-#pragma unroll
-    for (int e = 0; e < N; ++e) y[e] = g_dn(x[e], off);
-    if (l8 + off < 8) {
-#pragma unroll
-      for (int e = 0; e < N; ++e) x[e] += y[e];
-    }
-  }
+  g_suffix_step<N, 1>(x, l8);
+  g_suffix_step<N, 2>(x, l8);
+  g_suffix_step<N, 4>(x, l8);
+}
+// LDS hand-off between lanes of ONE wave: DS operations of a wave execute in order, so only the
+// compiler has to be kept from reordering / caching across the hand-off (no s_barrier, and no
+// wait for the global stores a workgroup barrier would drag in).
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 __device__ __forceinline__ double g_sum(double x) {
   x += __shfl_xor(x, 1, 8);
@@ -55,29 +90,38 @@ __device__ __forceinline__ double g_sum(double x) {
 
 // per-node LDS tile (doubles).  Phase 1 (dynamics): S, m6, Sd, psi, Dt.  Phase 2 (after the
 // derivative matrices exist) reuses the same storage for tq, tv and the frame Jacobian J.
+constexpr int kLjRef = 96;  // reference-tile doubles staged in LDS per node (larger tiles are read from HBM)
 struct LjNode {
   union {
-    struct { double S[8][6], m6[8][6], Sd[8][6], psi[8][6]; } p1;
+    struct { double S[8][6], m6[8][6]; } p1;
     struct { double tq[8][8], tv[8][8], J[8][6]; } p2;
   } u;
   double Dt[8][4];
   double M[8][8];
-  double vec[3][8];  // rhs / lu / D
-  double pad[2];     // node stride 314 doubles: spreads the 8 nodes of a wave over the banks
+  double vec[3][8];    // rhs / lu / D
+  double ref[kLjRef];  // the node's reference tile, staged once at kernel start
+  double frm[2][14];   // placement (12) of up to two frames used by the cost rows
+  int fpar[4];         // their parent joints, frame ids
+  double pad[2];       // odd multiple of 2 doubles: spreads the 8 nodes of a wave over the banks
+};
+// joint constants of the model, staged once per wave: placement 12 | axis 3 | com 3 | inertia 9 | mass | armature
+struct LjModel {
+  double j[8][30];
 };
 
 #ifndef AGX_K1_WAVES
 #define AGX_K1_WAVES 2
 #endif
 template <int NV, bool TERM>
-__global__ void __launch_bounds__(128, AGX_K1_WAVES) k_calc_qp_lj(const DevModel *__restrict__ mp, const DevOcp *__restrict__ op,
+__global__ void __launch_bounds__(64, AGX_K1_WAVES) k_calc_qp_lj(const DevModel *__restrict__ mp, const DevOcp *__restrict__ op,
                                                     const double *__restrict__ dts, const double *__restrict__ xs,
                                                     const double *__restrict__ us, RefView rv, double *__restrict__ qts,
                                                     double *__restrict__ auxs, const DevState *__restrict__ st) {
   constexpr int NX = 2 * NV;
   typedef QT<NV> Q;
   typedef AUX<NV> A;
-  __shared__ LjNode lds[16];
+  __shared__ LjNode lds[8];  // one wave per workgroup: 8 nodes
+  __shared__ LjModel lmod;
   const DevModel &m = *mp;
   const DevOcp &o = *op;
   const int T = o.T;
@@ -100,11 +144,47 @@ __global__ void __launch_bounds__(128, AGX_K1_WAVES) k_calc_qp_lj(const DevModel
   double *ax = auxs + ((long long)b * (T + 1) + t) * A::SIZE;
   const DevRows &rows = o.rows[TERM ? 1 : 0];
   const bool wr = act && jl;  // this lane stores
+  double chk = 0.0;
+  (void)chk;
+
+  // ---- prologue: every global read of the kernel is issued here, back to back, and parked in LDS
+  // (one memory round trip instead of one per use; nothing is loaded after the first store)
+  const double *gref = ref_at(rv, b, t, T);
+  const int *gframes = frames_at(rv, b, t, T);
+  {
+    if (threadIdx.x < 8) {
+      const int jj = threadIdx.x < NV ? threadIdx.x : NV - 1;
+      double *d = lmod.j[threadIdx.x];
+#pragma unroll
+      for (int e = 0; e < 12; ++e) d[e] = m.placement[jj][e];
+#pragma unroll
+      for (int e = 0; e < 3; ++e) { d[12 + e] = m.axis[jj][e]; d[15 + e] = m.com[jj][e]; }
+#pragma unroll
+      for (int e = 0; e < 9; ++e) d[18 + e] = m.inertia[jj][e];
+      d[27] = m.mass[jj];
+      d[28] = m.armature[jj];
+    }
+    for (int e = l8; e < o.stride; e += 8) L.ref[e] = gref[e];  // host guarantees stride <= kLjRef
+    // frames of the (up to two) frame-based cost rows
+    int slot = 0;
+    for (int r = 0; r < rows.n && slot < 2; ++r) {
+      const int kind = rows.kind[r];
+      if (kind != AGX_RES_FRAME_PLACEMENT && kind != AGX_RES_FRAME_TRANSLATION && kind != AGX_RES_FRAME_ROTATION) continue;
+      int frame = gframes ? gframes[r] : -1;
+      if (frame < 0) frame = rows.frame[r];
+      for (int e = l8; e < 12; e += 8) L.frm[slot][e] = m.frame_placement[frame][e];
+      if (l8 == 0) { L.fpar[slot] = m.frame_parent[frame]; L.fpar[2 + slot] = r; }
+      ++slot;
+    }
+  }
+  const double grav[3] = {m.gravity[0], m.gravity[1], m.gravity[2]};
+  __syncthreads();
+  const double *mj = lmod.j[l8];
 
   // ---- kinematics: local placement, then SE3 prefix product along the chain
   double R[9], p[3];
   {
-    const double *ax3 = m.axis[j];
+    const double *ax3 = mj + 12;
     double s, c;
     sincos(qj, &s, &c);
     const double omc = 1.0 - c;
@@ -118,27 +198,30 @@ __global__ void __launch_bounds__(128, AGX_K1_WAVES) k_calc_qp_lj(const DevModel
     Rq[6] = omc * ax3[2] * ax3[0] - s * ax3[1];
     Rq[7] = omc * ax3[2] * ax3[1] + s * ax3[0];
     Rq[8] = c + omc * ax3[2] * ax3[2];
-    mm3(m.placement[j], Rq, R);
-    p[0] = m.placement[j][9]; p[1] = m.placement[j][10]; p[2] = m.placement[j][11];
+    mm3(mj, Rq, R);
+    p[0] = mj[9]; p[1] = mj[10]; p[2] = mj[11];
   }
-#pragma unroll
-  for (int off = 1; off < 8; off <<= 1) {
+  auto se3_step = [&](auto OFFc) {
+    constexpr int OFF = decltype(OFFc)::value;
     double Rp[9], pp[3];
 #pragma unroll
-    for (int e = 0; e < 9; ++e) Rp[e] = g_up(R[e], off);
+    for (int e = 0; e < 9; ++e) Rp[e] = g_up<OFF>(R[e]);
 #pragma unroll
-    for (int e = 0; e < 3; ++e) pp[e] = g_up(p[e], off);
-    if (l8 >= off) {
+    for (int e = 0; e < 3; ++e) pp[e] = g_up<OFF>(p[e]);
+    if (l8 >= OFF) {
       double tt[3];
       mv3(Rp, p, tt);
       p[0] = pp[0] + tt[0]; p[1] = pp[1] + tt[1]; p[2] = pp[2] + tt[2];
       mm3(Rp, R, R);
     }
-  }
+  };
+  se3_step(std::integral_constant<int, 1>());
+  se3_step(std::integral_constant<int, 2>());
+  se3_step(std::integral_constant<int, 4>());
   double S[6];
   {
     double z[3];
-    mv3(R, m.axis[j], z);
+    mv3(R, mj + 12, z);
     cross3(p, z, S);
     S[3] = z[0]; S[4] = z[1]; S[5] = z[2];
     if (!jl) {
@@ -150,11 +233,11 @@ __global__ void __launch_bounds__(128, AGX_K1_WAVES) k_calc_qp_lj(const DevModel
   double Ib[10];
   {
     double cw[3];
-    mv3(R, m.com[j], cw);
+    mv3(R, mj + 15, cw);
     cw[0] += p[0]; cw[1] += p[1]; cw[2] += p[2];
-    const double ms = jl ? m.mass[j] : 0.0;
+    const double ms = jl ? mj[27] : 0.0;
     double Tm[9], Iw[9];
-    mm3(R, m.inertia[j], Tm);
+    mm3(R, mj + 18, Tm);
 #pragma unroll
     for (int a = 0; a < 3; ++a)
 #pragma unroll
@@ -175,9 +258,14 @@ __global__ void __launch_bounds__(128, AGX_K1_WAVES) k_calc_qp_lj(const DevModel
   g_suffix_sum<10>(Ic, l8);
   double m6[6];
   iapply(Ic, S, m6);
+#if defined(AGX_K1_STAGE) && AGX_K1_STAGE == 1
+  { if (wr) qt[l8] = m6[0] + m6[5] + R[0] + p[1]; return; }
+#endif
 
   // ---- TERM nodes carry costs only; running nodes: dynamics
-  double v6[6], Sd[6], h6[6], tqc[NV], tvc[NV], Mc[NV], qdd = 0.0;
+  double v6[6], Sd[6], h6[6], tqc[NV], tvc[NV], Mc[NV], qdd = 0.0, gapq = 0.0, gapv = 0.0;
+  // successor state for the gap, fetched before anything is stored
+  const double xnq = TERM ? 0.0 : xp[NX + j], xnv = TERM ? 0.0 : xp[NX + NV + j];
 #pragma unroll
   for (int i = 0; i < NV; ++i) { tqc[i] = 0.0; tvc[i] = 0.0; Mc[i] = 0.0; }
   if (!TERM) {
@@ -189,7 +277,7 @@ __global__ void __launch_bounds__(128, AGX_K1_WAVES) k_calc_qp_lj(const DevModel
 #pragma unroll
     for (int e = 0; e < 6; ++e) a0[e] = Sd[e] * vj;
     g_prefix_sum<6>(a0, l8);
-    a0[0] -= m.gravity[0]; a0[1] -= m.gravity[1]; a0[2] -= m.gravity[2];
+    a0[0] -= grav[0]; a0[1] -= grav[1]; a0[2] -= grav[2];
     iapply(Ib, v6, h6);
     double fb[6], g6[6], x6[6];
     iapply(Ib, a0, g6);
@@ -202,18 +290,17 @@ __global__ void __launch_bounds__(128, AGX_K1_WAVES) k_calc_qp_lj(const DevModel
 #pragma unroll
     for (int e = 0; e < 6; ++e) { L.u.p1.S[l8][e] = S[e]; L.u.p1.m6[l8][e] = m6[e]; }
     L.vec[0][l8] = uj - nle;
-    __syncthreads();
+    wave_lds_sync();
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       double val;
       if (i >= l8) val = dot6(S, L.u.p1.m6[i]);
       else val = dot6(L.u.p1.S[i], m6);
-      if (i == l8) val += m.armature[j];
+      if (i == l8) val += mj[28];
       Mc[i] = val;
       L.M[i][l8] = val;
-      if (wr) ax[A::M + i * NV + l8] = val;
     }
-    __syncthreads();
+    wave_lds_sync();
     // every lane factorises M (LDL', reciprocal pivots) and solves for qdd
     {
       double Lf[NV][NV], dk[NV], dinv[NV];
@@ -258,18 +345,18 @@ __global__ void __launch_bounds__(128, AGX_K1_WAVES) k_calc_qp_lj(const DevModel
       for (int i = 0; i < NV; ++i)
         if (i == l8) qdd = y[i];
     }
-    // gap f = xnext - xs[t+1]
-    if (wr) {
-      const double *xn = xp + NX;
-      qt[Q::f + l8] = qj + dt * vj + dt * dt * qdd - xn[l8];
-      qt[Q::f + NV + l8] = vj + dt * qdd - xn[NV + l8];
-    }
+    // gap f = xnext - xs[t+1]  (stored at the end: no load may queue behind a store)
+    gapq = qj + dt * vj + dt * dt * qdd - xnq;
+    gapv = vj + dt * qdd - xnv;
+#if defined(AGX_K1_STAGE) && AGX_K1_STAGE == 2
+    { if (wr) qt[l8] = gapq + gapv + Mc[0] + Mc[NV - 1]; return; }
+#endif
     // ---- pass B: accelerations with qdd, psi, composite force / momentum / E
     double a6[6];
 #pragma unroll
     for (int e = 0; e < 6; ++e) a6[e] = S[e] * qdd + Sd[e] * vj;
     g_prefix_sum<6>(a6, l8);
-    a6[0] -= m.gravity[0]; a6[1] -= m.gravity[1]; a6[2] -= m.gravity[2];
+    a6[0] -= grav[0]; a6[1] -= grav[1]; a6[2] -= grav[2];
     double psi[6];
     {
       double t1[6], t2[6];
@@ -332,10 +419,8 @@ __global__ void __launch_bounds__(128, AGX_K1_WAVES) k_calc_qp_lj(const DevModel
         colq[3 + e] = sxf[3 + e] + e2[e] + IcPs[3 + e];
       }
     }
-#pragma unroll
-    for (int e = 0; e < 6; ++e) { L.u.p1.Sd[l8][e] = Sd[e]; L.u.p1.psi[l8][e] = psi[e]; }
     L.Dt[l8][0] = Dt[0]; L.Dt[l8][1] = Dt[1]; L.Dt[l8][2] = Dt[2];
-    __syncthreads();
+    wave_lds_sync();
     // column l8 of dtau/dq (tqc) and dtau/dqdot (tvc)
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
@@ -352,32 +437,31 @@ __global__ void __launch_bounds__(128, AGX_K1_WAVES) k_calc_qp_lj(const DevModel
       tvc[i] = jl ? dvv : 0.0;
       tqc[i] = jl ? dqq : 0.0;
     }
-    __syncthreads();  // phase 1 storage is dead from here on
+    wave_lds_sync();  // phase 1 storage is dead from here on
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       L.u.p2.tq[i][l8] = tqc[i];
       L.u.p2.tv[i][l8] = tvc[i];
-      if (wr) { ax[A::tq + i * NV + l8] = tqc[i]; ax[A::tv + i * NV + l8] = tvc[i]; }
     }
+#if defined(AGX_K1_STAGE) && AGX_K1_STAGE == 3
+  { if (wr) qt[l8] = tqc[0] + tvc[NV - 1] + tqc[NV - 1] + tvc[0] + gapq; return; }
+#endif
   } else {
-    __syncthreads();
-    if (wr) {
-#pragma unroll
-      for (int i = 0; i < NV; ++i) { ax[A::M + i * NV + l8] = 0.0; ax[A::tq + i * NV + l8] = 0.0; ax[A::tv + i * NV + l8] = 0.0; }
-      qt[Q::f + l8] = 0.0;
-      qt[Q::f + NV + l8] = 0.0;
-    }
+    wave_lds_sync();
   }
 
   // ---- cost rows: lane j owns component j of state / control terms and column j of J'WJ
   double cost = 0.0, Lq = 0.0, Lv = 0.0, Lu = 0.0, Lvv = 0.0, Luu = 0.0, Lqqc[NV];
 #pragma unroll
   for (int i = 0; i < NV; ++i) Lqqc[i] = 0.0;
-  const double *ref = ref_at(rv, b, t, T);
-  const int *frames = frames_at(rv, b, t, T);
+  int fslot = 0;
   for (int r = 0; r < rows.n; ++r) {
+    const int kind0 = rows.kind[r];
+    const bool is_frame = kind0 == AGX_RES_FRAME_PLACEMENT || kind0 == AGX_RES_FRAME_TRANSLATION || kind0 == AGX_RES_FRAME_ROTATION;
+    const int my_slot = fslot;
+    if (is_frame) ++fslot;
     if (!rows.active[r]) continue;
-    const double *tile = ref + rows.off[r];
+    const double *tile = L.ref + rows.off[r];
     const double wi = tile[0];
     const double *rr = tile + 1;
     const double *aw = rr + rows.nref[r];
@@ -401,9 +485,9 @@ __global__ void __launch_bounds__(128, AGX_K1_WAVES) k_calc_qp_lj(const DevModel
         Luu += wu;
       }
     } else if (kind == AGX_RES_FRAME_PLACEMENT || kind == AGX_RES_FRAME_TRANSLATION || kind == AGX_RES_FRAME_ROTATION) {
-      int frame = frames ? frames[r] : -1;
-      if (frame < 0) frame = rows.frame[r];
-      const int jf = m.frame_parent[frame];
+      // staged frame data (first two frame rows), otherwise straight from the model
+      const double *fpl = L.frm[my_slot];  // host guarantees at most two frame rows
+      const int jf = L.fpar[my_slot];
       double RF[9], pF[3];
       if (jf >= 0) {
         double Rp[9], pp[3];
@@ -411,15 +495,15 @@ __global__ void __launch_bounds__(128, AGX_K1_WAVES) k_calc_qp_lj(const DevModel
         for (int e = 0; e < 9; ++e) Rp[e] = g_bc(R[e], jf);
 #pragma unroll
         for (int e = 0; e < 3; ++e) pp[e] = g_bc(p[e], jf);
-        mm3(Rp, m.frame_placement[frame], RF);
+        mm3(Rp, fpl, RF);
         double tt[3];
-        mv3(Rp, &m.frame_placement[frame][9], tt);
+        mv3(Rp, fpl + 9, tt);
         pF[0] = pp[0] + tt[0]; pF[1] = pp[1] + tt[1]; pF[2] = pp[2] + tt[2];
       } else {
 #pragma unroll
-        for (int e = 0; e < 9; ++e) RF[e] = m.frame_placement[frame][e];
+        for (int e = 0; e < 9; ++e) RF[e] = fpl[e];
 #pragma unroll
-        for (int e = 0; e < 3; ++e) pF[e] = m.frame_placement[frame][9 + e];
+        for (int e = 0; e < 3; ++e) pF[e] = fpl[9 + e];
       }
       const bool on = jl && (l8 <= jf);
       double res[6], Jc[6];
@@ -467,10 +551,10 @@ __global__ void __launch_bounds__(128, AGX_K1_WAVES) k_calc_qp_lj(const DevModel
         if (!on) Jc[e] = 0.0;
       }
       if (l8 == 0) cost += a;
-      __syncthreads();  // previous users of the J tile are done
+      wave_lds_sync();  // previous users of the J tile are done
 #pragma unroll
       for (int e = 0; e < 6; ++e) L.u.p2.J[l8][e] = Jc[e];
-      __syncthreads();
+      wave_lds_sync();
 #pragma unroll
       for (int e = 0; e < 6; ++e) Lq += we[e] * res[e] * Jc[e];
 #pragma unroll
@@ -483,13 +567,16 @@ __global__ void __launch_bounds__(128, AGX_K1_WAVES) k_calc_qp_lj(const DevModel
     }
   }
   const double sc = TERM ? 1.0 : dt;
+#if defined(AGX_K1_STAGE) && AGX_K1_STAGE == 4
+  { if (wr) qt[l8] = cost + Lq + Lv + Lu + Lqqc[0] + Lqqc[NV - 1] + tqc[0] + tvc[1] + Mc[2] + gapq; return; }
+#endif
   cost = g_sum(cost) * sc;
-  if (act && l8 == 0) qt[Q::cost] = cost;
+  if (act && l8 == 0) K1ST(qt[Q::cost], cost);
   // ---- QP transformation, column l8 of every block
   const double lu = sc * Lu, D = sc * Luu + preg;
   L.vec[1][l8] = jl ? lu : 0.0;
   L.vec[2][l8] = jl ? D : 0.0;
-  __syncthreads();
+  wave_lds_sync();
   double gw = 0.0, gq = sc * Lq, gv = sc * Lv;
   double DMc[NV], Dtq[NV], Dtv[NV];
 #pragma unroll
@@ -502,13 +589,23 @@ __global__ void __launch_bounds__(128, AGX_K1_WAVES) k_calc_qp_lj(const DevModel
     Dtq[l] = Dl * tqc[l];
     Dtv[l] = Dl * tvc[l];
   }
+  if (act) {  // all 8 lanes store: every block row is one whole 64-byte line (lane NV.. writes the zero padding)
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      K1ST(ax[A::M + i * A::LD + l8], jl ? Mc[i] : 0.0);
+      K1ST(ax[A::tq + i * A::LD + l8], jl ? tqc[i] : 0.0);
+      K1ST(ax[A::tv + i * A::LD + l8], jl ? tvc[i] : 0.0);
+    }
+  }
   if (wr) {
-    qt[Q::gw + l8] = TERM ? 0.0 : gw;
-    qt[Q::gx + l8] = gq;
-    qt[Q::gx + NV + l8] = gv;
-    ax[A::Lvv + l8] = sc * Lvv;
-    ax[A::Luu + l8] = sc * Luu;
-    ax[A::Lu + l8] = lu;
+    K1ST(qt[Q::f + l8], gapq);
+    K1ST(qt[Q::f + NV + l8], gapv);
+    K1ST(qt[Q::gw + l8], TERM ? 0.0 : gw);
+    K1ST(qt[Q::gx + l8], gq);
+    K1ST(qt[Q::gx + NV + l8], gv);
+    K1ST(ax[A::Lvv + l8], sc * Lvv);
+    K1ST(ax[A::Luu + l8], sc * Luu);
+    K1ST(ax[A::Lu + l8], lu);
   }
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
@@ -525,16 +622,19 @@ __global__ void __launch_bounds__(128, AGX_K1_WAVES) k_calc_qp_lj(const DevModel
         hvv += tvli * Dtv[l];
       }
     }
-    if (wr) {
-      qt[Q::Hww + i * NV + l8] = hww;
-      qt[Q::Hqw + i * NV + l8] = hqw;
-      qt[Q::Hvw + i * NV + l8] = hvw;
-      qt[Q::Hqq + i * NV + l8] = hqq;
-      qt[Q::Hqv + i * NV + l8] = hqv;
-      qt[Q::Hvv + i * NV + l8] = hvv;
-      ax[A::Lqq + i * NV + l8] = sc * Lqqc[i];
+    if (act) {
+      K1ST(qt[Q::Hww + i * Q::LD + l8], jl ? hww : 0.0);
+      K1ST(qt[Q::Hqw + i * Q::LD + l8], jl ? hqw : 0.0);
+      K1ST(qt[Q::Hvw + i * Q::LD + l8], jl ? hvw : 0.0);
+      K1ST(qt[Q::Hqq + i * Q::LD + l8], jl ? hqq : 0.0);
+      K1ST(qt[Q::Hqv + i * Q::LD + l8], jl ? hqv : 0.0);
+      K1ST(qt[Q::Hvv + i * Q::LD + l8], jl ? hvv : 0.0);
+      K1ST(ax[A::Lqq + i * A::LD + l8], jl ? sc * Lqqc[i] : 0.0);
     }
   }
+#ifdef AGX_K1_NOSTORE
+  if (wr) qt[l8] = chk;
+#endif
 }
 
 }  // namespace agx

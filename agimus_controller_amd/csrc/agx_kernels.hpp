@@ -203,16 +203,19 @@ __global__ void __launch_bounds__(64) k_calc_diff_term(const DevModel *__restric
 // QP tile (QT):  Hqq | Hqv | Hvv | Hqw | Hvw | Hww (NV x NV each) | gx (NX) | gw (NV) | f (NX) | cost
 // aux tile (AUX): M | tauq | tauv | Lqq (NV x NV each) | Lvv | Luu | Lu (NV each)
 // ---------------------------------------------------------------------------
+// Every NV x NV block is stored with a row stride of LD = 8 doubles: a row is one aligned 64-byte
+// line, so the column-per-lane kernels write whole lines and the 8 x 8 lane grid of the Riccati
+// kernel reads element [r][c] of a block at offset 8 r + c = its own lane id (one 512-byte load).
 template <int NV>
 struct QT {
-  static constexpr int NX = 2 * NV, B2 = NV * NV;
-  static constexpr int Hqq = 0, Hqv = B2, Hvv = 2 * B2, Hqw = 3 * B2, Hvw = 4 * B2, Hww = 5 * B2, gx = 6 * B2, gw = gx + NX,
-                       f = gw + NV, cost = f + NX, SIZE = cost + 2;  // padded to an even count
+  static constexpr int NX = 2 * NV, LD = 8, B2 = NV * LD;
+  static constexpr int Hqq = 0, Hqv = B2, Hvv = 2 * B2, Hqw = 3 * B2, Hvw = 4 * B2, Hww = 5 * B2, gx = 6 * B2, gw = gx + 16,
+                       f = gw + 8, cost = f + 16, SIZE = cost + 8;
 };
 template <int NV>
 struct AUX {
-  static constexpr int B2 = NV * NV;
-  static constexpr int M = 0, tq = B2, tv = 2 * B2, Lqq = 3 * B2, Lvv = 4 * B2, Luu = Lvv + NV, Lu = Luu + NV, SIZE = Lu + NV + (NV & 1);
+  static constexpr int LD = 8, B2 = NV * LD;
+  static constexpr int M = 0, tq = B2, tv = 2 * B2, Lqq = 3 * B2, Lvv = 4 * B2, Luu = Lvv + 8, Lu = Luu + 8, SIZE = Lu + 8;
 };
 
 template <int NV, bool CHAIN>
@@ -250,7 +253,7 @@ __global__ void __launch_bounds__(64) k_calc_qp(const DevModel *__restrict__ mp,
 #pragma unroll
   for (int i = 0; i < NV; ++i)
 #pragma unroll
-    for (int j = 0; j < NV; ++j) { L[i][j] = M[i][j]; ax[A::M + i * NV + j] = M[i][j]; }
+    for (int j = 0; j < NV; ++j) { L[i][j] = M[i][j]; ax[A::M + i * A::LD + j] = M[i][j]; }
   spd_inverse<NV>(L, Minv);
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
@@ -308,15 +311,15 @@ __global__ void __launch_bounds__(64) k_calc_qp(const DevModel *__restrict__ mp,
         hqv += tq[l][i] * dtv;
         hvv += tv[l][i] * dtv;
       }
-      qt[Q::Hww + i * NV + j] = hww;
-      qt[Q::Hqw + i * NV + j] = hqw;
-      qt[Q::Hvw + i * NV + j] = hvw;
-      qt[Q::Hqq + i * NV + j] = hqq;
-      qt[Q::Hqv + i * NV + j] = hqv;
-      qt[Q::Hvv + i * NV + j] = hvv;
-      ax[A::tq + i * NV + j] = tq[i][j];
-      ax[A::tv + i * NV + j] = tv[i][j];
-      ax[A::Lqq + i * NV + j] = dt * c.Lqq[i][j];
+      qt[Q::Hww + i * Q::LD + j] = hww;
+      qt[Q::Hqw + i * Q::LD + j] = hqw;
+      qt[Q::Hvw + i * Q::LD + j] = hvw;
+      qt[Q::Hqq + i * Q::LD + j] = hqq;
+      qt[Q::Hqv + i * Q::LD + j] = hqv;
+      qt[Q::Hvv + i * Q::LD + j] = hvv;
+      ax[A::tq + i * A::LD + j] = tq[i][j];
+      ax[A::tv + i * A::LD + j] = tv[i][j];
+      ax[A::Lqq + i * A::LD + j] = dt * c.Lqq[i][j];
     }
   }
 }
@@ -357,16 +360,16 @@ __global__ void __launch_bounds__(64) k_calc_qp_term(const DevModel *__restrict_
     ax[A::Lu + i] = 0.0;
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
-      qt[Q::Hqq + i * NV + j] = c.Lqq[i][j];
-      qt[Q::Hqv + i * NV + j] = 0.0;
-      qt[Q::Hvv + i * NV + j] = (i == j) ? c.Lvv[i] : 0.0;
-      qt[Q::Hqw + i * NV + j] = 0.0;
-      qt[Q::Hvw + i * NV + j] = 0.0;
-      qt[Q::Hww + i * NV + j] = 0.0;
-      ax[A::M + i * NV + j] = 0.0;
-      ax[A::tq + i * NV + j] = 0.0;
-      ax[A::tv + i * NV + j] = 0.0;
-      ax[A::Lqq + i * NV + j] = c.Lqq[i][j];
+      qt[Q::Hqq + i * Q::LD + j] = c.Lqq[i][j];
+      qt[Q::Hqv + i * Q::LD + j] = 0.0;
+      qt[Q::Hvv + i * Q::LD + j] = (i == j) ? c.Lvv[i] : 0.0;
+      qt[Q::Hqw + i * Q::LD + j] = 0.0;
+      qt[Q::Hvw + i * Q::LD + j] = 0.0;
+      qt[Q::Hww + i * Q::LD + j] = 0.0;
+      ax[A::M + i * A::LD + j] = 0.0;
+      ax[A::tq + i * A::LD + j] = 0.0;
+      ax[A::tv + i * A::LD + j] = 0.0;
+      ax[A::Lqq + i * A::LD + j] = c.Lqq[i][j];
     }
   }
 }
@@ -427,7 +430,7 @@ __global__ void __launch_bounds__(64) k_riccati(const DevOcp *__restrict__ op, c
   double *Kw = Kws + (long long)b * T * NV * NX, *kw = kws + (long long)b * T * NV;
   const int r = lane >> 3, c = lane & 7;
   const bool in = (r < NV) && (c < NV);
-  const int rc = in ? r * NV + c : 0, cr = in ? c * NV + r : 0;  // [r][c] and [c][r] of an NV x NV block
+  const int rc = in ? r * Q::LD + c : 0, cr = in ? c * Q::LD + r : 0;  // [r][c] and [c][r] of a block
   const int rr = r < NV ? r : 0, cc = c < NV ? c : 0;
   const double diag = (r == c) ? 1.0 : 0.0;
   const int row_base = lane & 56, col_lane = c;
@@ -602,7 +605,7 @@ __global__ void __launch_bounds__(128) k_step(const DevModel *__restrict__ mp, c
       for (int i = 0; i < NV; ++i) {
         double du = 0.0;
 #pragma unroll
-        for (int j = 0; j < NV; ++j) du += ax[A::M + i * NV + j] * w[j] + ax[A::tq + i * NV + j] * dx[j] + ax[A::tv + i * NV + j] * dx[NV + j];
+        for (int j = 0; j < NV; ++j) du += ax[A::M + i * A::LD + j] * w[j] + ax[A::tq + i * A::LD + j] * dx[j] + ax[A::tv + i * A::LD + j] * dx[NV + j];
         DU[(long long)t * NU + i] = du;
         // Lu + Fu' lam' = -(Lxu' dx + (Luu + preg) du)
         kkt = fmax(kkt, fabs((ax[A::Luu + i] + preg) * du));
@@ -620,7 +623,7 @@ __global__ void __launch_bounds__(128) k_step(const DevModel *__restrict__ mp, c
       for (int i = 0; i < NV; ++i) {
         double hq = dreg * dx[i];
 #pragma unroll
-        for (int j = 0; j < NV; ++j) hq += ax[A::Lqq + i * NV + j] * dx[j];
+        for (int j = 0; j < NV; ++j) hq += ax[A::Lqq + i * A::LD + j] * dx[j];
         kkt = fmax(kkt, fabs(hq));
         kkt = fmax(kkt, fabs((ax[A::Lvv + i] + dreg) * dx[NV + i]));
       }
@@ -731,89 +734,100 @@ __global__ void __launch_bounds__(128) k_step(const DevModel *__restrict__ mp, c
 // last direction.  k_sigma_tile rewrites the QP tiles in place with the sigma terms, k_riccati
 // (backward only) gives Kw, k_gains_to_u maps them to u-space: K = M Kw - taux.
 // ---------------------------------------------------------------------------
+// 8 lanes per node, lane j computes column j of every block (M, tq, tv staged through LDS).
 template <int NV>
-__global__ void k_sigma_tile(const DevOcp *__restrict__ op, double *__restrict__ qts, const double *__restrict__ auxs,
-                             const double *__restrict__ dxs, const double *__restrict__ dus) {
-  constexpr int NX = 2 * NV;
+__global__ void __launch_bounds__(128) k_sigma_tile(const DevOcp *__restrict__ op, double *__restrict__ qts,
+                                                    const double *__restrict__ auxs, const double *__restrict__ dxs,
+                                                    const double *__restrict__ dus) {
+  constexpr int NX = 2 * NV, LD = 8, B2 = NV * LD;
   typedef QT<NV> Q;
   typedef AUX<NV> A;
+  __shared__ double lds[16][3 * B2 + 2];
   const DevOcp &o = *op;
   const int T = o.T;
-  const long long unit = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (unit >= (long long)o.B * (T + 1)) return;
+  const int l8 = threadIdx.x & 7, g = threadIdx.x >> 3;
+  const long long n_nodes = (long long)o.B * (T + 1);
+  const long long node = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 3;
+  const bool ok = node < n_nodes;
+  const long long unit = ok ? node : 0;
   const int b = (int)(unit / (T + 1)), t = (int)(unit % (T + 1));
   double *qt = qts + unit * Q::SIZE;
   const double *ax = auxs + unit * A::SIZE;
   const double *dx = dxs + unit * NX;
   const double sig = kSigma;  // (preg is already folded into the tile by k_calc_qp)
-#pragma unroll
-  for (int i = 0; i < NV; ++i) {
-    qt[Q::Hqq + i * NV + i] += sig;
-    qt[Q::Hvv + i * NV + i] += sig;
-    qt[Q::gx + i] -= sig * dx[i];
-    qt[Q::gx + NV + i] -= sig * dx[NV + i];
+  const bool jl = l8 < NV, wr = ok && jl;
+  const int j = jl ? l8 : 0;
+  // stage M | tq | tv (contiguous in the aux tile)
+  double *sh = lds[g];
+  for (int e = l8; e < 3 * B2; e += 8) sh[e] = ax[A::M + e];
+  __syncthreads();
+  if (wr) {
+    qt[Q::Hqq + j * Q::LD + j] += sig;
+    qt[Q::Hvv + j * Q::LD + j] += sig;
   }
-  if (t == T) return;
-  const double *du = dus + ((long long)b * T + t) * NV;
-  double Mm[NV][NV], tq[NV][NV], tv[NV][NV];
+  double gq = dx[j], gv = dx[NV + j], gwv = 0.0;
+  if (t < T) {
+    const double *du = dus + ((long long)b * T + t) * NV;
+    const double *Mm = sh, *tq = sh + B2, *tv = sh + 2 * B2;
+    double Mc[NV], tqc[NV], tvc[NV];
 #pragma unroll
-  for (int i = 0; i < NV; ++i)
+    for (int l = 0; l < NV; ++l) {
+      Mc[l] = Mm[l * LD + j]; tqc[l] = tq[l * LD + j]; tvc[l] = tv[l * LD + j];
+      const double dul = du[l];
+      gwv += Mc[l] * dul; gq += tqc[l] * dul; gv += tvc[l] * dul;
+    }
 #pragma unroll
-    for (int j = 0; j < NV; ++j) { Mm[i][j] = ax[A::M + i * NV + j]; tq[i][j] = ax[A::tq + i * NV + j]; tv[i][j] = ax[A::tv + i * NV + j]; }
-#pragma unroll
-  for (int i = 0; i < NV; ++i) {
-    double gwi = 0.0, gq = 0.0, gv = 0.0;
-#pragma unroll
-    for (int l = 0; l < NV; ++l) { gwi += Mm[i][l] * du[l]; gq += tq[l][i] * du[l]; gv += tv[l][i] * du[l]; }
-    qt[Q::gw + i] -= sig * gwi;
-    qt[Q::gx + i] -= sig * gq;
-    qt[Q::gx + NV + i] -= sig * gv;
-#pragma unroll
-    for (int j = 0; j < NV; ++j) {
+    for (int i = 0; i < NV; ++i) {
       double hww = 0.0, hqw = 0.0, hvw = 0.0, hqq = 0.0, hqv = 0.0, hvv = 0.0;
 #pragma unroll
       for (int l = 0; l < NV; ++l) {
-        hww += Mm[i][l] * Mm[l][j];
-        hqw += tq[l][i] * Mm[l][j];
-        hvw += tv[l][i] * Mm[l][j];
-        hqq += tq[l][i] * tq[l][j];
-        hqv += tq[l][i] * tv[l][j];
-        hvv += tv[l][i] * tv[l][j];
+        const double Mil = Mm[i * LD + l], tqli = tq[l * LD + i], tvli = tv[l * LD + i];
+        hww += Mil * Mc[l]; hqw += tqli * Mc[l]; hvw += tvli * Mc[l];
+        hqq += tqli * tqc[l]; hqv += tqli * tvc[l]; hvv += tvli * tvc[l];
       }
-      qt[Q::Hww + i * NV + j] += sig * hww;
-      qt[Q::Hqw + i * NV + j] += sig * hqw;
-      qt[Q::Hvw + i * NV + j] += sig * hvw;
-      qt[Q::Hqq + i * NV + j] += sig * hqq;
-      qt[Q::Hqv + i * NV + j] += sig * hqv;
-      qt[Q::Hvv + i * NV + j] += sig * hvv;
+      if (wr) {
+        qt[Q::Hww + i * Q::LD + j] += sig * hww;
+        qt[Q::Hqw + i * Q::LD + j] += sig * hqw;
+        qt[Q::Hvw + i * Q::LD + j] += sig * hvw;
+        qt[Q::Hqq + i * Q::LD + j] += sig * hqq;
+        qt[Q::Hqv + i * Q::LD + j] += sig * hqv;
+        qt[Q::Hvv + i * Q::LD + j] += sig * hvv;
+      }
     }
+  }
+  if (wr) {
+    qt[Q::gw + j] -= sig * gwv;
+    qt[Q::gx + j] -= sig * gq;
+    qt[Q::gx + NV + j] -= sig * gv;
   }
 }
 
+// K = M Kw - taux: one lane per (node, column of K)
 template <int NV>
-__global__ void k_gains_to_u(const DevOcp *__restrict__ op, const double *__restrict__ auxs, const double *__restrict__ Kws,
-                             double *__restrict__ Kout) {
+__global__ void __launch_bounds__(256) k_gains_to_u(const DevOcp *__restrict__ op, const double *__restrict__ auxs,
+                                                    const double *__restrict__ Kws, double *__restrict__ Kout) {
   constexpr int NX = 2 * NV;
   typedef AUX<NV> A;
   const DevOcp &o = *op;
   const int T = o.T;
   const long long unit = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (unit >= (long long)o.B * T * NV) return;
-  const int i = (int)(unit % NV);
-  const long long node = unit / NV;  // b*T + t
+  const long long node = unit >> 4;  // 16 lanes per node, NX <= 16 of them active
+  const int j = (int)(unit & 15);
+  if (node >= (long long)o.B * T || j >= NX) return;
   const int b = (int)(node / T), t = (int)(node % T);
   const double *ax = auxs + ((long long)b * (T + 1) + t) * A::SIZE;
   const double *Kw = Kws + node * NV * NX;
-  double *K = Kout + node * NV * NX + (long long)i * NX;
-  double Mi[NV];
+  double *K = Kout + node * NV * NX;
+  const double *tx = (j < NV) ? ax + A::tq + j : ax + A::tv + (j - NV);
+  double kc[NV];
 #pragma unroll
-  for (int l = 0; l < NV; ++l) Mi[l] = ax[A::M + i * NV + l];
+  for (int l = 0; l < NV; ++l) kc[l] = Kw[l * NX + j];
 #pragma unroll
-  for (int j = 0; j < NX; ++j) {
-    double acc = (j < NV) ? -ax[A::tq + i * NV + j] : -ax[A::tv + i * NV + (j - NV)];
+  for (int i = 0; i < NV; ++i) {
+    double acc = -tx[i * A::LD];
 #pragma unroll
-    for (int l = 0; l < NV; ++l) acc += Mi[l] * Kw[l * NX + j];
-    K[j] = acc;
+    for (int l = 0; l < NV; ++l) acc += ax[A::M + i * A::LD + l] * kc[l];
+    K[i * NX + j] = acc;
   }
 }
 
