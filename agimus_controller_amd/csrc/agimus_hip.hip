@@ -48,7 +48,7 @@ struct agx_ocp {
   DevOcp *d_ocp = nullptr;
   double *d_dt = nullptr, *d_xs = nullptr, *d_us = nullptr, *d_x0 = nullptr, *d_tiles = nullptr;
   double *d_Kws = nullptr, *d_kws = nullptr, *d_Kout = nullptr, *d_dx = nullptr, *d_du = nullptr;
-  double *d_qt = nullptr, *d_aux = nullptr, *d_w = nullptr;  // QP tiles, aux tiles, acceleration steps
+  double *d_qt = nullptr, *d_aux = nullptr, *d_w = nullptr, *d_nodestat = nullptr;  // QP tiles, aux tiles, acceleration steps
   int qt_size = 0, aux_size = 0;
   bool k1_lanes = true;  // AGX_K1_LANES=0 selects the one-lane-per-node derivative kernel
   bool lanes_ok = true;  // problem fits the LDS staging of the 8-lanes-per-node kernel
@@ -174,8 +174,9 @@ int launch_calc_qp(agx_ocp *o, bool running_only = false) {
 int launch_riccati(agx_ocp *o, int forward, int gains_pass) {
   return dispatch(o->nv, o->chain, [&](auto NVc, auto CHc) -> int {
     constexpr int NV = decltype(NVc)::value;
-    hipLaunchKernelGGL((agx::k_riccati<NV>), dim3(o->B), dim3(64), 0, o->stream, o->d_ocp, o->d_dt, o->d_qt, o->d_Kws, o->d_kws,
-                       o->d_dx, o->d_w, o->d_state, forward, gains_pass);
+    (void)gains_pass;
+    hipLaunchKernelGGL((agx::k_riccati<NV, false>), dim3(o->B), dim3(64), 0, o->stream, o->d_ocp, o->d_dt, o->d_qt, o->d_aux, o->d_Kws,
+                       o->d_kws, o->d_dx, o->d_w, o->d_du, o->d_Kout, o->d_state, forward);
     HIPCHK(hipGetLastError());
     return 0;
   });
@@ -186,25 +187,22 @@ int launch_step(agx_ocp *o, int iter, int max_iter, int mode) {
   return dispatch(o->nv, o->chain, [&](auto NVc, auto CHc) -> int {
     constexpr int NV = decltype(NVc)::value;
     constexpr bool CH = decltype(CHc)::value;
+    const long long nodes = (long long)o->B * (o->T + 1);
+    hipLaunchKernelGGL((agx::k_node_kkt<NV>), dim3((int)((nodes * 8 + 255) / 256)), dim3(256), 0, o->stream, o->d_ocp, o->d_qt, o->d_aux,
+                       o->d_dx, o->d_w, o->d_du, o->d_nodestat, o->d_state);
     hipLaunchKernelGGL((agx::k_step<NV, CH>), dim3(o->B), dim3(128), 0, o->stream, o->d_model, o->d_ocp, o->d_dt, o->d_xs, o->d_us,
-                       o->rv, o->d_qt, o->d_aux, o->d_dx, o->d_w, o->d_du, o->d_state, iter, max_iter, mode, o->d_ndone);
+                       o->rv, o->d_qt, o->d_aux, o->d_dx, o->d_nodestat, o->d_du, o->d_state, iter, max_iter, mode, o->d_ndone);
     HIPCHK(hipGetLastError());
     return 0;
   });
 }
 
-// exit path: sigma tiles -> Riccati backward -> gains in u-space
+// exit path: the sigma (proximal) Riccati sweep that yields the gains the solver reports, one kernel
 int launch_gains(agx_ocp *o) {
   return dispatch(o->nv, o->chain, [&](auto NVc, auto CHc) -> int {
     constexpr int NV = decltype(NVc)::value;
-    const long long nodes = (long long)o->B * (o->T + 1);
-    hipLaunchKernelGGL((agx::k_sigma_tile<NV>), dim3((int)((nodes * 8 + 127) / 128)), dim3(128), 0, o->stream, o->d_ocp, o->d_qt, o->d_aux,
-                       o->d_dx, o->d_du);
-    hipLaunchKernelGGL((agx::k_riccati<NV>), dim3(o->B), dim3(64), 0, o->stream, o->d_ocp, o->d_dt, o->d_qt, o->d_Kws, o->d_kws,
-                       o->d_dx, o->d_w, o->d_state, 0, 1);
-    const long long rows = (long long)o->B * o->T * 16;
-    hipLaunchKernelGGL((agx::k_gains_to_u<NV>), dim3((int)((rows + 255) / 256)), dim3(256), 0, o->stream, o->d_ocp, o->d_aux, o->d_Kws,
-                       o->d_Kout);
+    hipLaunchKernelGGL((agx::k_riccati<NV, true>), dim3(o->B), dim3(64), 0, o->stream, o->d_ocp, o->d_dt, o->d_qt, o->d_aux, o->d_Kws,
+                       o->d_kws, o->d_dx, o->d_w, o->d_du, o->d_Kout, o->d_state, 0);
     HIPCHK(hipGetLastError());
     return 0;
   });
@@ -388,6 +386,7 @@ int agx_ocp_create(const agx_model *m, const agx_ocp_desc *d, int batch, int dev
   ALLOC(o->d_dx, B * (T + 1) * nx);
   ALLOC(o->d_du, B * T * nu);
   ALLOC(o->d_w, B * T * nu);
+  ALLOC(o->d_nodestat, B * (T + 1) * 4);
   ALLOC(o->d_qt, B * (T + 1) * (size_t)o->qt_size);
   ALLOC(o->d_aux, B * (T + 1) * (size_t)o->aux_size);
   ALLOC(o->d_ref, B * (T + 1) * (size_t)o->stride);
@@ -421,7 +420,7 @@ void agx_ocp_destroy(agx_ocp *o) {
   (void)hipSetDevice(o->device);
   if (o->stream) (void)hipStreamSynchronize(o->stream);
   void *ptrs[] = {o->d_model, o->d_ocp, o->d_dt, o->d_xs, o->d_us, o->d_x0, o->d_tiles, o->d_Kws, o->d_kws, o->d_Kout, o->d_dx,
-                  o->d_du, o->d_ref, o->d_frames, o->d_state, o->d_ndone, o->d_scratch, o->d_traj, o->d_pts, o->d_sine, o->d_qt, o->d_aux, o->d_w};
+                  o->d_du, o->d_ref, o->d_frames, o->d_state, o->d_ndone, o->d_scratch, o->d_traj, o->d_pts, o->d_sine, o->d_qt, o->d_aux, o->d_w, o->d_nodestat};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
   if (o->h_ndone) (void)hipHostFree(o->h_ndone);
@@ -697,7 +696,7 @@ int agx_ocp_time_kernel(agx_ocp *o, int which, int reps, double *avg_ms) {
   if (set_device(o)) return -1;
   // state for the timed kernel: fresh solver state, QP tiles and a direction at the resident point
   if (reset_state(o)) return -1;
-  if (which == 1 || which == 2) { if (launch_calc_qp(o)) return -1; }
+  if (which == 1 || which == 2 || which == 5 || which == 6) { if (launch_calc_qp(o)) return -1; }
   if (which == 2) { if (launch_riccati(o, 1, 0)) return -1; }
   // warm-up launch, then `reps` timed launches bracketed by events on the problem's stream
   for (int pass = 0; pass < 2; ++pass) {
@@ -710,6 +709,8 @@ int agx_ocp_time_kernel(agx_ocp *o, int which, int reps, double *avg_ms) {
       else if (which == 2) rc = launch_step(o, 0, 1 << 30, 1 | 4);
       else if (which == 3) rc = launch_calc_qp(o, true);
       else if (which == 4) rc = launch_calc_diff(o, false, true);
+      else if (which == 5) rc = launch_riccati(o, 0, 0);
+      else if (which == 6) rc = launch_gains(o);
       else return fail("agx_ocp_time_kernel: unknown kernel");
       if (rc) return rc;
     }

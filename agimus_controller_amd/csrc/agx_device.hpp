@@ -51,6 +51,37 @@ struct DevOcp {
 
 namespace agx {
 
+// ------------------------------------------------------------------ DPP helpers (8-lane groups)
+// Cross-lane moves on the VALU (no LDS traffic).  A DPP row is 16 lanes = two 8-lane groups.
+template <int CTRL, int BANK = 0xf>
+__device__ __forceinline__ int dpp_i32(int old, int x) { return __builtin_amdgcn_update_dpp(old, x, CTRL, 0xf, BANK, false); }
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov(double x) {
+  const int lo = __double2loint(x), hi = __double2hiint(x);
+  return __hiloint2double(__builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, true), __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ double dpp_xor1(double x) { return dpp_mov<0xB1>(x); }  // quad_perm [1,0,3,2]
+__device__ __forceinline__ double dpp_xor2(double x) { return dpp_mov<0x4E>(x); }  // quad_perm [2,3,0,1]
+__device__ __forceinline__ double dpp_xor4(double x) {                            // lanes 0-3 <-> 4-7 of each group
+  const int lo = __double2loint(x), hi = __double2hiint(x);
+  int l2 = dpp_i32<0x104, 0x5>(0, lo);  // row_shl:4 into banks 0, 2
+  l2 = dpp_i32<0x114, 0xa>(l2, lo);     // row_shr:4 into banks 1, 3
+  int h2 = dpp_i32<0x104, 0x5>(0, hi);
+  h2 = dpp_i32<0x114, 0xa>(h2, hi);
+  return __hiloint2double(h2, l2);
+}
+// Every lane of an 8-lane group holds 8 partial sums p[0..7] (one per row); afterwards lane l
+// holds the group total of row l.  Butterfly with 4 + 2 + 1 exchanges instead of 8 x 3.
+__device__ __forceinline__ double transpose_reduce8(const double *p, int l8) {
+  const bool b4 = l8 & 4, b2 = l8 & 2, b1 = l8 & 1;
+  double k4[4], k2[2];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) k4[k] = (b4 ? p[k + 4] : p[k]) + dpp_xor4(b4 ? p[k] : p[k + 4]);
+#pragma unroll
+  for (int k = 0; k < 2; ++k) k2[k] = (b2 ? k4[k + 2] : k4[k]) + dpp_xor2(b2 ? k4[k] : k4[k + 2]);
+  return (b1 ? k2[1] : k2[0]) + dpp_xor1(b1 ? k2[0] : k2[1]);
+}
+
 // ------------------------------------------------------------------ 3-vectors
 AGX_DEV void cross3(const double *a, const double *b, double *c) {
   double c0 = a[1] * b[2] - a[2] * b[1];

@@ -27,13 +27,6 @@ namespace agx {
 // groups; values that cross from one group into the next land only in lanes the callers mask out
 // (l8 < off for shift-up, l8 + off >= 8 for shift-down).  The LDS pipe of the CU is the scarce
 // resource of this kernel -- ds_bpermute-based __shfl would put ~400 more instructions on it.
-template <int CTRL>
-__device__ __forceinline__ double dpp_mov(double x) {
-  const int lo = __double2loint(x), hi = __double2hiint(x);
-  const int lo2 = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, true);
-  const int hi2 = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, true);
-  return __hiloint2double(hi2, lo2);
-}
 template <int OFF>
 __device__ __forceinline__ double g_up(double x) { return dpp_mov<0x110 + OFF>(x); }  // row_shr:OFF -> lane i reads lane i-OFF
 template <int OFF>
@@ -73,6 +66,16 @@ __device__ __forceinline__ void g_suffix_sum(double *x, int l8) {
   g_suffix_step<N, 2>(x, l8);
   g_suffix_step<N, 4>(x, l8);
 }
+// Two block rows at once as 16-byte stores: neighbouring lanes (columns c, c+1) swap one value so
+// that the even lane owns [i][c..c+1] and the odd lane [i+1][c-1..c]: half as many store
+// instructions, each lane writes an aligned double2, every row is still a whole 64-byte line.
+__device__ __forceinline__ void store_row_pair(double *blk, int i, int l8, double a, double b) {
+  const bool even = !(l8 & 1);
+  const double y = dpp_mov<0xB1>(even ? b : a);  // quad_perm [1,0,3,2]: swap with the neighbour lane
+  const double2 v = even ? make_double2(a, y) : make_double2(y, b);
+  *reinterpret_cast<double2 *>(blk + (even ? i : i + 1) * 8 + (l8 & 6)) = v;
+}
+
 // LDS hand-off between lanes of ONE wave: DS operations of a wave execute in order, so only the
 // compiler has to be kept from reordering / caching across the hand-off (no s_barrier, and no
 // wait for the global stores a workgroup barrier would drag in).
@@ -90,19 +93,21 @@ __device__ __forceinline__ double g_sum(double x) {
 
 // per-node LDS tile (doubles).  Phase 1 (dynamics): S, m6, Sd, psi, Dt.  Phase 2 (after the
 // derivative matrices exist) reuses the same storage for tq, tv and the frame Jacobian J.
-constexpr int kLjRef = 96;  // reference-tile doubles staged in LDS per node (larger tiles are read from HBM)
+constexpr int kLjRef = 64;  // reference-tile doubles staged in LDS per node (larger tiles use the one-lane-per-node kernel)
+// Per-node LDS tile.  The kernel runs in three phases that reuse the same storage:
+//   c  (costs):      the node's reference tile, the frames its cost rows use, the frame Jacobian J
+//   d1 (dynamics):   S, m6 = Ic S, Dt of every joint (the all-to-all operands of CRBA / RNEA derivatives)
+//   d2 (transform):  the full dtau/dq, dtau/dqdot matrices
 struct LjNode {
   union {
-    struct { double S[8][6], m6[8][6]; } p1;
-    struct { double tq[8][8], tv[8][8], J[8][6]; } p2;
+    struct { double ref[kLjRef], frm[2][14], J[8][6]; } c;
+    struct { double S[8][6], m6[8][6], Dt[8][4]; } d1;
+    struct { double tq[8][8], tv[8][8]; } d2;
   } u;
-  double Dt[8][4];
   double M[8][8];
-  double vec[3][8];    // rhs / lu / D
-  double ref[kLjRef];  // the node's reference tile, staged once at kernel start
-  double frm[2][14];   // placement (12) of up to two frames used by the cost rows
-  int fpar[4];         // their parent joints, frame ids
-  double pad[2];       // odd multiple of 2 doubles: spreads the 8 nodes of a wave over the banks
+  double vec[3][8];  // rhs / lu / D
+  int fpar[4];       // parent joints of the staged frames
+  double pad[2];     // keeps the node stride an odd multiple of 2 doubles (bank spread over the 8 nodes of a wave)
 };
 // joint constants of the model, staged once per wave: placement 12 | axis 3 | com 3 | inertia 9 | mass | armature
 struct LjModel {
@@ -164,7 +169,7 @@ __global__ void __launch_bounds__(64, AGX_K1_WAVES) k_calc_qp_lj(const DevModel 
       d[27] = m.mass[jj];
       d[28] = m.armature[jj];
     }
-    for (int e = l8; e < o.stride; e += 8) L.ref[e] = gref[e];  // host guarantees stride <= kLjRef
+    for (int e = l8; e < o.stride; e += 8) L.u.c.ref[e] = gref[e];  // host guarantees stride <= kLjRef
     // frames of the (up to two) frame-based cost rows
     int slot = 0;
     for (int r = 0; r < rows.n && slot < 2; ++r) {
@@ -172,7 +177,7 @@ __global__ void __launch_bounds__(64, AGX_K1_WAVES) k_calc_qp_lj(const DevModel 
       if (kind != AGX_RES_FRAME_PLACEMENT && kind != AGX_RES_FRAME_TRANSLATION && kind != AGX_RES_FRAME_ROTATION) continue;
       int frame = gframes ? gframes[r] : -1;
       if (frame < 0) frame = rows.frame[r];
-      for (int e = l8; e < 12; e += 8) L.frm[slot][e] = m.frame_placement[frame][e];
+      for (int e = l8; e < 12; e += 8) L.u.c.frm[slot][e] = m.frame_placement[frame][e];
       if (l8 == 0) { L.fpar[slot] = m.frame_parent[frame]; L.fpar[2 + slot] = r; }
       ++slot;
     }
@@ -229,6 +234,124 @@ __global__ void __launch_bounds__(64, AGX_K1_WAVES) k_calc_qp_lj(const DevModel 
       for (int e = 0; e < 6; ++e) S[e] = 0.0;
     }
   }
+  // ---- cost rows: lane j owns component j of state / control terms and column j of J'WJ
+  double cost = 0.0, Lq = 0.0, Lv = 0.0, Lu = 0.0, Lvv = 0.0, Luu = 0.0, Lqqc[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) Lqqc[i] = 0.0;
+  int fslot = 0;
+  for (int r = 0; r < rows.n; ++r) {
+    const int kind0 = rows.kind[r];
+    const bool is_frame = kind0 == AGX_RES_FRAME_PLACEMENT || kind0 == AGX_RES_FRAME_TRANSLATION || kind0 == AGX_RES_FRAME_ROTATION;
+    const int my_slot = fslot;
+    if (is_frame) ++fslot;
+    if (!rows.active[r]) continue;
+    const double *tile = L.u.c.ref + rows.off[r];
+    const double wi = tile[0];
+    const double *rr = tile + 1;
+    const double *aw = rr + rows.nref[r];
+    const int kind = rows.kind[r];
+    if (kind == AGX_RES_STATE) {
+      const double rq = qj - rr[j], rvv = vj - rr[NV + j];
+      const double wq = jl ? wi * aw[j] : 0.0, wv = jl ? wi * aw[NV + j] : 0.0;
+      cost += 0.5 * (wq * rq * rq + wv * rvv * rvv);
+      Lq += wq * rq;
+      Lv += wv * rvv;
+      Lvv += wv;
+#pragma unroll
+      for (int i = 0; i < NV; ++i)
+        if (i == l8) Lqqc[i] += wq;
+    } else if (kind == AGX_RES_CONTROL) {
+      if (!TERM) {
+        const double ru = uj - rr[j];
+        const double wu = jl ? wi * aw[j] : 0.0;
+        cost += 0.5 * wu * ru * ru;
+        Lu += wu * ru;
+        Luu += wu;
+      }
+    } else if (kind == AGX_RES_FRAME_PLACEMENT || kind == AGX_RES_FRAME_TRANSLATION || kind == AGX_RES_FRAME_ROTATION) {
+      // staged frame data (first two frame rows), otherwise straight from the model
+      const double *fpl = L.u.c.frm[my_slot];  // host guarantees at most two frame rows
+      const int jf = L.fpar[my_slot];
+      double RF[9], pF[3];
+      if (jf >= 0) {
+        double Rp[9], pp[3];
+#pragma unroll
+        for (int e = 0; e < 9; ++e) Rp[e] = g_bc(R[e], jf);
+#pragma unroll
+        for (int e = 0; e < 3; ++e) pp[e] = g_bc(p[e], jf);
+        mm3(Rp, fpl, RF);
+        double tt[3];
+        mv3(Rp, fpl + 9, tt);
+        pF[0] = pp[0] + tt[0]; pF[1] = pp[1] + tt[1]; pF[2] = pp[2] + tt[2];
+      } else {
+#pragma unroll
+        for (int e = 0; e < 9; ++e) RF[e] = fpl[e];
+#pragma unroll
+        for (int e = 0; e < 3; ++e) pF[e] = fpl[9 + e];
+      }
+      const bool on = jl && (l8 <= jf);
+      double res[6], Jc[6];
+      int nr;
+      double dl[3], tz[3], lin[3], ang[3];
+      dl[0] = pF[0] - p[0]; dl[1] = pF[1] - p[1]; dl[2] = pF[2] - p[2];
+      cross3(S + 3, dl, tz);  // z x (pF - pj): world linear velocity of the frame per unit joint rate
+      if (kind == AGX_RES_FRAME_PLACEMENT) {
+        nr = 6;
+        double Rrel[9], d3[3], prel[3], TL[9], TR[9];
+        mtm3(rr, RF, Rrel);
+        d3[0] = pF[0] - rr[9]; d3[1] = pF[1] - rr[10]; d3[2] = pF[2] - rr[11];
+        mtv3(rr, d3, prel);
+        log6<true>(Rrel, prel, res, TL, TR);
+        mtv3(RF, tz, lin);
+        mtv3(RF, S + 3, ang);
+#pragma unroll
+        for (int e = 0; e < 3; ++e) {
+          Jc[e] = TL[3 * e] * lin[0] + TL[3 * e + 1] * lin[1] + TL[3 * e + 2] * lin[2] + TR[3 * e] * ang[0] + TR[3 * e + 1] * ang[1] + TR[3 * e + 2] * ang[2];
+          Jc[3 + e] = TL[3 * e] * ang[0] + TL[3 * e + 1] * ang[1] + TL[3 * e + 2] * ang[2];
+        }
+      } else if (kind == AGX_RES_FRAME_TRANSLATION) {
+        nr = 3;
+        res[0] = pF[0] - rr[0]; res[1] = pF[1] - rr[1]; res[2] = pF[2] - rr[2];
+        res[3] = res[4] = res[5] = 0.0;
+        Jc[0] = tz[0]; Jc[1] = tz[1]; Jc[2] = tz[2];
+        Jc[3] = Jc[4] = Jc[5] = 0.0;
+      } else {
+        nr = 3;
+        double Rrel[9], TL[9];
+        mtm3(rr, RF, Rrel);
+        log3(Rrel, res);
+        res[3] = res[4] = res[5] = 0.0;
+        jlog3(res, TL);
+        mtv3(RF, S + 3, ang);
+#pragma unroll
+        for (int e = 0; e < 3; ++e) Jc[e] = TL[3 * e] * ang[0] + TL[3 * e + 1] * ang[1] + TL[3 * e + 2] * ang[2];
+        Jc[3] = Jc[4] = Jc[5] = 0.0;
+      }
+      double we[6], a = 0.0;
+#pragma unroll
+      for (int e = 0; e < 6; ++e) {
+        we[e] = (e < nr) ? wi * aw[e] : 0.0;
+        a += 0.5 * we[e] * res[e] * res[e];
+        if (!on) Jc[e] = 0.0;
+      }
+      if (l8 == 0) cost += a;
+      wave_lds_sync();  // previous users of the J tile are done
+#pragma unroll
+      for (int e = 0; e < 6; ++e) L.u.c.J[l8][e] = Jc[e];
+      wave_lds_sync();
+#pragma unroll
+      for (int e = 0; e < 6; ++e) Lq += we[e] * res[e] * Jc[e];
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        double acc = 0.0;
+#pragma unroll
+        for (int e = 0; e < 6; ++e) acc += we[e] * L.u.c.J[i][e] * Jc[e];
+        Lqqc[i] += acc;
+      }
+    }
+  }
+  wave_lds_sync();  // the cost phase's LDS (reference tile, frames, J) is dead from here on
+
   // body inertia in the world frame
   double Ib[10];
   {
@@ -288,14 +411,14 @@ __global__ void __launch_bounds__(64, AGX_K1_WAVES) k_calc_qp_lj(const DevModel 
     const double nle = dot6(S, fb);
     // publish S, m6 ; column j of M
 #pragma unroll
-    for (int e = 0; e < 6; ++e) { L.u.p1.S[l8][e] = S[e]; L.u.p1.m6[l8][e] = m6[e]; }
+    for (int e = 0; e < 6; ++e) { L.u.d1.S[l8][e] = S[e]; L.u.d1.m6[l8][e] = m6[e]; }
     L.vec[0][l8] = uj - nle;
     wave_lds_sync();
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       double val;
-      if (i >= l8) val = dot6(S, L.u.p1.m6[i]);
-      else val = dot6(L.u.p1.S[i], m6);
+      if (i >= l8) val = dot6(S, L.u.d1.m6[i]);
+      else val = dot6(L.u.d1.S[i], m6);
       if (i == l8) val += mj[28];
       Mc[i] = val;
       L.M[i][l8] = val;
@@ -419,18 +542,18 @@ __global__ void __launch_bounds__(64, AGX_K1_WAVES) k_calc_qp_lj(const DevModel 
         colq[3 + e] = sxf[3 + e] + e2[e] + IcPs[3 + e];
       }
     }
-    L.Dt[l8][0] = Dt[0]; L.Dt[l8][1] = Dt[1]; L.Dt[l8][2] = Dt[2];
+    L.u.d1.Dt[l8][0] = Dt[0]; L.u.d1.Dt[l8][1] = Dt[1]; L.u.d1.Dt[l8][2] = Dt[2];
     wave_lds_sync();
     // column l8 of dtau/dq (tqc) and dtau/dqdot (tvc)
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       double dvv, dqq;
       if (i >= l8) {
-        const double *mi = L.u.p1.m6[i], *Di = L.Dt[i];
+        const double *mi = L.u.d1.m6[i], *Di = L.u.d1.Dt[i];
         dvv = 2.0 * dot6(mi, Sd) + dot3(Di, S + 3);
         dqq = dot3(Di, Sd + 3) + dot6(mi, psi);
       } else {
-        const double *Si = L.u.p1.S[i];
+        const double *Si = L.u.d1.S[i];
         dvv = dot6(Si, colv);
         dqq = dot6(Si, colq);
       }
@@ -440,8 +563,8 @@ __global__ void __launch_bounds__(64, AGX_K1_WAVES) k_calc_qp_lj(const DevModel 
     wave_lds_sync();  // phase 1 storage is dead from here on
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-      L.u.p2.tq[i][l8] = tqc[i];
-      L.u.p2.tv[i][l8] = tvc[i];
+      L.u.d2.tq[i][l8] = tqc[i];
+      L.u.d2.tv[i][l8] = tvc[i];
     }
 #if defined(AGX_K1_STAGE) && AGX_K1_STAGE == 3
   { if (wr) qt[l8] = tqc[0] + tvc[NV - 1] + tqc[NV - 1] + tvc[0] + gapq; return; }
@@ -450,122 +573,6 @@ __global__ void __launch_bounds__(64, AGX_K1_WAVES) k_calc_qp_lj(const DevModel 
     wave_lds_sync();
   }
 
-  // ---- cost rows: lane j owns component j of state / control terms and column j of J'WJ
-  double cost = 0.0, Lq = 0.0, Lv = 0.0, Lu = 0.0, Lvv = 0.0, Luu = 0.0, Lqqc[NV];
-#pragma unroll
-  for (int i = 0; i < NV; ++i) Lqqc[i] = 0.0;
-  int fslot = 0;
-  for (int r = 0; r < rows.n; ++r) {
-    const int kind0 = rows.kind[r];
-    const bool is_frame = kind0 == AGX_RES_FRAME_PLACEMENT || kind0 == AGX_RES_FRAME_TRANSLATION || kind0 == AGX_RES_FRAME_ROTATION;
-    const int my_slot = fslot;
-    if (is_frame) ++fslot;
-    if (!rows.active[r]) continue;
-    const double *tile = L.ref + rows.off[r];
-    const double wi = tile[0];
-    const double *rr = tile + 1;
-    const double *aw = rr + rows.nref[r];
-    const int kind = rows.kind[r];
-    if (kind == AGX_RES_STATE) {
-      const double rq = qj - rr[j], rvv = vj - rr[NV + j];
-      const double wq = jl ? wi * aw[j] : 0.0, wv = jl ? wi * aw[NV + j] : 0.0;
-      cost += 0.5 * (wq * rq * rq + wv * rvv * rvv);
-      Lq += wq * rq;
-      Lv += wv * rvv;
-      Lvv += wv;
-#pragma unroll
-      for (int i = 0; i < NV; ++i)
-        if (i == l8) Lqqc[i] += wq;
-    } else if (kind == AGX_RES_CONTROL) {
-      if (!TERM) {
-        const double ru = uj - rr[j];
-        const double wu = jl ? wi * aw[j] : 0.0;
-        cost += 0.5 * wu * ru * ru;
-        Lu += wu * ru;
-        Luu += wu;
-      }
-    } else if (kind == AGX_RES_FRAME_PLACEMENT || kind == AGX_RES_FRAME_TRANSLATION || kind == AGX_RES_FRAME_ROTATION) {
-      // staged frame data (first two frame rows), otherwise straight from the model
-      const double *fpl = L.frm[my_slot];  // host guarantees at most two frame rows
-      const int jf = L.fpar[my_slot];
-      double RF[9], pF[3];
-      if (jf >= 0) {
-        double Rp[9], pp[3];
-#pragma unroll
-        for (int e = 0; e < 9; ++e) Rp[e] = g_bc(R[e], jf);
-#pragma unroll
-        for (int e = 0; e < 3; ++e) pp[e] = g_bc(p[e], jf);
-        mm3(Rp, fpl, RF);
-        double tt[3];
-        mv3(Rp, fpl + 9, tt);
-        pF[0] = pp[0] + tt[0]; pF[1] = pp[1] + tt[1]; pF[2] = pp[2] + tt[2];
-      } else {
-#pragma unroll
-        for (int e = 0; e < 9; ++e) RF[e] = fpl[e];
-#pragma unroll
-        for (int e = 0; e < 3; ++e) pF[e] = fpl[9 + e];
-      }
-      const bool on = jl && (l8 <= jf);
-      double res[6], Jc[6];
-      int nr;
-      double dl[3], tz[3], lin[3], ang[3];
-      dl[0] = pF[0] - p[0]; dl[1] = pF[1] - p[1]; dl[2] = pF[2] - p[2];
-      cross3(S + 3, dl, tz);  // z x (pF - pj): world linear velocity of the frame per unit joint rate
-      if (kind == AGX_RES_FRAME_PLACEMENT) {
-        nr = 6;
-        double Rrel[9], d3[3], prel[3], TL[9], TR[9];
-        mtm3(rr, RF, Rrel);
-        d3[0] = pF[0] - rr[9]; d3[1] = pF[1] - rr[10]; d3[2] = pF[2] - rr[11];
-        mtv3(rr, d3, prel);
-        log6<true>(Rrel, prel, res, TL, TR);
-        mtv3(RF, tz, lin);
-        mtv3(RF, S + 3, ang);
-#pragma unroll
-        for (int e = 0; e < 3; ++e) {
-          Jc[e] = TL[3 * e] * lin[0] + TL[3 * e + 1] * lin[1] + TL[3 * e + 2] * lin[2] + TR[3 * e] * ang[0] + TR[3 * e + 1] * ang[1] + TR[3 * e + 2] * ang[2];
-          Jc[3 + e] = TL[3 * e] * ang[0] + TL[3 * e + 1] * ang[1] + TL[3 * e + 2] * ang[2];
-        }
-      } else if (kind == AGX_RES_FRAME_TRANSLATION) {
-        nr = 3;
-        res[0] = pF[0] - rr[0]; res[1] = pF[1] - rr[1]; res[2] = pF[2] - rr[2];
-        res[3] = res[4] = res[5] = 0.0;
-        Jc[0] = tz[0]; Jc[1] = tz[1]; Jc[2] = tz[2];
-        Jc[3] = Jc[4] = Jc[5] = 0.0;
-      } else {
-        nr = 3;
-        double Rrel[9], TL[9];
-        mtm3(rr, RF, Rrel);
-        log3(Rrel, res);
-        res[3] = res[4] = res[5] = 0.0;
-        jlog3(res, TL);
-        mtv3(RF, S + 3, ang);
-#pragma unroll
-        for (int e = 0; e < 3; ++e) Jc[e] = TL[3 * e] * ang[0] + TL[3 * e + 1] * ang[1] + TL[3 * e + 2] * ang[2];
-        Jc[3] = Jc[4] = Jc[5] = 0.0;
-      }
-      double we[6], a = 0.0;
-#pragma unroll
-      for (int e = 0; e < 6; ++e) {
-        we[e] = (e < nr) ? wi * aw[e] : 0.0;
-        a += 0.5 * we[e] * res[e] * res[e];
-        if (!on) Jc[e] = 0.0;
-      }
-      if (l8 == 0) cost += a;
-      wave_lds_sync();  // previous users of the J tile are done
-#pragma unroll
-      for (int e = 0; e < 6; ++e) L.u.p2.J[l8][e] = Jc[e];
-      wave_lds_sync();
-#pragma unroll
-      for (int e = 0; e < 6; ++e) Lq += we[e] * res[e] * Jc[e];
-#pragma unroll
-      for (int i = 0; i < NV; ++i) {
-        double acc = 0.0;
-#pragma unroll
-        for (int e = 0; e < 6; ++e) acc += we[e] * L.u.p2.J[i][e] * Jc[e];
-        Lqqc[i] += acc;
-      }
-    }
-  }
   const double sc = TERM ? 1.0 : dt;
 #if defined(AGX_K1_STAGE) && AGX_K1_STAGE == 4
   { if (wr) qt[l8] = cost + Lq + Lv + Lu + Lqqc[0] + Lqqc[NV - 1] + tqc[0] + tvc[1] + Mc[2] + gapq; return; }
@@ -589,13 +596,20 @@ __global__ void __launch_bounds__(64, AGX_K1_WAVES) k_calc_qp_lj(const DevModel 
     Dtq[l] = Dl * tqc[l];
     Dtv[l] = Dl * tvc[l];
   }
-  if (act) {  // all 8 lanes store: every block row is one whole 64-byte line (lane NV.. writes the zero padding)
+  // all 8 lanes store (lanes >= NV write the zero padding): every block row is one whole 64-byte line
+  auto store_block = [&](double *blk, const double *col) {
+#ifdef AGX_K1_NOSTORE
+    for (int i = 0; i < NV; ++i) chk += col[i];
+#else
 #pragma unroll
-    for (int i = 0; i < NV; ++i) {
-      K1ST(ax[A::M + i * A::LD + l8], jl ? Mc[i] : 0.0);
-      K1ST(ax[A::tq + i * A::LD + l8], jl ? tqc[i] : 0.0);
-      K1ST(ax[A::tv + i * A::LD + l8], jl ? tvc[i] : 0.0);
-    }
+    for (int i = 0; i + 1 < NV; i += 2) store_row_pair(blk, i, l8, jl ? col[i] : 0.0, jl ? col[i + 1] : 0.0);
+    if (NV & 1) blk[(NV - 1) * 8 + l8] = jl ? col[NV - 1] : 0.0;
+#endif
+  };
+  if (act) {
+    store_block(ax + A::M, Mc);
+    store_block(ax + A::tq, tqc);
+    store_block(ax + A::tv, tvc);
   }
   if (wr) {
     K1ST(qt[Q::f + l8], gapq);
@@ -607,13 +621,14 @@ __global__ void __launch_bounds__(64, AGX_K1_WAVES) k_calc_qp_lj(const DevModel 
     K1ST(ax[A::Luu + l8], sc * Luu);
     K1ST(ax[A::Lu + l8], lu);
   }
+  double cww[NV], cqw[NV], cvw[NV], cqq[NV], cqv[NV], cvv[NV], clq[NV];
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
     double hww = 0.0, hqw = 0.0, hvw = 0.0, hqq = sc * Lqqc[i], hqv = 0.0, hvv = (i == l8) ? sc * Lvv : 0.0;
     if (!TERM) {
 #pragma unroll
       for (int l = 0; l < NV; ++l) {
-        const double Mil = L.M[i][l], tqli = L.u.p2.tq[l][i], tvli = L.u.p2.tv[l][i];
+        const double Mil = L.M[i][l], tqli = L.u.d2.tq[l][i], tvli = L.u.d2.tv[l][i];
         hww += Mil * DMc[l];
         hqw += tqli * DMc[l];
         hvw += tvli * DMc[l];
@@ -622,15 +637,16 @@ __global__ void __launch_bounds__(64, AGX_K1_WAVES) k_calc_qp_lj(const DevModel 
         hvv += tvli * Dtv[l];
       }
     }
-    if (act) {
-      K1ST(qt[Q::Hww + i * Q::LD + l8], jl ? hww : 0.0);
-      K1ST(qt[Q::Hqw + i * Q::LD + l8], jl ? hqw : 0.0);
-      K1ST(qt[Q::Hvw + i * Q::LD + l8], jl ? hvw : 0.0);
-      K1ST(qt[Q::Hqq + i * Q::LD + l8], jl ? hqq : 0.0);
-      K1ST(qt[Q::Hqv + i * Q::LD + l8], jl ? hqv : 0.0);
-      K1ST(qt[Q::Hvv + i * Q::LD + l8], jl ? hvv : 0.0);
-      K1ST(ax[A::Lqq + i * A::LD + l8], jl ? sc * Lqqc[i] : 0.0);
-    }
+    cww[i] = hww; cqw[i] = hqw; cvw[i] = hvw; cqq[i] = hqq; cqv[i] = hqv; cvv[i] = hvv; clq[i] = sc * Lqqc[i];
+  }
+  if (act) {
+    store_block(qt + Q::Hww, cww);
+    store_block(qt + Q::Hqw, cqw);
+    store_block(qt + Q::Hvw, cvw);
+    store_block(qt + Q::Hqq, cqq);
+    store_block(qt + Q::Hqv, cqv);
+    store_block(qt + Q::Hvv, cvv);
+    store_block(ax + A::Lqq, clq);
   }
 #ifdef AGX_K1_NOSTORE
   if (wr) qt[l8] = chk;

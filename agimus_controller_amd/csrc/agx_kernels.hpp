@@ -11,6 +11,8 @@
 // agimus_controller/agimus_controller/ocp_base_croco.py:172 (unconstrained branch).
 #pragma once
 
+#include <type_traits>
+
 #include "agx_device.hpp"
 
 // Per-instance solver state, device resident.
@@ -404,6 +406,17 @@ __device__ __forceinline__ double wave_sum(double v) {
 // the feed-forward kw.  Per pivot: 6 cross-lane fetches (column k of the lane's row, row k of
 // the lane's column), 12 FMAs.
 // ---------------------------------------------------------------------------
+// value held by lane (my row, column K) of the 8 x 8 lane grid, K a compile-time constant: DPP
+// row_share inside the 16-lane DPP row (two grid rows), one pass per half selected by the bank mask.
+template <int K>
+__device__ __forceinline__ double grid_col(double x) {
+  const int lo = __double2loint(x), hi = __double2hiint(x);
+  int lo2 = __builtin_amdgcn_update_dpp(0, lo, 0x150 + K, 0xf, 0x3, false);
+  lo2 = __builtin_amdgcn_update_dpp(lo2, lo, 0x150 + 8 + K, 0xf, 0xc, false);
+  int hi2 = __builtin_amdgcn_update_dpp(0, hi, 0x150 + K, 0xf, 0x3, false);
+  hi2 = __builtin_amdgcn_update_dpp(hi2, hi, 0x150 + 8 + K, 0xf, 0xc, false);
+  return __hiloint2double(hi2, lo2);
+}
 __device__ __forceinline__ double fast_rcp(double x) {
   double y = __builtin_amdgcn_rcp(x);
   y = y * (2.0 - x * y);
@@ -411,23 +424,34 @@ __device__ __forceinline__ double fast_rcp(double x) {
   return y;
 }
 
-template <int NV>
+// GAINS = true is the exit pass: CSQP's proximal (sigma) backward sweep whose gains the solver reports.
+// sigma enters every Hessian block exactly like an extra control weight (D -> D + sigma) plus sigma I
+// on Hxx; the corrections  sigma [taux M]' [taux M]  are formed on the fly from the aux tile, the
+// gradient recursion is skipped (it does not influence the gains) and the gains are mapped to
+// u-space in registers:  K = M Kw - taux  -> Kout.  No forward pass.
+template <int NV, bool GAINS>
 __global__ void __launch_bounds__(64) k_riccati(const DevOcp *__restrict__ op, const double *__restrict__ dts,
-                                                const double *__restrict__ qts, double *__restrict__ Kws,
-                                                double *__restrict__ kws, double *__restrict__ dxs,
-                                                double *__restrict__ wss, const DevState *__restrict__ st, int forward,
-                                                int gains_pass) {
+                                                const double *__restrict__ qts, const double *__restrict__ auxs,
+                                                double *__restrict__ Kws, double *__restrict__ kws,
+                                                double *__restrict__ dxs, double *__restrict__ wss,
+                                                double *__restrict__ dus, double *__restrict__ Kout,
+                                                DevState *__restrict__ st, int forward) {
+  constexpr int gains_pass = GAINS ? 1 : 0;
+  typedef AUX<NV> A;
   static_assert(NV <= 8, "the register-resident Riccati kernel maps an NV x NV block onto an 8 x 8 lane grid");
   constexpr int NX = 2 * NV, TS = QT<NV>::SIZE;
   typedef QT<NV> Q;
   const DevOcp &o = *op;
   const int T = o.T, b = blockIdx.x, lane = threadIdx.x;
-  const DevState &S = st[b];
+  DevState &S = st[b];
   // gains pass (on exit): every instance, with the regularisation its last direction was computed with
   if (!gains_pass && S.done) return;
   const double dreg = gains_pass ? (S.solved ? S.dreg : S.gains_dreg) : S.dreg;
   const double *qb = qts + (long long)b * (T + 1) * TS;
+  const double *ab = auxs + (long long)b * (T + 1) * A::SIZE;
   double *Kw = Kws + (long long)b * T * NV * NX, *kw = kws + (long long)b * T * NV;
+  double *Ko = GAINS ? Kout + (long long)b * T * NV * NX : nullptr;
+  const double sig = GAINS ? kSigma : 0.0;
   const int r = lane >> 3, c = lane & 7;
   const bool in = (r < NV) && (c < NV);
   const int rc = in ? r * Q::LD + c : 0, cr = in ? c * Q::LD + r : 0;  // [r][c] and [c][r] of a block
@@ -438,30 +462,61 @@ __global__ void __launch_bounds__(64) k_riccati(const DevOcp *__restrict__ op, c
   double Vqq, Vqv, Vvq, Vvv, vxq, vxv;
   {
     const double *tt = qb + (long long)T * TS;
-    Vqq = in ? tt[Q::Hqq + rc] + dreg * diag : 0.0;
+    Vqq = in ? tt[Q::Hqq + rc] + (dreg + sig) * diag : 0.0;
     Vqv = in ? tt[Q::Hqv + rc] : 0.0;
     Vvq = in ? tt[Q::Hqv + cr] : 0.0;
-    Vvv = in ? tt[Q::Hvv + rc] + dreg * diag : 0.0;
+    Vvv = in ? tt[Q::Hvv + rc] + (dreg + sig) * diag : 0.0;
     vxq = (r < NV) ? tt[Q::gx + rr] : 0.0;
     vxv = (r < NV) ? tt[Q::gx + NV + rr] : 0.0;
   }
-  // tile elements of the current node, prefetched one node ahead
-  double hqq, hqv, hvq, hvv, hqw, hvw, hwq, hwv, hww, gq, gv, gwr, fq, fv;
-  auto load_tile = [&](int t) {
-    const double *tl = qb + (long long)t * TS;
-    hqq = tl[Q::Hqq + rc]; hqv = tl[Q::Hqv + rc]; hvq = tl[Q::Hqv + cr]; hvv = tl[Q::Hvv + rc];
-    hqw = tl[Q::Hqw + rc]; hvw = tl[Q::Hvw + rc]; hwq = tl[Q::Hqw + cr]; hwv = tl[Q::Hvw + cr];
-    hww = tl[Q::Hww + rc];
-    gq = tl[Q::gx + rr]; gv = tl[Q::gx + NV + rr]; gwr = tl[Q::gw + rr];
-    fq = tl[Q::f + cc]; fv = tl[Q::f + NV + cc];
+  // tile elements of a node, prefetched TWO nodes ahead into two register sets
+  struct Tile {
+    double hqq, hqv, hvq, hvv, hqw, hvw, hwq, hwv, hww, gq, gv, gwr, fq, fv;
+    double aMr[NV], aMc[NV], aqr[NV], aqc[NV], avr[NV], avc[NV], atq, atv;  // GAINS: columns r, c of M, tq, tv
   };
-  load_tile(T - 1);
-  for (int t = T - 1; t >= 0; --t) {
+  auto load_tile = [&](Tile &z, int t) {
+    const double *tl = qb + (long long)t * TS;
+    if (GAINS) {
+      const double *al = ab + (long long)t * A::SIZE;
+#pragma unroll
+      for (int l = 0; l < NV; ++l) {
+        z.aMr[l] = al[A::M + l * A::LD + rr]; z.aMc[l] = al[A::M + l * A::LD + cc];
+        z.aqr[l] = al[A::tq + l * A::LD + rr]; z.aqc[l] = al[A::tq + l * A::LD + cc];
+        z.avr[l] = al[A::tv + l * A::LD + rr]; z.avc[l] = al[A::tv + l * A::LD + cc];
+      }
+      z.atq = al[A::tq + rc]; z.atv = al[A::tv + rc];
+    }
+    z.hqq = tl[Q::Hqq + rc]; z.hqv = tl[Q::Hqv + rc]; z.hvq = tl[Q::Hqv + cr]; z.hvv = tl[Q::Hvv + rc];
+    z.hqw = tl[Q::Hqw + rc]; z.hvw = tl[Q::Hvw + rc]; z.hwq = tl[Q::Hqw + cr]; z.hwv = tl[Q::Hvw + cr];
+    z.hww = tl[Q::Hww + rc];
+    if (!GAINS) {
+      z.gq = tl[Q::gx + rr]; z.gv = tl[Q::gx + NV + rr]; z.gwr = tl[Q::gw + rr];
+      z.fq = tl[Q::f + cc]; z.fv = tl[Q::f + NV + cc];
+    }
+  };
+  auto step = [&](Tile &z, int t) {
     const double h = dts[t], h2 = h * h;
-    // current tile -> working copies, then start fetching the next one
-    const double Hqq_ = hqq, Hqv_ = hqv, Hvq_ = hvq, Hvv_ = hvv, Hqw_ = hqw, Hvw_ = hvw, Hwq_ = hwq, Hwv_ = hwv, Hww_ = hww;
-    const double gq_ = gq, gv_ = gv, gw_ = gwr, fq_ = (c < NV) ? fq : 0.0, fv_ = (c < NV) ? fv : 0.0;
-    if (t > 0) load_tile(t - 1);
+    // current tile -> working copies, then refill this register set with the tile two nodes ahead
+    double Hqq_ = z.hqq, Hqv_ = z.hqv, Hvq_ = z.hvq, Hvv_ = z.hvv, Hqw_ = z.hqw, Hvw_ = z.hvw, Hwq_ = z.hwq, Hwv_ = z.hwv, Hww_ = z.hww;
+    const double gq_ = GAINS ? 0.0 : z.gq, gv_ = GAINS ? 0.0 : z.gv, gw_ = GAINS ? 0.0 : z.gwr;
+    const double fq_ = (c < NV && !GAINS) ? z.fq : 0.0, fv_ = (c < NV && !GAINS) ? z.fv : 0.0;
+    double Mr_[NV], tq_rc = 0.0, tv_rc = 0.0;
+    if (GAINS) {
+      // sigma [taux M]' [taux M] at [r][c] (and at [c][r] for the transposed blocks), sigma I on Hxx
+      double xww = 0.0, xqw = 0.0, xwq = 0.0, xvw = 0.0, xwv = 0.0, xqq = 0.0, xqv = 0.0, xvq = 0.0, xvv = 0.0;
+#pragma unroll
+      for (int l = 0; l < NV; ++l) {
+        xww += z.aMr[l] * z.aMc[l];
+        xqw += z.aqr[l] * z.aMc[l]; xwq += z.aMr[l] * z.aqc[l];
+        xvw += z.avr[l] * z.aMc[l]; xwv += z.aMr[l] * z.avc[l];
+        xqq += z.aqr[l] * z.aqc[l]; xqv += z.aqr[l] * z.avc[l]; xvq += z.avr[l] * z.aqc[l]; xvv += z.avr[l] * z.avc[l];
+        Mr_[l] = z.aMr[l];
+      }
+      Hww_ += sig * xww; Hqw_ += sig * xqw; Hwq_ += sig * xwq; Hvw_ += sig * xvw; Hwv_ += sig * xwv;
+      Hqq_ += sig * (xqq + diag); Hqv_ += sig * xqv; Hvq_ += sig * xvq; Hvv_ += sig * (xvv + diag);
+      tq_rc = z.atq; tv_rc = z.atv;
+    }
+    if (t >= 2) load_tile(z, t - 2);
     // ---- phase A
     // vp = vx + V f  (row reduction over c)
     double pq = Vqq * fq_ + Vqv * fv_, pv = Vvq * fq_ + Vvv * fv_;
@@ -489,13 +544,14 @@ __global__ void __launch_bounds__(64) k_riccati(const DevOcp *__restrict__ op, c
     if (r >= NV) { gW = 0.0; gQ = 0.0; gV = 0.0; }
     // ---- phase B: Gauss-Jordan pivots k = 0..NV-1 in the ww block
     double rp_row = 1.0;
-#pragma unroll
-    for (int k = 0; k < NV; ++k) {
+    auto pivot = [&](auto Kc) {
+      constexpr int k = decltype(Kc)::value;
+      if (k >= NV) return;
       const double piv = __shfl(Mww, 9 * k, 64);
       const double rp = fast_rcp(piv);
       const double gk = __shfl(gW, 8 * k, 64);
-      // column k of my row (three row blocks), row k of my column (three column blocks)
-      const double cw = __shfl(Mww, row_base | k, 64), cq = __shfl(Mqw, row_base | k, 64), cv = __shfl(Mvw, row_base | k, 64);
+      // column k of my row (three row blocks: DPP), row k of my column (three column blocks: bpermute)
+      const double cw = grid_col<k>(Mww), cq = grid_col<k>(Mqw), cv = grid_col<k>(Mvw);
       const double rw = __shfl(Mww, 8 * k + col_lane, 64), rq = __shfl(Mwq, 8 * k + col_lane, 64), rv2 = __shfl(Mwv, 8 * k + col_lane, 64);
       const double fw = (r == k) ? 0.0 : cw * rp;  // the pivot row itself is left untouched
       const double fqx = cq * rp, fvx = cv * rp;
@@ -503,62 +559,159 @@ __global__ void __launch_bounds__(64) k_riccati(const DevOcp *__restrict__ op, c
       Mqw -= fqx * rw; Mqq -= fqx * rq; Mqv -= fqx * rv2; gQ -= fqx * gk;
       Mvw -= fvx * rw; Mvq -= fvx * rq; Mvv -= fvx * rv2; gV -= fvx * gk;
       if (r == k) rp_row = rp;
-    }
+    };
+    pivot(std::integral_constant<int, 0>()); pivot(std::integral_constant<int, 1>()); pivot(std::integral_constant<int, 2>());
+    pivot(std::integral_constant<int, 3>()); pivot(std::integral_constant<int, 4>()); pivot(std::integral_constant<int, 5>());
+    pivot(std::integral_constant<int, 6>()); pivot(std::integral_constant<int, 7>());
     // gains of this node: Kw = D^-1 [Mwq Mwv], kw = D^-1 gW
-    if (in) {
-      Kw[(long long)t * NV * NX + r * NX + c] = Mwq * rp_row;
-      Kw[(long long)t * NV * NX + r * NX + NV + c] = Mwv * rp_row;
+    if (!GAINS) {
+      if (in) {
+        Kw[(long long)t * NV * NX + r * NX + c] = Mwq * rp_row;
+        Kw[(long long)t * NV * NX + r * NX + NV + c] = Mwv * rp_row;
+      }
+      if (c == 0 && r < NV) kw[(long long)t * NV + r] = gW * rp_row;
+    } else {
+      // u-space gains  K = M Kw - taux : row r of M against column c of Kw
+      const double kq = Mwq * rp_row, kv = Mwv * rp_row;
+      double Kq = -tq_rc, Kv = -tv_rc;
+#pragma unroll
+      for (int l = 0; l < NV; ++l) {
+        Kq += Mr_[l] * __shfl(kq, 8 * l + col_lane, 64);
+        Kv += Mr_[l] * __shfl(kv, 8 * l + col_lane, 64);
+      }
+      if (in) {
+        Ko[(long long)t * NV * NX + r * NX + c] = Kq;
+        Ko[(long long)t * NV * NX + r * NX + NV + c] = Kv;
+      }
     }
-    if (c == 0 && r < NV) kw[(long long)t * NV + r] = gW * rp_row;
     // value function of node t
-    Vqq = Mqq + dreg * diag; Vqv = Mqv; Vvq = Mvq; Vvv = Mvv + dreg * diag;
+    Vqq = Mqq + dreg * diag; Vqv = Mqv; Vvq = Mvq; Vvv = Mvv + dreg * diag;  // (sigma is part of H at every node)
     if (!in) { Vqq = 0.0; Vqv = 0.0; Vvq = 0.0; Vvv = 0.0; }
     vxq = gQ; vxv = gV;
-  }
-  if (!forward) return;
-  // ---- forward pass, shuffle only: lane j < NX holds dx_j, lane a < NV computes w_a
-  double *dx = dxs + (long long)b * (T + 1) * NX, *ws = wss + (long long)b * T * NV;
-  double dxv = 0.0;
-  if (lane < NX) dx[lane] = 0.0;
-  __threadfence_block();  // the gains written above are read back by other lanes below
-  double krow[NX], kwa = 0.0, fvv = 0.0;
-  auto load_gain = [&](int t) {
-    if (lane < NV) {
-#pragma unroll
-      for (int j = 0; j < NX; ++j) krow[j] = Kw[(long long)t * NV * NX + lane * NX + j];
-      kwa = kw[(long long)t * NV + lane];
-    }
-    if (lane < NX) fvv = qb[(long long)t * TS + Q::f + lane];
   };
-  load_gain(0);
-  for (int t = 0; t < T; ++t) {
+  Tile ta, tb;
+  load_tile(ta, T - 1);
+  if (T >= 2) load_tile(tb, T - 2);
+  for (int t = T - 1; t >= 0; t -= 2) {
+    step(ta, t);
+    if (t >= 1) step(tb, t - 1);
+  }
+  if (GAINS || !forward) return;
+  // ---- forward pass: lane a < NV owns joint a (dx_q[a], dx_v[a], w[a]); the only cross-lane traffic
+  // is the broadcast of dx to every lane (v_readlane), the state update is lane-local.
+  double *dx = dxs + (long long)b * (T + 1) * NX, *ws = wss + (long long)b * T * NV;
+  double dq = 0.0, dv = 0.0;
+  if (lane < NV) { dx[lane] = 0.0; dx[NV + lane] = 0.0; }
+  __threadfence_block();  // the gains written above are read back by other lanes below
+  const int la = lane < NV ? lane : 0;
+  struct Gain { double k[NX], kw, fq, fv; };
+  auto load_gain = [&](Gain &g, int t) {
+#pragma unroll
+    for (int j = 0; j < NX; ++j) g.k[j] = Kw[(long long)t * NV * NX + la * NX + j];
+    g.kw = kw[(long long)t * NV + la];
+    g.fq = qb[(long long)t * TS + Q::f + la];
+    g.fv = qb[(long long)t * TS + Q::f + NV + la];
+  };
+  auto fstep = [&](Gain &g, int t) {
     const double h = dts[t], h2 = h * h;
-    double kr[NX];
+    double w0 = -g.kw, w1 = 0.0;  // two accumulation chains
 #pragma unroll
-    for (int j = 0; j < NX; ++j) kr[j] = krow[j];
-    const double kwc = kwa, fc = fvv;
-    if (t + 1 < T) load_gain(t + 1);
-    double wv = -kwc;
-#pragma unroll
-    for (int j = 0; j < NX; ++j) {
-      const double dj = __shfl(dxv, j, 64);
-      wv -= kr[j] * dj;
+    for (int j = 0; j < NV; ++j) {
+      w0 -= g.k[j] * __shfl(dq, j, 64);
+      w1 -= g.k[NV + j] * __shfl(dv, j, 64);
     }
-    if (lane >= NV) wv = 0.0;
-    const double dx_up = __shfl(dxv, (lane + NV) & 63, 64);
-    const double w_dn = __shfl(wv, lane >= NV ? lane - NV : lane, 64);
-    double nxt;
-    if (lane < NV) nxt = dxv + h * dx_up + h2 * wv + fc;
-    else nxt = dxv + h * w_dn + fc;
-    if (lane < NV) ws[(long long)t * NV + lane] = wv;
-    dxv = (lane < NX) ? nxt : 0.0;
-    if (lane < NX) dx[(long long)(t + 1) * NX + lane] = dxv;
+    const double wv = w0 + w1, fqc = g.fq, fvc = g.fv;
+    if (t + 4 < T) load_gain(g, t + 4);  // refill this register set four nodes ahead
+    const double nq = dq + h * dv + h2 * wv + fqc;
+    const double nv2 = dv + h * wv + fvc;
+    dq = nq; dv = nv2;
+    if (lane < NV) {
+      ws[(long long)t * NV + lane] = wv;
+      dx[(long long)(t + 1) * NX + lane] = dq;
+      dx[(long long)(t + 1) * NX + NV + lane] = dv;
+    }
+  };
+  Gain g0, g1, g2, g3;
+  load_gain(g0, 0);
+  if (T > 1) load_gain(g1, 1);
+  if (T > 2) load_gain(g2, 2);
+  if (T > 3) load_gain(g3, 3);
+  for (int t = 0; t < T; t += 4) {
+    fstep(g0, t);
+    if (t + 1 < T) fstep(g1, t + 1);
+    if (t + 2 < T) fstep(g2, t + 2);
+    if (t + 3 < T) fstep(g3, t + 3);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// K3: per-node quantities of the direction, node parallel with 8 lanes per node:
+//   du = M w + taux dx  and the node's share of the KKT residual (through the QP-optimality
+//   identity, mim_solvers checkKKTConditions), of the cost and of the gap norm:
+//     Lu + Fu' lam' = -(Lxu' dx + (Luu + preg) du),   Lx + Fx' lam' - lam = -(Lxx dx + Lxu du + dreg dx)
+// Lane j holds component j of w / dx and column j of every matrix row (one 64-byte line per row
+// and node); the row sums run over the group as a DPP butterfly.  nodestat[node] = {kkt, cost, gap, 0}.
+// ---------------------------------------------------------------------------
+template <int NV>
+__global__ void __launch_bounds__(256) k_node_kkt(const DevOcp *__restrict__ op, const double *__restrict__ qts,
+                                                  const double *__restrict__ auxs, const double *__restrict__ dxs,
+                                                  const double *__restrict__ wss, double *__restrict__ dus,
+                                                  double *__restrict__ nodestat, const DevState *__restrict__ st) {
+  constexpr int NX = 2 * NV;
+  typedef QT<NV> Q;
+  typedef AUX<NV> A;
+  const DevOcp &o = *op;
+  const int T = o.T;
+  const int l8 = threadIdx.x & 7;
+  const long long n_nodes = (long long)o.B * (T + 1);
+  const long long node = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 3;
+  const bool ok = node < n_nodes;
+  const long long nid = ok ? node : 0;
+  const int b = (int)(nid / (T + 1)), t = (int)(nid % (T + 1));
+  const DevState &S = st[b];
+  const bool act = ok && !S.done;
+  const double preg = S.preg, dreg = S.dreg;
+  const bool jl = l8 < NV;
+  const int jj = jl ? l8 : 0;
+  const double *qt = qts + nid * Q::SIZE;
+  const double *ax = auxs + nid * A::SIZE;
+  const double *dx = dxs + nid * NX;
+  const double dq = jl ? dx[jj] : 0.0, dv = jl ? dx[NV + jj] : 0.0;
+  double kkt = 0.0, gap = 0.0;
+  if (t < T) {
+    const double wj = jl ? wss[((long long)b * T + t) * NV + jj] : 0.0;
+    const double fq = jl ? qt[Q::f + jj] : 0.0, fv = jl ? qt[Q::f + NV + jj] : 0.0;
+    kkt = fmax(fabs(fq), fabs(fv));
+    gap = fabs(fq) + fabs(fv);
+    double pr[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+      pr[i] = (i < NV) ? ax[A::M + i * A::LD + l8] * wj + ax[A::tq + i * A::LD + l8] * dq + ax[A::tv + i * A::LD + l8] * dv : 0.0;
+    const double du = transpose_reduce8(pr, l8);
+    if (jl) {
+      if (act) dus[((long long)b * T + t) * NV + l8] = du;
+      kkt = fmax(kkt, fabs((ax[A::Luu + l8] + preg) * du));
+    }
+  }
+  if (t > 0) {
+    double pr[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) pr[i] = (i < NV) ? ax[A::Lqq + i * A::LD + l8] * dq : 0.0;
+    const double hq = transpose_reduce8(pr, l8);
+    if (jl) kkt = fmax(kkt, fmax(fabs(hq + dreg * dq), fabs((ax[A::Lvv + l8] + dreg) * dv)));
+  }
+  // group max / sum (fixed order: deterministic)
+  kkt = fmax(kkt, dpp_xor4(kkt)); kkt = fmax(kkt, dpp_xor2(kkt)); kkt = fmax(kkt, dpp_xor1(kkt));
+  gap += dpp_xor4(gap); gap += dpp_xor2(gap); gap += dpp_xor1(gap);
+  if (act && l8 == 0) {
+    double *ns = nodestat + nid * 4;
+    ns[0] = kkt; ns[1] = qt[Q::cost]; ns[2] = gap; ns[3] = 0.0;
   }
 }
 
 // ---------------------------------------------------------------------------
 // K4: step kernel, one workgroup per instance, lanes over nodes.
-//   prologue: du = M w + taux dx per node, KKT residual, cost and gap sums -> convergence test
+//   instance totals of the per-node KKT / cost / gap shares (k_node_kkt) -> convergence test
 //   then the merit line search: alpha = 2^-n, accept the first merit_try < merit.
 // mode bit0: run the line search / state update; without it only the prologue runs (test hook).
 // mode bit2: timing mode (no convergence exit, nothing committed) so that launches are repeatable.
@@ -568,7 +721,7 @@ __global__ void __launch_bounds__(128) k_step(const DevModel *__restrict__ mp, c
                                               const double *__restrict__ dts, double *__restrict__ xs,
                                               double *__restrict__ us, RefView rv, const double *__restrict__ qts,
                                               const double *__restrict__ auxs, const double *__restrict__ dxs,
-                                              const double *__restrict__ wss, double *__restrict__ dus,
+                                              const double *__restrict__ nodestat, const double *__restrict__ dus,
                                               DevState *__restrict__ st, int iter, int max_iter, int mode,
                                               int *__restrict__ n_done) {
   constexpr int NX = 2 * NV, NU = NV;
@@ -582,52 +735,18 @@ __global__ void __launch_bounds__(128) k_step(const DevModel *__restrict__ mp, c
   DevState &S = st[b];
   if (S.done) return;
   double *X = xs + (long long)b * (T + 1) * NX, *U = us + (long long)b * T * NU;
-  const double *DX = dxs + (long long)b * (T + 1) * NX, *W = wss + (long long)b * T * NV;
-  double *DU = dus + (long long)b * T * NU;
+  const double *DX = dxs + (long long)b * (T + 1) * NX;
+  const double *DU = dus + (long long)b * T * NU;
   const double preg = S.preg, dreg = S.dreg;
+
   constexpr int NPT = 4;  // nodes per thread: supports T + 1 <= 4 * blockDim
-  // ---- prologue
-  double kkt = 0.0, msum = 0.0, csum = 0.0, gsum = 0.0;
-  for (int r = 0; r < NPT; ++r) {
-    const int t = tid + r * blockDim.x;
-    if (t > T) break;
-    const double *qt = qts + ((long long)b * (T + 1) + t) * Q::SIZE;
-    const double *ax = auxs + ((long long)b * (T + 1) + t) * A::SIZE;
-    double dx[NX];
-#pragma unroll
-    for (int i = 0; i < NX; ++i) dx[i] = DX[(long long)t * NX + i];
-    csum += qt[Q::cost];
-    if (t < T) {
-      double w[NV];
-#pragma unroll
-      for (int i = 0; i < NV; ++i) w[i] = W[(long long)t * NV + i];
-#pragma unroll
-      for (int i = 0; i < NV; ++i) {
-        double du = 0.0;
-#pragma unroll
-        for (int j = 0; j < NV; ++j) du += ax[A::M + i * A::LD + j] * w[j] + ax[A::tq + i * A::LD + j] * dx[j] + ax[A::tv + i * A::LD + j] * dx[NV + j];
-        DU[(long long)t * NU + i] = du;
-        // Lu + Fu' lam' = -(Lxu' dx + (Luu + preg) du)
-        kkt = fmax(kkt, fabs((ax[A::Luu + i] + preg) * du));
-      }
-#pragma unroll
-      for (int i = 0; i < NX; ++i) {
-        const double fv = qt[Q::f + i];
-        kkt = fmax(kkt, fabs(fv));
-        gsum += fabs(fv);
-      }
-    }
-    if (t > 0) {
-      // Lx + Fx' lam' - lam = -(Lxx dx + Lxu du + dreg dx)
-#pragma unroll
-      for (int i = 0; i < NV; ++i) {
-        double hq = dreg * dx[i];
-#pragma unroll
-        for (int j = 0; j < NV; ++j) hq += ax[A::Lqq + i * A::LD + j] * dx[j];
-        kkt = fmax(kkt, fabs(hq));
-        kkt = fmax(kkt, fabs((ax[A::Lvv + i] + dreg) * dx[NV + i]));
-      }
-    }
+  // ---- per-node KKT / cost / gap shares (k_node_kkt) -> instance totals, fixed summation order
+  double kkt = 0.0, csum = 0.0, gsum = 0.0;
+  for (int t = tid; t <= T; t += blockDim.x) {
+    const double *ns = nodestat + ((long long)b * (T + 1) + t) * 4;
+    kkt = fmax(kkt, ns[0]);
+    csum += ns[1];
+    gsum += ns[2];
   }
   kkt = wave_max(kkt);
   csum = wave_sum(csum);
