@@ -28,7 +28,7 @@ EXPORTED_SYMBOLS = [
     "agx_ocp_upload_warmstart", "agx_ocp_solve_resident", "agx_ocp_download", "agx_ocp_download_first",
     "agx_ocp_shift_warmstart", "agx_ocp_x0_from_prediction", "agx_ocp_integrate", "agx_model_rnea",
     "agx_model_frame_placement", "agx_ocp_get_residuals", "agx_ocp_calc_diff", "agx_ocp_direction",
-    "agx_ocp_time_kernel", "agx_traj_sine_create", "agx_traj_set_window",
+    "agx_ocp_time_kernel", "agx_ocp_profile", "agx_traj_sine_create", "agx_traj_set_window",
     "agx_traj_get_point", "agx_traj_warmstart_from_reference", "agx_ocp_mpc_step",
 ]  # fmt: skip
 
@@ -231,6 +231,13 @@ class HipOcp:
         ms = C.c_double()
         _chk(lib().agx_ocp_time_kernel(self._h, int(which), int(reps), C.byref(ms)))
         return ms.value
+
+    def profile(self, enable: bool):
+        """Switch in-situ kernel timing on/off; returns (ms_sum[3], count[3]) accumulated so far."""
+        ms = (C.c_double * 3)()
+        cnt = (C.c_longlong * 3)()
+        _chk(lib().agx_ocp_profile(self._h, 1 if enable else 0, ms, cnt))
+        return list(ms), list(cnt)
 
     # -- resident trajectory -------------------------------------------------
     def sine_trajectory(self, n_points, dt, q0, amp, pulsation, scale_duration, t0, w_q, w_qdot, w_effort, w_pose, frame):

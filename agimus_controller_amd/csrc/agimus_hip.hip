@@ -67,6 +67,12 @@ struct agx_ocp {
   int n_points = 0;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   int last_max_iter = 0;
+  // in-situ kernel timing (agx_ocp_profile): event pairs around the launches of the SQP loop
+  bool prof = false;
+  std::vector<hipEvent_t> prof_ev;  // [2 * k] start, [2 * k + 1] stop
+  std::vector<int> prof_kind;
+  double prof_ms[3] = {0, 0, 0};
+  long long prof_n[3] = {0, 0, 0};
 };
 
 namespace {
@@ -148,18 +154,20 @@ int launch_calc_diff(agx_ocp *o, bool masked, bool running_only = false) {
 
 // K1 production: QP tiles in acceleration-input form.  Serial chains use the 8-lanes-per-node
 // kernel (agx_k1_lanes.hpp); trees fall back to one lane per node.
-int launch_calc_qp(agx_ocp *o, bool running_only = false) {
+int launch_calc_qp(agx_ocp *o, bool running_only = false, bool term_only = false) {
   return dispatch(o->nv, o->chain, [&](auto NVc, auto CHc) -> int {
     constexpr int NV = decltype(NVc)::value;
     constexpr bool CH = decltype(CHc)::value;
     const long long units = (long long)o->B * o->T;
     if (CH && o->k1_lanes && o->lanes_ok) {
+      if (!term_only)
       hipLaunchKernelGGL((agx::k_calc_qp_lj<NV, false>), dim3((int)((units * 8 + 63) / 64)), dim3(64), 0, o->stream, o->d_model,
                          o->d_ocp, o->d_dt, o->d_xs, o->d_us, o->rv, o->d_qt, o->d_aux, o->d_state);
       if (!running_only)
         hipLaunchKernelGGL((agx::k_calc_qp_lj<NV, true>), dim3((int)(((long long)o->B * 8 + 63) / 64)), dim3(64), 0, o->stream,
                            o->d_model, o->d_ocp, o->d_dt, o->d_xs, o->d_us, o->rv, o->d_qt, o->d_aux, o->d_state);
     } else {
+      if (!term_only)
       hipLaunchKernelGGL((agx::k_calc_qp<NV, CH>), dim3((int)((units + 63) / 64)), dim3(64), 0, o->stream, o->d_model, o->d_ocp,
                          o->d_dt, o->d_xs, o->d_us, o->rv, o->d_qt, o->d_aux, o->d_state);
       if (!running_only)
@@ -214,6 +222,30 @@ int reset_state(agx_ocp *o) {
   return 0;
 }
 
+int prof_mark(agx_ocp *o, int kind, bool start) {
+  if (!o->prof) return 0;
+  hipEvent_t e;
+  HIPCHK(hipEventCreate(&e));
+  HIPCHK(hipEventRecord(e, o->stream));
+  o->prof_ev.push_back(e);
+  if (start) o->prof_kind.push_back(kind);
+  return 0;
+}
+int prof_collect(agx_ocp *o) {
+  if (!o->prof || o->prof_ev.empty()) return 0;
+  HIPCHK(hipStreamSynchronize(o->stream));
+  for (size_t k = 0; k < o->prof_kind.size(); ++k) {
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, o->prof_ev[2 * k], o->prof_ev[2 * k + 1]));
+    o->prof_ms[o->prof_kind[k]] += ms;
+    o->prof_n[o->prof_kind[k]] += 1;
+  }
+  for (hipEvent_t e : o->prof_ev) (void)hipEventDestroy(e);
+  o->prof_ev.clear();
+  o->prof_kind.clear();
+  return 0;
+}
+
 // The SQP loop of SolverCSQP::solve on the resident buffers.
 int solve_resident(agx_ocp *o, int max_iter, double max_time) {
   if (max_iter <= 0) max_iter = 1000;
@@ -222,9 +254,16 @@ int solve_resident(agx_ocp *o, int max_iter, double max_time) {
   if (reset_state(o)) return -1;
   hipLaunchKernelGGL(agx::k_pin_x0, dim3((o->B * o->nx + 255) / 256), dim3(256), 0, o->stream, o->d_xs, o->d_x0, o->B, o->T, o->nx);
   for (int it = 0; it < max_iter; ++it) {
-    if (launch_calc_qp(o)) return -1;
+    if (prof_mark(o, 0, true)) return -1;
+    if (launch_calc_qp(o, true, false)) return -1;  // running nodes: the node-parallel derivative pass
+    if (prof_mark(o, 0, false)) return -1;
+    if (launch_calc_qp(o, false, true)) return -1;  // terminal nodes
+    if (prof_mark(o, 1, true)) return -1;
     if (launch_riccati(o, 1, 0)) return -1;
+    if (prof_mark(o, 1, false)) return -1;
+    if (prof_mark(o, 2, true)) return -1;
     if (launch_step(o, it, max_iter, 1)) return -1;
+    if (prof_mark(o, 2, false)) return -1;
     if (it + 1 == max_iter) break;
     // early exit once every instance has finished (one 4-byte read back)
     HIPCHK(hipMemcpyAsync(o->h_ndone, o->d_ndone, sizeof(int), hipMemcpyDeviceToHost, o->stream));
@@ -235,7 +274,8 @@ int solve_resident(agx_ocp *o, int max_iter, double max_time) {
       if (el > max_time) break;
     }
   }
-  return launch_gains(o);
+  if (launch_gains(o)) return -1;
+  return prof_collect(o);
 }
 
 }  // namespace
@@ -720,6 +760,17 @@ int agx_ocp_time_kernel(agx_ocp *o, int which, int reps, double *avg_ms) {
   float ms = 0.f;
   HIPCHK(hipEventElapsedTime(&ms, o->ev0, o->ev1));
   *avg_ms = (double)ms / reps;
+  return 0;
+}
+
+int agx_ocp_profile(agx_ocp *o, int enable, double *ms_sum, long long *count) {
+  if (!o) return fail("null handle");
+  if (ms_sum && count)
+    for (int k = 0; k < 3; ++k) { ms_sum[k] = o->prof_ms[k]; count[k] = o->prof_n[k]; }
+  if (enable != (o->prof ? 1 : 0)) {
+    o->prof = enable != 0;
+    for (int k = 0; k < 3; ++k) { o->prof_ms[k] = 0.0; o->prof_n[k] = 0; }
+  }
   return 0;
 }
 

@@ -33,7 +33,7 @@ from agimus_controller_amd.factory import robot_tables as rt  # noqa: E402
 HBM_PEAK = 8.0e12  # B/s, /opt/skills/guides/MI355X_MICROARCH.md "HBM3E peak BW"
 # Algorithmic doubles per node and launch (nv = 7): K1 read x,u + reference tile and
 # write the 673-double derivative tile; K2+K3 one Riccati backward + one linear forward; K4 one trial.
-ALGO_DOUBLES = {"calc_diff": 775, "direction": 778 + 448, "linesearch": 138}
+ALGO_DOUBLES = {"calc_qp": 775, "riccati": 778 + 448, "step": 138}
 
 
 def parse():
@@ -45,6 +45,7 @@ def parse():
     ap.add_argument("--horizon", type=int, default=100)
     ap.add_argument("--max-iter", type=int, default=10, help="SQP iteration cap (ROS default 10)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-batch1", action="store_true", help="skip the batch = 1 latency leg (profiling runs)")
     ap.add_argument("--cpu-instances", type=int, default=0, help="instances of the CPU sample (0 = 2 per core)")
     return ap.parse_args()
 
@@ -62,8 +63,9 @@ def cpu_baseline(args, table, tcp, po, n_steps=3):
     over the instances): a bounded sample of the workload (first instances, first steps)."""
     from oracle.oracle import Oracle  # test infrastructure: only this leg of bench.py uses it
 
-    cores = os.cpu_count() or 1
-    B = args.cpu_instances or 2 * cores
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = avail
+    B = args.cpu_instances or min(2 * avail, 256)
     T, dt = args.horizon, 0.01
     q0, amp, puls, scale, t0 = workloads.sine_batch_params(B, lower=table.lower_position_limit, upper=table.upper_position_limit)
     o = Oracle(table, po, B)
@@ -105,7 +107,16 @@ def cpu_baseline(args, table, tcp, po, n_steps=3):
     xs = np.stack([np.concatenate([p[0], p[1]], 1) for p in pts[: T + 1]], 1)
     us = np.stack([p[2] for p in pts[:T]], 1)
     x0 = xs[:, 0].copy()
-    o.solve(refs[0][:, :, :], None, x0, xs, us, 1, nthreads=cores)  # thread pool / page warm-up
+    # thread count: the best of a few candidates on one untimed iteration (big hosts oversubscribe easily)
+    best = None
+    for nt in sorted({min(avail, c) for c in (16, 32, 64, avail)}):
+        o.solve(refs[0], None, x0, xs, us, 1, nthreads=nt)  # thread pool / page warm-up
+        t0 = time.perf_counter()
+        o.solve(refs[0], None, x0, xs, us, 1, nthreads=nt)
+        el = time.perf_counter() - t0
+        if best is None or el < best[0]:
+            best = (el, nt)
+    cores = best[1]
     t_start = time.perf_counter()
     iters = []
     for k in range(n_steps):
@@ -142,7 +153,7 @@ def main():
     B, T, dt = args.batch, args.horizon, 0.01
     table, tcp, po = make_problem(T)
     hip = backend.HipOcp(table, po, B, device=local_rank)
-    n_points = args.warmup + args.steps + T + 2
+    n_points = args.warmup + args.steps + T + 2 + 10
     # per-instance seeds follow the GLOBAL instance index so every rank works on different instances
     q0, amp, puls, scale, t0 = workloads.sine_batch_params(B, seed0=1234 + rank * B, lower=table.lower_position_limit,
                                                            upper=table.upper_position_limit)
@@ -179,19 +190,33 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
-    # per-kernel device time, measured live with HIP events on the solver's stream
+    # per-kernel device time, measured live and in situ: a few more MPC steps of the same loop with
+    # HIP events around every launch on the solver's stream (outside the timed region above)
     kernels = {}
     if rank == 0:
-        nodes = {"calc_diff": B * T, "direction": B * (T + 1), "linesearch": B * (T + 1)}
-        for name, which in (("calc_diff", 3), ("direction", 1), ("linesearch", 2)):
-            ms = hip.time_kernel(which, 10)
+        nodes = {"calc_qp": B * T, "riccati": B * (T + 1), "step": B * (T + 1)}
+        hip.profile(True)
+        k0 = args.warmup + args.steps
+        for k in range(k0, k0 + min(10, T // 2)):
+            if k + T + 1 <= n_points:
+                step(k)
+        ms_sum, cnt = hip.profile(False)
+        for i, name in enumerate(("calc_qp", "riccati", "step")):
+            ms = ms_sum[i] / max(cnt[i], 1)
             algo = ALGO_DOUBLES[name] * 8 * nodes[name]
-            kernels[name] = {"ms": ms, "algorithmic_bytes": algo, "GBps": algo / (ms * 1e-3) / 1e9,
+            kernels[name] = {"ms": ms, "launches": cnt[i], "algorithmic_bytes": algo, "GBps": algo / (ms * 1e-3) / 1e9,
                              "frac_hbm": algo / (ms * 1e-3) / HBM_PEAK}
 
     result = None
     if rank == 0:
-        k1 = kernels["calc_diff"]
+        k1 = kernels["calc_qp"]
+        traffic = None
+        tfile = ROOT / "profiles" / "pmc_traffic.json"  # HBM bytes per launch from separate rocprofv3 --pmc passes
+        if tfile.exists():
+            try:
+                traffic = json.loads(tfile.read_text()).get(f"k_calc_qp_lj,B={B},T={T}")
+            except Exception:
+                traffic = None
         result = {
             "metric": "MPC steps/sec (horizon=100, Panda 7-DoF)",
             "value": world * B * args.steps / elapsed,
@@ -219,18 +244,35 @@ def main():
                 "step_includes": "window select, x0<-xs[1], warm-start shift, SQP solve, D2H of us[0],K[0],x1,status",
             },
             "roofline": {
-                "kernel": "k_calc_diff (node-parallel derivative pass, running nodes)",
+                "kernel": "k_calc_qp_lj (node-parallel derivative pass, running nodes, 8 lanes per node)",
                 "bound": "hbm",
                 "achieved": k1["GBps"],
                 "peak": HBM_PEAK / 1e9,
                 "unit": "GB/s",
                 "frac": k1["frac_hbm"],
-                "traffic": None,
+                "traffic": traffic,
                 "avg_launch_ms": k1["ms"],
                 "algorithmic_bytes_per_launch": k1["algorithmic_bytes"],
             },
             "kernels": kernels,
         }
+        if world == 1 and not args.no_batch1:
+            # BASELINE.json configs[1]: the same workload at batch = 1 (latency of one controller)
+            h1 = backend.HipOcp(table, po, 1, device=local_rank)
+            p1 = workloads.sine_batch_params(1, lower=table.lower_position_limit, upper=table.upper_position_limit)
+            h1.sine_trajectory(n_points, dt, *p1, w["w_q"], w["w_qdot"], w["w_effort"], w["w_pose"], tcp)
+            for k in range(args.warmup):
+                h1.mpc_step(k, args.max_iter, first=(k == 0))
+                h1.download_first()
+            h1.sync()
+            t1 = time.perf_counter()
+            for k in range(args.warmup, args.warmup + args.steps):
+                h1.mpc_step(k, args.max_iter, first=(k == 0))
+                h1.download_first()
+            h1.sync()
+            ms1 = (time.perf_counter() - t1) / args.steps * 1e3
+            result["batch1"] = {"ms_per_step": ms1, "value": 1e3 / ms1, "unit": "MPC steps/s", "workload": "same, batch = 1"}
+            h1.close()
         if not args.no_cpu_baseline and world == 1:
             try:
                 result["cpu_baseline"] = cpu_baseline(args, table, tcp, po)

@@ -210,6 +210,12 @@ int agx_ocp_direction(agx_ocp *ocp, double *K, double *k, double *dx, double *du
  * nodes only (one launch), 4 = canonical-tile derivative pass (running nodes).            */
 int agx_ocp_time_kernel(agx_ocp *ocp, int which, int reps, double *avg_ms);
 
+/* In-situ kernel timing: while enabled, every solve brackets the launches of its SQP loop with
+ * hipEvents on the problem's stream; ms_sum / count [3] return the accumulated device time and
+ * launch count of {derivative pass over the running nodes, Riccati backward + forward, step
+ * (per-node KKT + convergence test + line search)} since profiling was switched on.           */
+int agx_ocp_profile(agx_ocp *ocp, int enable, double *ms_sum, long long *count);
+
 /* ---- device-resident reference trajectory --------------- */
 /* Sine wave in configuration space, trajectories/sine_wave_configuration_space.py:41-72,
  * for B instances and n_points time samples t_k = t0[b] + k*dt, written as

@@ -4,6 +4,7 @@ db = sqlite3.connect(sys.argv[1]); cur = db.cursor()
 tabs = [r[0] for r in cur.execute("select name from sqlite_master where type in ('table','view')")]
 cols = [r[1] for r in cur.execute("pragma table_info(counters_collection)")]
 rows = cur.execute("select kernel_name, counter_name, sum(value), count(*) from counters_collection group by kernel_name, counter_name").fetchall() if "kernel_name" in cols else []
+raw = cur.execute("select kernel_name, counter_name, value from counters_collection").fetchall() if "kernel_name" in cols else []
 if not rows:
     print(cols); sys.exit()
 agg = collections.defaultdict(dict)
