@@ -52,6 +52,7 @@ struct agx_ocp {
   int qt_size = 0, aux_size = 0;
   bool k1_lanes = true;  // AGX_K1_LANES=0 selects the one-lane-per-node derivative kernel
   bool lanes_ok = true;  // problem fits the LDS staging of the 8-lanes-per-node kernel
+  bool speculate = true;  // AGX_SPECULATE_GAINS=0: gains sweep only on exit
   double *d_ref = nullptr;  // owned tile [B][T+1][stride]
   int *d_frames = nullptr;  // owned [B][T+1][AGX_MAX_ROWS]
   bool frames_set = false;
@@ -179,12 +180,16 @@ int launch_calc_qp(agx_ocp *o, bool running_only = false, bool term_only = false
   });
 }
 
-int launch_riccati(agx_ocp *o, int forward, int gains_pass) {
+// K2: direction sweep; with `pair` the speculative gains sweep of SQP iteration `iter` rides in the same launch
+int launch_riccati(agx_ocp *o, int forward, bool pair = false, int iter = 0) {
   return dispatch(o->nv, o->chain, [&](auto NVc, auto CHc) -> int {
     constexpr int NV = decltype(NVc)::value;
-    (void)gains_pass;
-    hipLaunchKernelGGL((agx::k_riccati<NV, false>), dim3(o->B), dim3(64), 0, o->stream, o->d_ocp, o->d_dt, o->d_qt, o->d_aux, o->d_Kws,
-                       o->d_kws, o->d_dx, o->d_w, o->d_du, o->d_Kout, o->d_state, forward);
+    if (pair)
+      hipLaunchKernelGGL((agx::k_riccati_pair<NV>), dim3(2 * o->B), dim3(64), 0, o->stream, o->d_ocp, o->d_dt, o->d_qt, o->d_aux,
+                         o->d_Kws, o->d_kws, o->d_dx, o->d_w, o->d_du, o->d_Kout, o->d_state, iter);
+    else
+      hipLaunchKernelGGL((agx::k_riccati<NV, false>), dim3(o->B), dim3(64), 0, o->stream, o->d_ocp, o->d_dt, o->d_qt, o->d_aux,
+                         o->d_Kws, o->d_kws, o->d_dx, o->d_w, o->d_du, o->d_Kout, o->d_state, forward, 0);
     HIPCHK(hipGetLastError());
     return 0;
   });
@@ -205,12 +210,13 @@ int launch_step(agx_ocp *o, int iter, int max_iter, int mode) {
   });
 }
 
-// exit path: the sigma (proximal) Riccati sweep that yields the gains the solver reports, one kernel
-int launch_gains(agx_ocp *o) {
+// exit path: the sigma (proximal) Riccati sweep that yields the gains the solver reports, one kernel.
+// gmode 0: every instance; 2: only instances whose last direction has no (speculative) sweep yet.
+int launch_gains(agx_ocp *o, int gmode = 0) {
   return dispatch(o->nv, o->chain, [&](auto NVc, auto CHc) -> int {
     constexpr int NV = decltype(NVc)::value;
     hipLaunchKernelGGL((agx::k_riccati<NV, true>), dim3(o->B), dim3(64), 0, o->stream, o->d_ocp, o->d_dt, o->d_qt, o->d_aux, o->d_Kws,
-                       o->d_kws, o->d_dx, o->d_w, o->d_du, o->d_Kout, o->d_state, 0);
+                       o->d_kws, o->d_dx, o->d_w, o->d_du, o->d_Kout, o->d_state, 0, gmode);
     HIPCHK(hipGetLastError());
     return 0;
   });
@@ -259,7 +265,8 @@ int solve_resident(agx_ocp *o, int max_iter, double max_time) {
     if (prof_mark(o, 0, false)) return -1;
     if (launch_calc_qp(o, false, true)) return -1;  // terminal nodes
     if (prof_mark(o, 1, true)) return -1;
-    if (launch_riccati(o, 1, 0)) return -1;
+    // from the second iteration on (where warm-started MPC steps converge) the gains sweep rides along
+    if (launch_riccati(o, 1, o->speculate && it >= 1, it)) return -1;
     if (prof_mark(o, 1, false)) return -1;
     if (prof_mark(o, 2, true)) return -1;
     if (launch_step(o, it, max_iter, 1)) return -1;
@@ -274,7 +281,7 @@ int solve_resident(agx_ocp *o, int max_iter, double max_time) {
       if (el > max_time) break;
     }
   }
-  if (launch_gains(o)) return -1;
+  if (launch_gains(o, 2)) return -1;  // instances whose last direction has no gains sweep yet
   return prof_collect(o);
 }
 
@@ -382,6 +389,7 @@ int agx_ocp_create(const agx_model *m, const agx_ocp_desc *d, int batch, int dev
   o->nv = m->h.nv; o->nx = 2 * o->nv; o->nu = o->nv;
   o->chain = m->h.is_chain != 0;
   if (const char *e = getenv("AGX_K1_LANES")) o->k1_lanes = (e[0] != '0');
+  if (const char *e = getenv("AGX_SPECULATE_GAINS")) o->speculate = (e[0] != '0');
   o->T = d->horizon; o->B = batch; o->device = device;
   o->tile = AGX_TILE_DOUBLES(o->nv);
   o->qt_size = 6 * o->nv * 8 + 48;   // QT<NV>::SIZE
@@ -736,7 +744,7 @@ int agx_ocp_time_kernel(agx_ocp *o, int which, int reps, double *avg_ms) {
   if (set_device(o)) return -1;
   // state for the timed kernel: fresh solver state, QP tiles and a direction at the resident point
   if (reset_state(o)) return -1;
-  if (which == 1 || which == 2 || which == 5 || which == 6) { if (launch_calc_qp(o)) return -1; }
+  if (which == 1 || which == 2 || which == 5 || which == 6 || which == 7) { if (launch_calc_qp(o)) return -1; }
   if (which == 2) { if (launch_riccati(o, 1, 0)) return -1; }
   // warm-up launch, then `reps` timed launches bracketed by events on the problem's stream
   for (int pass = 0; pass < 2; ++pass) {
@@ -751,6 +759,7 @@ int agx_ocp_time_kernel(agx_ocp *o, int which, int reps, double *avg_ms) {
       else if (which == 4) rc = launch_calc_diff(o, false, true);
       else if (which == 5) rc = launch_riccati(o, 0, 0);
       else if (which == 6) rc = launch_gains(o);
+      else if (which == 7) rc = launch_riccati(o, 1, true, 1);
       else return fail("agx_ocp_time_kernel: unknown kernel");
       if (rc) return rc;
     }

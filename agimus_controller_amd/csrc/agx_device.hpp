@@ -55,6 +55,20 @@ namespace agx {
 // Cross-lane moves on the VALU (no LDS traffic).  A DPP row is 16 lanes = two 8-lane groups.
 template <int CTRL, int BANK = 0xf>
 __device__ __forceinline__ int dpp_i32(int old, int x) { return __builtin_amdgcn_update_dpp(old, x, CTRL, 0xf, BANK, false); }
+// value of a compile-time-known lane, through the scalar unit (v_readlane) instead of the LDS crossbar
+__device__ __forceinline__ double readlane_f64(double x, int l) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(x), l), hi = __builtin_amdgcn_readlane(__double2hiint(x), l);
+  return __hiloint2double(hi, lo);
+}
+// LDS hand-off between lanes of ONE wave: DS operations of a wave execute in order, so only the
+// compiler has to be kept from reordering / caching across the hand-off (no s_barrier, and no
+// wait for the global stores a workgroup barrier would drag in).
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 template <int CTRL>
 __device__ __forceinline__ double dpp_mov(double x) {
   const int lo = __double2loint(x), hi = __double2hiint(x);

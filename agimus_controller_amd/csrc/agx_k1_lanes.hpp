@@ -76,14 +76,6 @@ __device__ __forceinline__ void store_row_pair(double *blk, int i, int l8, doubl
   *reinterpret_cast<double2 *>(blk + (even ? i : i + 1) * 8 + (l8 & 6)) = v;
 }
 
-// LDS hand-off between lanes of ONE wave: DS operations of a wave execute in order, so only the
-// compiler has to be kept from reordering / caching across the hand-off (no s_barrier, and no
-// wait for the global stores a workgroup barrier would drag in).
-__device__ __forceinline__ void wave_lds_sync() {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
 __device__ __forceinline__ double g_sum(double x) {
   x += __shfl_xor(x, 1, 8);
   x += __shfl_xor(x, 2, 8);

@@ -21,7 +21,8 @@ struct DevState {
   double preg, dreg;             // crocoddyl regularisation (reg_min 1e-9)
   int iter, qp_iters, solved, flags;
   int done;                      // 1: instance finished (solved, or regularisation saturated)
-  int need_gains;
+  int gains_iter;  // SQP iteration whose tiles the reported gains (Kout) were swept from (-1: none)
+  int dir_iter;    // SQP iteration of the last direction this instance computed
   double gains_preg, gains_dreg; // regularisation the last direction was computed with
 };
 
@@ -430,23 +431,29 @@ __device__ __forceinline__ double fast_rcp(double x) {
 // gradient recursion is skipped (it does not influence the gains) and the gains are mapped to
 // u-space in registers:  K = M Kw - taux  -> Kout.  No forward pass.
 template <int NV, bool GAINS>
-__global__ void __launch_bounds__(64) k_riccati(const DevOcp *__restrict__ op, const double *__restrict__ dts,
-                                                const double *__restrict__ qts, const double *__restrict__ auxs,
-                                                double *__restrict__ Kws, double *__restrict__ kws,
-                                                double *__restrict__ dxs, double *__restrict__ wss,
-                                                double *__restrict__ dus, double *__restrict__ Kout,
-                                                DevState *__restrict__ st, int forward) {
+__device__ __forceinline__ void riccati_body(const int b, const DevOcp *__restrict__ op, const double *__restrict__ dts,
+                                             const double *__restrict__ qts, const double *__restrict__ auxs,
+                                             double *__restrict__ Kws, double *__restrict__ kws,
+                                             double *__restrict__ dxs, double *__restrict__ wss,
+                                             double *__restrict__ dus, double *__restrict__ Kout,
+                                             DevState *__restrict__ st, int forward, int gmode, int iter) {
   constexpr int gains_pass = GAINS ? 1 : 0;
   typedef AUX<NV> A;
-  static_assert(NV <= 8, "the register-resident Riccati kernel maps an NV x NV block onto an 8 x 8 lane grid");
+  static_assert(NV <= 7, "the register-resident Riccati kernel maps an NV x NV block plus a gradient column onto an 8 x 8 lane grid");
   constexpr int NX = 2 * NV, TS = QT<NV>::SIZE;
   typedef QT<NV> Q;
   const DevOcp &o = *op;
-  const int T = o.T, b = blockIdx.x, lane = threadIdx.x;
+  const int T = o.T, lane = threadIdx.x;
   DevState &S = st[b];
-  // gains pass (on exit): every instance, with the regularisation its last direction was computed with
+  // direction sweep: live instances.  Gains sweep, by gmode:
+  //   0  every instance (agx_ocp_direction, timing), with the regularisation of its last direction;
+  //   1  speculative, launched next to the direction sweep of SQP iteration `iter`: live instances, same dreg;
+  //   2  fix-up on exit: only instances whose last direction (dir_iter) has no sweep yet.
   if (!gains_pass && S.done) return;
-  const double dreg = gains_pass ? (S.solved ? S.dreg : S.gains_dreg) : S.dreg;
+  if (gains_pass && gmode == 1 && S.done) return;
+  if (gains_pass && gmode == 2 && S.gains_iter == S.dir_iter) return;
+  const double dreg = (gains_pass && gmode != 1) ? (S.solved ? S.dreg : S.gains_dreg) : S.dreg;
+  if (gains_pass && gmode != 0 && lane == 0) S.gains_iter = (gmode == 1) ? iter : S.dir_iter;
   const double *qb = qts + (long long)b * (T + 1) * TS;
   const double *ab = auxs + (long long)b * (T + 1) * A::SIZE;
   double *Kw = Kws + (long long)b * T * NV * NX, *kw = kws + (long long)b * T * NV;
@@ -472,20 +479,27 @@ __global__ void __launch_bounds__(64) k_riccati(const DevOcp *__restrict__ op, c
   // tile elements of a node, prefetched TWO nodes ahead into two register sets
   struct Tile {
     double hqq, hqv, hvq, hvv, hqw, hvw, hwq, hwv, hww, gq, gv, gwr, fq, fv;
-    double aMr[NV], aMc[NV], aqr[NV], aqc[NV], avr[NV], avc[NV], atq, atv;  // GAINS: columns r, c of M, tq, tv
+  };
+  // GAINS: the aux blocks M | tq | tv of a node (contiguous, 3 * NV * LD doubles) travel
+  // global -> three registers (one node ahead) -> LDS (double buffered); every lane then reads
+  // the columns it needs as LDS broadcasts instead of holding 6 * NV prefetched values.
+  constexpr int AXN = 3 * A::B2;
+  __shared__ double s_aux[GAINS ? 2 : 1][GAINS ? AXN : 1];
+  double axr0 = 0.0, axr1 = 0.0, axr2 = 0.0;
+  auto aux_fetch = [&](int t) {
+    const double *al = ab + (long long)t * A::SIZE + A::M;
+    axr0 = (lane < AXN) ? al[lane] : 0.0;
+    axr1 = (64 + lane < AXN) ? al[64 + lane] : 0.0;
+    axr2 = (128 + lane < AXN) ? al[128 + lane] : 0.0;
+  };
+  auto aux_put = [&](int t) {
+    double *sa = s_aux[GAINS ? (t & 1) : 0];
+    if (lane < AXN) sa[lane] = axr0;
+    if (64 + lane < AXN) sa[64 + lane] = axr1;
+    if (128 + lane < AXN) sa[128 + lane] = axr2;
   };
   auto load_tile = [&](Tile &z, int t) {
     const double *tl = qb + (long long)t * TS;
-    if (GAINS) {
-      const double *al = ab + (long long)t * A::SIZE;
-#pragma unroll
-      for (int l = 0; l < NV; ++l) {
-        z.aMr[l] = al[A::M + l * A::LD + rr]; z.aMc[l] = al[A::M + l * A::LD + cc];
-        z.aqr[l] = al[A::tq + l * A::LD + rr]; z.aqc[l] = al[A::tq + l * A::LD + cc];
-        z.avr[l] = al[A::tv + l * A::LD + rr]; z.avc[l] = al[A::tv + l * A::LD + cc];
-      }
-      z.atq = al[A::tq + rc]; z.atv = al[A::tv + rc];
-    }
     z.hqq = tl[Q::Hqq + rc]; z.hqv = tl[Q::Hqv + rc]; z.hvq = tl[Q::Hqv + cr]; z.hvv = tl[Q::Hvv + rc];
     z.hqw = tl[Q::Hqw + rc]; z.hvw = tl[Q::Hvw + rc]; z.hwq = tl[Q::Hqw + cr]; z.hwv = tl[Q::Hvw + cr];
     z.hww = tl[Q::Hww + rc];
@@ -502,30 +516,44 @@ __global__ void __launch_bounds__(64) k_riccati(const DevOcp *__restrict__ op, c
     const double fq_ = (c < NV && !GAINS) ? z.fq : 0.0, fv_ = (c < NV && !GAINS) ? z.fv : 0.0;
     double Mr_[NV], tq_rc = 0.0, tv_rc = 0.0;
     if (GAINS) {
+      // aux pipeline: registers hold node t-1 (fetched during the previous step) -> LDS; fetch node t-2
+      wave_lds_sync();
+      if (t >= 1) aux_put(t - 1);
+      if (t >= 2) aux_fetch(t - 2);
+      wave_lds_sync();
+      const double *sa = s_aux[GAINS ? (t & 1) : 0];
       // sigma [taux M]' [taux M] at [r][c] (and at [c][r] for the transposed blocks), sigma I on Hxx
       double xww = 0.0, xqw = 0.0, xwq = 0.0, xvw = 0.0, xwv = 0.0, xqq = 0.0, xqv = 0.0, xvq = 0.0, xvv = 0.0;
 #pragma unroll
       for (int l = 0; l < NV; ++l) {
-        xww += z.aMr[l] * z.aMc[l];
-        xqw += z.aqr[l] * z.aMc[l]; xwq += z.aMr[l] * z.aqc[l];
-        xvw += z.avr[l] * z.aMc[l]; xwv += z.aMr[l] * z.avc[l];
-        xqq += z.aqr[l] * z.aqc[l]; xqv += z.aqr[l] * z.avc[l]; xvq += z.avr[l] * z.aqc[l]; xvv += z.avr[l] * z.avc[l];
-        Mr_[l] = z.aMr[l];
+        const double aMr = sa[A::M + l * A::LD + rr], aMc = sa[A::M + l * A::LD + cc];
+        const double aqr = sa[A::tq + l * A::LD + rr], aqc = sa[A::tq + l * A::LD + cc];
+        const double avr = sa[A::tv + l * A::LD + rr], avc = sa[A::tv + l * A::LD + cc];
+        xww += aMr * aMc;
+        xqw += aqr * aMc; xwq += aMr * aqc;
+        xvw += avr * aMc; xwv += aMr * avc;
+        xqq += aqr * aqc; xqv += aqr * avc; xvq += avr * aqc; xvv += avr * avc;
+        Mr_[l] = aMr;
       }
       Hww_ += sig * xww; Hqw_ += sig * xqw; Hwq_ += sig * xwq; Hvw_ += sig * xvw; Hwv_ += sig * xwv;
       Hqq_ += sig * (xqq + diag); Hqv_ += sig * xqv; Hvq_ += sig * xvq; Hvv_ += sig * (xvv + diag);
-      tq_rc = z.atq; tv_rc = z.atv;
+      tq_rc = sa[A::tq + rc]; tv_rc = sa[A::tv + rc];
     }
     if (t >= 2) load_tile(z, t - 2);
     // ---- phase A
-    // vp = vx + V f  (row reduction over c)
-    double pq = Vqq * fq_ + Vqv * fv_, pv = Vvq * fq_ + Vvv * fv_;
-#pragma unroll
-    for (int off = 1; off < 8; off <<= 1) {
-      pq += __shfl_xor(pq, off, 64);
-      pv += __shfl_xor(pv, off, 64);
+    // The gradient rides in the spare grid column c = 7 of the w column block (NV <= 7):
+    // lane (r, 7) keeps qw[r] in Mww, qx[r] in Mqw / Mvw, so the pivots below update it like any
+    // other column and no separate broadcast of the pivot row's gradient is needed.
+    const bool gcol = !GAINS && (c == 7) && (r < NV);
+    double vpq = 0.0, vpv = 0.0;
+    if (!GAINS) {
+      // vp = vx + V f  (row reduction over c; lanes outside the block contribute zeros)
+      double pq = Vqq * fq_ + Vqv * fv_, pv = Vvq * fq_ + Vvv * fv_;
+      pq += dpp_xor1(pq); pv += dpp_xor1(pv);
+      pq += dpp_xor2(pq); pv += dpp_xor2(pv);
+      pq += dpp_xor4(pq); pv += dpp_xor4(pv);
+      vpq = vxq + pq; vpv = vxv + pv;
     }
-    const double vpq = vxq + pq, vpv = vxv + pv;
     // Y = G' V  (rows indexed by the acceleration variable):  Yq = h^2 Vqq + h Vvq, Yv = h^2 Vqv + h Vvv
     const double Yq = h2 * Vqq + h * Vvq, Yv = h2 * Vqv + h * Vvv;
     // Y' at [r][c]: Yq'[r][c] = Yq[c][r] = h^2 Vqq + h Vqv ; Yv'[r][c] = Yv[c][r] = h^2 Vvq + h Vvv
@@ -537,39 +565,39 @@ __global__ void __launch_bounds__(64) k_riccati(const DevOcp *__restrict__ op, c
     double Mqv = Hqv_ + h * Vqq + Vqv;
     double Mvq = Hvq_ + h * Vqq + Vvq;
     double Mvv = Hvv_ + h2 * Vqq + h * (Vqv + Vvq) + Vvv;
-    double gW = gw_ + h2 * vpq + h * vpv;   // qw[r]
-    double gQ = gq_ + vpq;                  // qx = gx + Phi' vp
-    double gV = gv_ + h * vpq + vpv;
     if (!in) { Mww = diag; Mwq = 0.0; Mwv = 0.0; Mqw = 0.0; Mvw = 0.0; Mqq = 0.0; Mqv = 0.0; Mvq = 0.0; Mvv = 0.0; }
-    if (r >= NV) { gW = 0.0; gQ = 0.0; gV = 0.0; }
+    if (gcol) {
+      Mww = gw_ + h2 * vpq + h * vpv;  // qw[r]
+      Mqw = gq_ + vpq;                 // qx = gx + Phi' vp
+      Mvw = gv_ + h * vpq + vpv;
+    }
     // ---- phase B: Gauss-Jordan pivots k = 0..NV-1 in the ww block
     double rp_row = 1.0;
     auto pivot = [&](auto Kc) {
       constexpr int k = decltype(Kc)::value;
       if (k >= NV) return;
-      const double piv = __shfl(Mww, 9 * k, 64);
-      const double rp = fast_rcp(piv);
-      const double gk = __shfl(gW, 8 * k, 64);
-      // column k of my row (three row blocks: DPP), row k of my column (three column blocks: bpermute)
-      const double cw = grid_col<k>(Mww), cq = grid_col<k>(Mqw), cv = grid_col<k>(Mvw);
+      // row k of my column (three column blocks: bpermute), column k of my row (three row blocks: DPP)
       const double rw = __shfl(Mww, 8 * k + col_lane, 64), rq = __shfl(Mwq, 8 * k + col_lane, 64), rv2 = __shfl(Mwv, 8 * k + col_lane, 64);
+      const double cw = grid_col<k>(Mww), cq = grid_col<k>(Mqw), cv = grid_col<k>(Mvw);
+      const double piv = readlane_f64(Mww, 9 * k);  // wave-uniform: scalar broadcast
+      const double rp = fast_rcp(piv);
       const double fw = (r == k) ? 0.0 : cw * rp;  // the pivot row itself is left untouched
       const double fqx = cq * rp, fvx = cv * rp;
-      Mww -= fw * rw; Mwq -= fw * rq; Mwv -= fw * rv2; gW -= fw * gk;
-      Mqw -= fqx * rw; Mqq -= fqx * rq; Mqv -= fqx * rv2; gQ -= fqx * gk;
-      Mvw -= fvx * rw; Mvq -= fvx * rq; Mvv -= fvx * rv2; gV -= fvx * gk;
+      Mww -= fw * rw; Mwq -= fw * rq; Mwv -= fw * rv2;
+      Mqw -= fqx * rw; Mqq -= fqx * rq; Mqv -= fqx * rv2;
+      Mvw -= fvx * rw; Mvq -= fvx * rq; Mvv -= fvx * rv2;
       if (r == k) rp_row = rp;
     };
     pivot(std::integral_constant<int, 0>()); pivot(std::integral_constant<int, 1>()); pivot(std::integral_constant<int, 2>());
     pivot(std::integral_constant<int, 3>()); pivot(std::integral_constant<int, 4>()); pivot(std::integral_constant<int, 5>());
-    pivot(std::integral_constant<int, 6>()); pivot(std::integral_constant<int, 7>());
-    // gains of this node: Kw = D^-1 [Mwq Mwv], kw = D^-1 gW
+    pivot(std::integral_constant<int, 6>());
+    // gains of this node: Kw = D^-1 [Mwq Mwv], kw = D^-1 qw
     if (!GAINS) {
       if (in) {
         Kw[(long long)t * NV * NX + r * NX + c] = Mwq * rp_row;
         Kw[(long long)t * NV * NX + r * NX + NV + c] = Mwv * rp_row;
       }
-      if (c == 0 && r < NV) kw[(long long)t * NV + r] = gW * rp_row;
+      if (gcol) kw[(long long)t * NV + r] = Mww * rp_row;
     } else {
       // u-space gains  K = M Kw - taux : row r of M against column c of Kw
       const double kq = Mwq * rp_row, kv = Mwv * rp_row;
@@ -584,12 +612,14 @@ __global__ void __launch_bounds__(64) k_riccati(const DevOcp *__restrict__ op, c
         Ko[(long long)t * NV * NX + r * NX + NV + c] = Kv;
       }
     }
+    // gradient of the value function of node t (lanes of the gradient column)
+    vxq = Mqw; vxv = Mvw;
     // value function of node t
     Vqq = Mqq + dreg * diag; Vqv = Mqv; Vvq = Mvq; Vvv = Mvv + dreg * diag;  // (sigma is part of H at every node)
     if (!in) { Vqq = 0.0; Vqv = 0.0; Vvq = 0.0; Vvv = 0.0; }
-    vxq = gQ; vxv = gV;
   };
   Tile ta, tb;
+  if (GAINS) { aux_fetch(T - 1); aux_put(T - 1); if (T >= 2) aux_fetch(T - 2); }
   load_tile(ta, T - 1);
   if (T >= 2) load_tile(tb, T - 2);
   for (int t = T - 1; t >= 0; t -= 2) {
@@ -617,8 +647,8 @@ __global__ void __launch_bounds__(64) k_riccati(const DevOcp *__restrict__ op, c
     double w0 = -g.kw, w1 = 0.0;  // two accumulation chains
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
-      w0 -= g.k[j] * __shfl(dq, j, 64);
-      w1 -= g.k[NV + j] * __shfl(dv, j, 64);
+      w0 -= g.k[j] * readlane_f64(dq, j);
+      w1 -= g.k[NV + j] * readlane_f64(dv, j);
     }
     const double wv = w0 + w1, fqc = g.fq, fvc = g.fv;
     if (t + 4 < T) load_gain(g, t + 4);  // refill this register set four nodes ahead
@@ -642,6 +672,33 @@ __global__ void __launch_bounds__(64) k_riccati(const DevOcp *__restrict__ op, c
     if (t + 2 < T) fstep(g2, t + 2);
     if (t + 3 < T) fstep(g3, t + 3);
   }
+}
+
+template <int NV, bool GAINS>
+__global__ void __launch_bounds__(64) k_riccati(const DevOcp *__restrict__ op, const double *__restrict__ dts,
+                                                const double *__restrict__ qts, const double *__restrict__ auxs,
+                                                double *__restrict__ Kws, double *__restrict__ kws,
+                                                double *__restrict__ dxs, double *__restrict__ wss,
+                                                double *__restrict__ dus, double *__restrict__ Kout,
+                                                DevState *__restrict__ st, int forward, int gmode) {
+  riccati_body<NV, GAINS>(blockIdx.x, op, dts, qts, auxs, Kws, kws, dxs, wss, dus, Kout, st, forward, gmode, 0);
+}
+
+// Direction sweep and speculative gains sweep of one SQP iteration in ONE launch: both are latency
+// bound at one wave per SIMD, so the second wave rides along almost for free.  Even workgroups run
+// the direction, odd ones the sigma sweep of the same instance; they share only read-only inputs.
+template <int NV>
+__global__ void __launch_bounds__(64) k_riccati_pair(const DevOcp *__restrict__ op, const double *__restrict__ dts,
+                                                     const double *__restrict__ qts, const double *__restrict__ auxs,
+                                                     double *__restrict__ Kws, double *__restrict__ kws,
+                                                     double *__restrict__ dxs, double *__restrict__ wss,
+                                                     double *__restrict__ dus, double *__restrict__ Kout,
+                                                     DevState *__restrict__ st, int iter) {
+  const int b = blockIdx.x >> 1;
+  if (blockIdx.x & 1)
+    riccati_body<NV, true>(b, op, dts, qts, auxs, Kws, kws, dxs, wss, dus, Kout, st, 0, 1, iter);
+  else
+    riccati_body<NV, false>(b, op, dts, qts, auxs, Kws, kws, dxs, wss, dus, Kout, st, 1, 0, iter);
 }
 
 // ---------------------------------------------------------------------------
@@ -757,6 +814,7 @@ __global__ void __launch_bounds__(128) k_step(const DevModel *__restrict__ mp, c
     double kk = 0.0, cc = 0.0, gg = 0.0;
     for (int w = 0; w < nw; ++w) { kk = fmax(kk, red[w]); cc += red[2 + w]; gg += red[4 + w]; }
     S.kkt = kk; S.cost = cc; S.gap = gg; S.merit = cc + o.mu_dyn * gg; S.qp_iters = 1;
+    if (!(mode & 4)) S.dir_iter = iter;
     if (!(kk == kk)) S.flags |= 1;
     const bool conv = (kk <= o.tol) && (mode & 1) && !(mode & 4);
     if (conv) { S.solved = 1; S.done = 1; S.iter = iter; atomicAdd(n_done, 1); }
@@ -849,108 +907,6 @@ __global__ void __launch_bounds__(128) k_step(const DevModel *__restrict__ mp, c
 }
 
 // ---------------------------------------------------------------------------
-// Exit path: gains reported by the solver = CSQP's proximal (sigma) backward pass around the
-// last direction.  k_sigma_tile rewrites the QP tiles in place with the sigma terms, k_riccati
-// (backward only) gives Kw, k_gains_to_u maps them to u-space: K = M Kw - taux.
-// ---------------------------------------------------------------------------
-// 8 lanes per node, lane j computes column j of every block (M, tq, tv staged through LDS).
-template <int NV>
-__global__ void __launch_bounds__(128) k_sigma_tile(const DevOcp *__restrict__ op, double *__restrict__ qts,
-                                                    const double *__restrict__ auxs, const double *__restrict__ dxs,
-                                                    const double *__restrict__ dus) {
-  constexpr int NX = 2 * NV, LD = 8, B2 = NV * LD;
-  typedef QT<NV> Q;
-  typedef AUX<NV> A;
-  __shared__ double lds[16][3 * B2 + 2];
-  const DevOcp &o = *op;
-  const int T = o.T;
-  const int l8 = threadIdx.x & 7, g = threadIdx.x >> 3;
-  const long long n_nodes = (long long)o.B * (T + 1);
-  const long long node = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 3;
-  const bool ok = node < n_nodes;
-  const long long unit = ok ? node : 0;
-  const int b = (int)(unit / (T + 1)), t = (int)(unit % (T + 1));
-  double *qt = qts + unit * Q::SIZE;
-  const double *ax = auxs + unit * A::SIZE;
-  const double *dx = dxs + unit * NX;
-  const double sig = kSigma;  // (preg is already folded into the tile by k_calc_qp)
-  const bool jl = l8 < NV, wr = ok && jl;
-  const int j = jl ? l8 : 0;
-  // stage M | tq | tv (contiguous in the aux tile)
-  double *sh = lds[g];
-  for (int e = l8; e < 3 * B2; e += 8) sh[e] = ax[A::M + e];
-  __syncthreads();
-  if (wr) {
-    qt[Q::Hqq + j * Q::LD + j] += sig;
-    qt[Q::Hvv + j * Q::LD + j] += sig;
-  }
-  double gq = dx[j], gv = dx[NV + j], gwv = 0.0;
-  if (t < T) {
-    const double *du = dus + ((long long)b * T + t) * NV;
-    const double *Mm = sh, *tq = sh + B2, *tv = sh + 2 * B2;
-    double Mc[NV], tqc[NV], tvc[NV];
-#pragma unroll
-    for (int l = 0; l < NV; ++l) {
-      Mc[l] = Mm[l * LD + j]; tqc[l] = tq[l * LD + j]; tvc[l] = tv[l * LD + j];
-      const double dul = du[l];
-      gwv += Mc[l] * dul; gq += tqc[l] * dul; gv += tvc[l] * dul;
-    }
-#pragma unroll
-    for (int i = 0; i < NV; ++i) {
-      double hww = 0.0, hqw = 0.0, hvw = 0.0, hqq = 0.0, hqv = 0.0, hvv = 0.0;
-#pragma unroll
-      for (int l = 0; l < NV; ++l) {
-        const double Mil = Mm[i * LD + l], tqli = tq[l * LD + i], tvli = tv[l * LD + i];
-        hww += Mil * Mc[l]; hqw += tqli * Mc[l]; hvw += tvli * Mc[l];
-        hqq += tqli * tqc[l]; hqv += tqli * tvc[l]; hvv += tvli * tvc[l];
-      }
-      if (wr) {
-        qt[Q::Hww + i * Q::LD + j] += sig * hww;
-        qt[Q::Hqw + i * Q::LD + j] += sig * hqw;
-        qt[Q::Hvw + i * Q::LD + j] += sig * hvw;
-        qt[Q::Hqq + i * Q::LD + j] += sig * hqq;
-        qt[Q::Hqv + i * Q::LD + j] += sig * hqv;
-        qt[Q::Hvv + i * Q::LD + j] += sig * hvv;
-      }
-    }
-  }
-  if (wr) {
-    qt[Q::gw + j] -= sig * gwv;
-    qt[Q::gx + j] -= sig * gq;
-    qt[Q::gx + NV + j] -= sig * gv;
-  }
-}
-
-// K = M Kw - taux: one lane per (node, column of K)
-template <int NV>
-__global__ void __launch_bounds__(256) k_gains_to_u(const DevOcp *__restrict__ op, const double *__restrict__ auxs,
-                                                    const double *__restrict__ Kws, double *__restrict__ Kout) {
-  constexpr int NX = 2 * NV;
-  typedef AUX<NV> A;
-  const DevOcp &o = *op;
-  const int T = o.T;
-  const long long unit = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  const long long node = unit >> 4;  // 16 lanes per node, NX <= 16 of them active
-  const int j = (int)(unit & 15);
-  if (node >= (long long)o.B * T || j >= NX) return;
-  const int b = (int)(node / T), t = (int)(node % T);
-  const double *ax = auxs + ((long long)b * (T + 1) + t) * A::SIZE;
-  const double *Kw = Kws + node * NV * NX;
-  double *K = Kout + node * NV * NX;
-  const double *tx = (j < NV) ? ax + A::tq + j : ax + A::tv + (j - NV);
-  double kc[NV];
-#pragma unroll
-  for (int l = 0; l < NV; ++l) kc[l] = Kw[l * NX + j];
-#pragma unroll
-  for (int i = 0; i < NV; ++i) {
-    double acc = -tx[i * A::LD];
-#pragma unroll
-    for (int l = 0; l < NV; ++l) acc += ax[A::M + i * A::LD + l] * kc[l];
-    K[i * NX + j] = acc;
-  }
-}
-
-// ---------------------------------------------------------------------------
 // small utilities
 // ---------------------------------------------------------------------------
 __global__ void k_reset_state(DevState *st, int B, int *n_done) {
@@ -960,7 +916,7 @@ __global__ void k_reset_state(DevState *st, int B, int *n_done) {
   DevState s;
   s.kkt = 0.0; s.cost = 0.0; s.merit = 0.0; s.gap = 0.0;
   s.preg = kRegMin; s.dreg = kRegMin;
-  s.iter = 0; s.qp_iters = 0; s.solved = 0; s.flags = 0; s.done = 0; s.need_gains = 0;
+  s.iter = 0; s.qp_iters = 0; s.solved = 0; s.flags = 0; s.done = 0; s.gains_iter = -1; s.dir_iter = -1;
   s.gains_preg = kRegMin; s.gains_dreg = kRegMin;
   st[b] = s;
 }

@@ -11,7 +11,7 @@ reps = B // 4
 hb = backend.HipOcp(tab, po, B)
 hb.set_refs(np.tile(ref, (reps, 1, 1))); hb.upload_x0(np.tile(x0, (reps, 1))); hb.upload_warmstart(np.tile(xs, (reps, 1, 1)), np.tile(us, (reps, 1, 1)))
 out = []
-for which, name in ((3, "calc_qp"), (0, "calc_qp+term"), (1, "riccati"), (5, "ric_bwd"), (6, "gains"), (2, "step")):
+for which, name in ((3, "calc_qp"), (0, "calc_qp+term"), (1, "riccati"), (5, "ric_bwd"), (6, "gains"), (7, "pair"), (2, "step")):
     ms = min(hb.time_kernel(which, 10) for _ in range(3))
     out.append(f"{name} {ms*1e3:.1f}us")
 print(os.environ.get("AGX_LIB", "default"), "B", B, " | ".join(out))
