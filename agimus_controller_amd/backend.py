@@ -25,7 +25,7 @@ EXPORTED_SYMBOLS = [
     "agx_last_error", "agx_device_count", "agx_row_nref", "agx_row_nr", "agx_ref_stride",
     "agx_model_create", "agx_model_destroy", "agx_ocp_create", "agx_ocp_destroy", "agx_ocp_set_stream",
     "agx_ocp_sync", "agx_ocp_set_refs", "agx_ocp_set_refs_device", "agx_ocp_solve", "agx_ocp_upload_x0",
-    "agx_ocp_upload_warmstart", "agx_ocp_solve_resident", "agx_ocp_download", "agx_ocp_download_first",
+    "agx_ocp_upload_warmstart", "agx_ocp_solve_resident", "agx_ocp_download", "agx_ocp_download_first", "agx_ocp_first_packed",
     "agx_ocp_shift_warmstart", "agx_ocp_x0_from_prediction", "agx_ocp_integrate", "agx_model_rnea",
     "agx_model_frame_placement", "agx_ocp_get_residuals", "agx_ocp_calc_diff", "agx_ocp_direction",
     "agx_ocp_time_kernel", "agx_ocp_profile", "agx_traj_sine_create", "agx_traj_set_window",
@@ -171,12 +171,35 @@ class HipOcp:
         _chk(lib().agx_ocp_download(self._h, _p(xs), _p(us), _p(K), _p(st)))
         return xs, us, K, st
 
-    def download_first(self, want_status=True):
-        us0 = np.empty((self.B, self.nu))
-        K0 = np.empty((self.B, self.nu, self.nx))
-        x1 = np.empty((self.B, self.nx))
-        st = np.zeros(self.B, dtype=_abi.STATUS_DTYPE) if want_status else None
-        _chk(lib().agx_ocp_download_first(self._h, _p(us0), _p(K0), _p(x1), _p(st)))
+    def download_first(self, want_status=True, copy=True):
+        """us[0], K[0], xs[1] (+ status) of every instance: one packed transfer into the handle's
+        pinned buffer.  copy=False returns views into that buffer, valid until the next call."""
+        ptr = C.POINTER(C.c_double)()
+        stride = C.c_int(0)
+        _chk(lib().agx_ocp_first_packed(self._h, C.byref(ptr), C.byref(stride)))
+        addr = C.addressof(ptr.contents)
+        cached = getattr(self, "_first_view", None)
+        if cached is None or cached[0] != addr:
+            cached = (addr, np.ctypeslib.as_array(ptr, shape=(self.B, stride.value)))
+            self._first_view = cached  # the pinned buffer lives as long as the handle
+        buf = cached[1]
+        nu, nx = self.nu, self.nx
+        nk = nu * nx
+        us0 = buf[:, :nu]
+        K0 = buf[:, nu:nu + nk].reshape(self.B, nu, nx)
+        x1 = buf[:, nu + nk:nu + nk + nx]
+        if copy:
+            us0, K0, x1 = us0.copy(), K0.copy(), x1.copy()
+        st = None
+        if want_status:
+            q = buf[:, nu + nk + nx:]
+            names = ("kkt", "cost", "merit", "gap_norm", "iter", "qp_iters", "solved", "flags")
+            if copy:
+                st = np.zeros(self.B, dtype=_abi.STATUS_DTYPE)
+                for k, name in enumerate(names):
+                    st[name] = q[:, k] if k < 4 else q[:, k].astype(np.int32)
+            else:
+                st = {name: q[:, k] for k, name in enumerate(names)}  # views (float64) into the pinned buffer
         return us0, K0, x1, st
 
     def shift_warmstart(self):

@@ -58,7 +58,12 @@ struct agx_ocp {
   bool frames_set = false;
   DevState *d_state = nullptr;
   int *d_ndone = nullptr;
-  int *h_ndone = nullptr;  // pinned
+  int *h_ndone = nullptr;  // pinned; [0] finished-instance count, [1] its sequence stamp, [2] stamp of the packed results
+  int *h_ndone_dev = nullptr;  // the same words as the device sees them (mapped host memory)
+  int seq = 0;
+  bool poll = true;  // AGX_HOST_POLL=0: stream-ordered copies + synchronize instead of polled mapped words
+  double *d_first = nullptr, *h_first = nullptr;  // packed first-node results [B][first_stride], device / pinned host
+  int first_stride = 0;
   double *d_scratch = nullptr;
   size_t scratch_bytes = 0;
   RefView rv{};
@@ -66,7 +71,7 @@ struct agx_ocp {
   double *d_traj = nullptr, *d_pts = nullptr;
   double *d_sine = nullptr;  // q0, amp, puls, scale, t0
   int n_points = 0;
-  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_done = nullptr;
   int last_max_iter = 0;
   // in-situ kernel timing (agx_ocp_profile): event pairs around the launches of the SQP loop
   bool prof = false;
@@ -252,6 +257,29 @@ int prof_collect(agx_ocp *o) {
   return 0;
 }
 
+// Hand-off of one word from the stream to the host without a copy or a synchronize: a one-thread
+// kernel stores value and sequence stamp into mapped pinned memory, the host spins on the stamp.
+int publish(agx_ocp *o, int slot_value, int slot_seq, const int *d_value, int seq) {
+  hipLaunchKernelGGL(agx::k_publish, dim3(1), dim3(1), 0, o->stream, d_value, o->h_ndone_dev + slot_value, o->h_ndone_dev + slot_seq, seq);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+int wait_stamp(agx_ocp *o, int slot_seq, int seq) {
+  volatile int *w = o->h_ndone + slot_seq;
+  for (unsigned long spins = 1;; ++spins) {
+    if (__atomic_load_n(w, __ATOMIC_ACQUIRE) == seq) return 0;
+    if ((spins & 0x3FFF) == 0) {  // every so often make sure the stream is still alive
+      const hipError_t e = hipStreamQuery(o->stream);
+      if (e == hipSuccess) {
+        if (__atomic_load_n(w, __ATOMIC_ACQUIRE) == seq) return 0;
+        return fail("stream drained without publishing its stamp");
+      }
+      if (e != hipErrorNotReady) return fail(std::string("stream error while waiting: ") + hipGetErrorString(e));
+    }
+    __builtin_ia32_pause();
+  }
+}
+
 // The SQP loop of SolverCSQP::solve on the resident buffers.
 int solve_resident(agx_ocp *o, int max_iter, double max_time) {
   if (max_iter <= 0) max_iter = 1000;
@@ -259,10 +287,18 @@ int solve_resident(agx_ocp *o, int max_iter, double max_time) {
   auto t0 = std::chrono::steady_clock::now();
   if (reset_state(o)) return -1;
   hipLaunchKernelGGL(agx::k_pin_x0, dim3((o->B * o->nx + 255) / 256), dim3(256), 0, o->stream, o->d_xs, o->d_x0, o->B, o->T, o->nx);
+  // The derivative pass of iteration it+1 is enqueued BEFORE the host waits for iteration it's
+  // "everyone finished" word: it skips finished instances, so when the loop ends it was an empty
+  // launch, and when it does not the GPU never idles over the host round trip.
+  const bool ahead = !o->prof && max_time <= 0.0;
+  bool k1_queued = false;
   for (int it = 0; it < max_iter; ++it) {
-    if (prof_mark(o, 0, true)) return -1;
-    if (launch_calc_qp(o, true, false)) return -1;  // running nodes: the node-parallel derivative pass
-    if (prof_mark(o, 0, false)) return -1;
+    if (!k1_queued) {
+      if (prof_mark(o, 0, true)) return -1;
+      if (launch_calc_qp(o, true, false)) return -1;  // running nodes: the node-parallel derivative pass
+      if (prof_mark(o, 0, false)) return -1;
+    }
+    k1_queued = false;
     if (launch_calc_qp(o, false, true)) return -1;  // terminal nodes
     if (prof_mark(o, 1, true)) return -1;
     // from the second iteration on (where warm-started MPC steps converge) the gains sweep rides along
@@ -273,9 +309,21 @@ int solve_resident(agx_ocp *o, int max_iter, double max_time) {
     if (prof_mark(o, 2, false)) return -1;
     if (it + 1 == max_iter) break;
     // early exit once every instance has finished (one 4-byte read back)
-    HIPCHK(hipMemcpyAsync(o->h_ndone, o->d_ndone, sizeof(int), hipMemcpyDeviceToHost, o->stream));
-    HIPCHK(hipStreamSynchronize(o->stream));
-    if (*o->h_ndone >= o->B) break;
+    const int seq = ++o->seq;
+    if (o->poll) {
+      if (publish(o, 0, 1, o->d_ndone, seq)) return -1;
+    } else {
+      HIPCHK(hipMemcpyAsync(o->h_ndone, o->d_ndone, sizeof(int), hipMemcpyDeviceToHost, o->stream));
+      HIPCHK(hipEventRecord(o->ev_done, o->stream));
+    }
+    if (ahead) {
+      if (launch_calc_qp(o, true, false)) return -1;
+      k1_queued = true;
+    }
+    // waits for the finished count only, not for the pass queued behind it
+    if (o->poll) { if (wait_stamp(o, 1, seq)) return -1; }
+    else HIPCHK(hipEventSynchronize(o->ev_done));
+    if (__atomic_load_n(o->h_ndone, __ATOMIC_ACQUIRE) >= o->B) break;
     if (max_time > 0.0) {
       const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
       if (el > max_time) break;
@@ -442,7 +490,10 @@ int agx_ocp_create(const agx_model *m, const agx_ocp_desc *d, int batch, int dev
   ALLOC(o->d_state, B);
   ALLOC(o->d_ndone, 1);
 #undef ALLOC
-  if (hipHostMalloc((void **)&o->h_ndone, sizeof(int)) != hipSuccess) { agx_ocp_destroy(o); return fail("hipHostMalloc failed"); }
+  if (hipHostMalloc((void **)&o->h_ndone, 4 * sizeof(int), hipHostMallocMapped) != hipSuccess) { agx_ocp_destroy(o); return fail("hipHostMalloc failed"); }
+  std::memset(o->h_ndone, 0, 4 * sizeof(int));
+  if (hipHostGetDevicePointer((void **)&o->h_ndone_dev, o->h_ndone, 0) != hipSuccess) o->poll = false;
+  if (const char *e = getenv("AGX_HOST_POLL")) o->poll = o->poll && (e[0] != '0');
   if (hipMemcpy(o->d_model, &o->hm, sizeof(DevModel), hipMemcpyHostToDevice) != hipSuccess ||
       hipMemcpy(o->d_ocp, &o->ho, sizeof(DevOcp), hipMemcpyHostToDevice) != hipSuccess ||
       hipMemcpy(o->d_dt, o->dt.data(), sizeof(double) * T, hipMemcpyHostToDevice) != hipSuccess) {
@@ -453,6 +504,7 @@ int agx_ocp_create(const agx_model *m, const agx_ocp_desc *d, int batch, int dev
   o->own_stream = true;
   (void)hipEventCreate(&o->ev0);
   (void)hipEventCreate(&o->ev1);
+  (void)hipEventCreateWithFlags(&o->ev_done, hipEventDisableTiming);
   o->rv.base = o->d_ref;
   o->rv.bstride = (long long)(T + 1) * o->stride;
   o->rv.tstride = o->stride;
@@ -474,6 +526,9 @@ void agx_ocp_destroy(agx_ocp *o) {
   if (o->h_ndone) (void)hipHostFree(o->h_ndone);
   if (o->ev0) (void)hipEventDestroy(o->ev0);
   if (o->ev1) (void)hipEventDestroy(o->ev1);
+  if (o->ev_done) (void)hipEventDestroy(o->ev_done);
+  if (o->d_first && !o->poll) (void)hipFree(o->d_first);
+  if (o->h_first) (void)hipHostFree(o->h_first);
   if (o->own_stream && o->stream) (void)hipStreamDestroy(o->stream);
   delete o;
 }
@@ -579,15 +634,55 @@ int agx_ocp_download(agx_ocp *o, double *xs, double *us, double *K, agx_status *
   return 0;
 }
 
-int agx_ocp_download_first(agx_ocp *o, double *us0, double *K0, double *x1, agx_status *st) {
-  if (!o) return fail("null handle");
+// What a controller consumes per cycle, packed on the device and copied with ONE transfer into a
+// pinned host buffer owned by the handle: per instance
+//   [ us0 (nu) | K0 (nu x ndx, row major) | x1 (nx) | kkt cost merit gap iter qp_iters solved flags ].
+int agx_ocp_first_packed(agx_ocp *o, const double **host, int *stride) {
+  if (!o || !host) return fail("agx_ocp_first_packed: null argument");
   if (set_device(o)) return -1;
-  const size_t B = o->B, T = o->T, nx = o->nx, nu = o->nu;
-  if (us0) HIPCHK(hipMemcpy2DAsync(us0, sizeof(double) * nu, o->d_us, sizeof(double) * T * nu, sizeof(double) * nu, B, hipMemcpyDeviceToHost, o->stream));
-  if (K0) HIPCHK(hipMemcpy2DAsync(K0, sizeof(double) * nu * nx, o->d_Kout, sizeof(double) * T * nu * nx, sizeof(double) * nu * nx, B, hipMemcpyDeviceToHost, o->stream));
-  if (x1) HIPCHK(hipMemcpy2DAsync(x1, sizeof(double) * nx, o->d_xs + nx, sizeof(double) * (T + 1) * nx, sizeof(double) * nx, B, hipMemcpyDeviceToHost, o->stream));
-  if (st) return agx_ocp_download(o, nullptr, nullptr, nullptr, st);
-  HIPCHK(hipStreamSynchronize(o->stream));
+  const int FS = o->nu + o->nu * o->nx + o->nx + 8;
+  if (!o->h_first) {
+    HIPCHK(hipHostMalloc((void **)&o->h_first, sizeof(double) * (size_t)o->B * FS, hipHostMallocMapped));
+    if (o->poll) {
+      HIPCHK(hipHostGetDevicePointer((void **)&o->d_first, o->h_first, 0));  // the pack kernel writes host memory directly
+    } else {
+      HIPCHK(hipMalloc((void **)&o->d_first, sizeof(double) * (size_t)o->B * FS));
+    }
+    o->first_stride = FS;
+  }
+  const long long n = (long long)o->B * FS;
+  hipLaunchKernelGGL(agx::k_pack_first, dim3((int)((n + 255) / 256)), dim3(256), 0, o->stream, o->d_us, o->d_Kout, o->d_xs, o->d_state,
+                     o->d_first, o->B, o->T, o->nx, o->nu, o->last_max_iter);
+  HIPCHK(hipGetLastError());
+  if (o->poll) {
+    const int seq = ++o->seq;
+    if (publish(o, 3, 2, o->d_ndone, seq)) return -1;
+    if (wait_stamp(o, 2, seq)) return -1;
+  } else {
+    HIPCHK(hipMemcpyAsync(o->h_first, o->d_first, sizeof(double) * n, hipMemcpyDeviceToHost, o->stream));
+    HIPCHK(hipStreamSynchronize(o->stream));
+  }
+  *host = o->h_first;
+  if (stride) *stride = FS;
+  return 0;
+}
+
+int agx_ocp_download_first(agx_ocp *o, double *us0, double *K0, double *x1, agx_status *st) {
+  const double *h = nullptr;
+  int FS = 0;
+  if (agx_ocp_first_packed(o, &h, &FS)) return -1;
+  const int nu = o->nu, nx = o->nx, nk = nu * nx;
+  for (int b = 0; b < o->B; ++b) {
+    const double *r = h + (size_t)b * FS;
+    if (us0) std::memcpy(us0 + (size_t)b * nu, r, sizeof(double) * nu);
+    if (K0) std::memcpy(K0 + (size_t)b * nk, r + nu, sizeof(double) * nk);
+    if (x1) std::memcpy(x1 + (size_t)b * nx, r + nu + nk, sizeof(double) * nx);
+    if (st) {
+      const double *q = r + nu + nk + nx;
+      st[b].kkt = q[0]; st[b].cost = q[1]; st[b].merit = q[2]; st[b].gap_norm = q[3];
+      st[b].iter = (int)q[4]; st[b].qp_iters = (int)q[5]; st[b].solved = (int)q[6]; st[b].flags = (int)q[7];
+    }
+  }
   return 0;
 }
 

@@ -130,6 +130,7 @@ __global__ void __launch_bounds__(64, AGX_K1_WAVES) k_calc_qp_lj(const DevModel 
   const long long nid = node_ok ? node : 0;  // out-of-range groups shadow node 0 and store nothing
   const int b = TERM ? (int)nid : (int)(nid / T), t = TERM ? T : (int)(nid % T);
   const bool act = node_ok && !st[b].done;
+  if (!__any(act)) return;  // the whole wave (= workgroup) belongs to finished instances
   const bool jl = l8 < NV;       // lane carries a joint
   const int j = jl ? l8 : NV - 1;
   const double preg = st[b].preg;

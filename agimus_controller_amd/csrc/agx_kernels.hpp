@@ -727,6 +727,7 @@ __global__ void __launch_bounds__(256) k_node_kkt(const DevOcp *__restrict__ op,
   const int b = (int)(nid / (T + 1)), t = (int)(nid % (T + 1));
   const DevState &S = st[b];
   const bool act = ok && !S.done;
+  if (!__any(act)) return;  // wave of finished instances (no workgroup barrier below)
   const double preg = S.preg, dreg = S.dreg;
   const bool jl = l8 < NV;
   const int jj = jl ? l8 : 0;
@@ -919,6 +920,41 @@ __global__ void k_reset_state(DevState *st, int B, int *n_done) {
   s.iter = 0; s.qp_iters = 0; s.solved = 0; s.flags = 0; s.done = 0; s.gains_iter = -1; s.dir_iter = -1;
   s.gains_preg = kRegMin; s.gains_dreg = kRegMin;
   st[b] = s;
+}
+
+// stream -> host hand-off through mapped pinned memory: value first, then the sequence stamp
+__global__ void k_publish(const int *__restrict__ d_value, int *host_value, int *host_seq, int seq) {
+  __hip_atomic_store(host_value, *d_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  __threadfence_system();
+  __hip_atomic_store(host_seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// first-node results of every instance, packed for one device-to-host transfer (agx_ocp_first_packed)
+__global__ void k_pack_first(const double *__restrict__ us, const double *__restrict__ Kout, const double *__restrict__ xs,
+                             const DevState *__restrict__ st, double *__restrict__ out, int B, int T, int NX, int NU,
+                             int last_max_iter) {
+  const int NK = NU * NX, FS = NU + NK + NX + 8;
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long long)B * FS) return;
+  const int b = (int)(i / FS), e = (int)(i % FS);
+  double v;
+  if (e < NU) v = us[(long long)b * T * NU + e];
+  else if (e < NU + NK) v = Kout[(long long)b * T * NK + (e - NU)];
+  else if (e < NU + NK + NX) v = xs[((long long)b * (T + 1) + 1) * NX + (e - NU - NK)];
+  else {
+    const DevState &S = st[b];
+    switch (e - NU - NK - NX) {
+      case 0: v = S.kkt; break;
+      case 1: v = S.cost; break;
+      case 2: v = S.merit; break;
+      case 3: v = S.gap; break;
+      case 4: v = S.done ? S.iter : last_max_iter; break;
+      case 5: v = S.qp_iters; break;
+      case 6: v = S.solved; break;
+      default: v = S.flags; break;
+    }
+  }
+  out[i] = v;
 }
 
 // xs[b][0] <- x0[b]   (SolverCSQP pins xs_[0] = problem.x0)

@@ -162,7 +162,7 @@ def main():
 
     def step(k):
         hip.mpc_step(k, args.max_iter, first=(k == 0))
-        return hip.download_first()
+        return hip.download_first(copy=False)
 
     def sync_all():
         if dist is not None:

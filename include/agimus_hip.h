@@ -171,6 +171,11 @@ int agx_ocp_download(agx_ocp *ocp, double *xs, double *us, double *K, agx_status
 /* Only what the ROS node publishes (agimus_controller_ros/agimus_controller.py:418-426):
  * us0 [B][nu], K0 [B][nu][ndx], x1 [B][nx] (may be NULL).                      */
 int agx_ocp_download_first(agx_ocp *ocp, double *us0, double *K0, double *x1, agx_status *st);
+/* Same data without the host-side scatter: one device-side pack, one transfer into a pinned buffer
+ * owned by the handle.  *host -> [B][*stride] doubles, per instance
+ *   us0 (nu) | K0 (nu*ndx, row major) | x1 (nx) | kkt cost merit gap_norm iter qp_iters solved flags;
+ * valid until the next call on this handle.                                      */
+int agx_ocp_first_packed(agx_ocp *ocp, const double **host, int *stride);
 
 /* Replaces WarmStartShiftPreviousSolution.shift
  * (warm_start_shift_previous_solution.py:85-109) on the resident solution.     */
