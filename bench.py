@@ -58,7 +58,7 @@ def make_problem(T):
     return table, tcp, po
 
 
-def cpu_baseline(args, table, tcp, po, n_steps=3):
+def cpu_baseline(args, table, tcp, po, n_steps=24):
     """The same MPC steps on the host cores with the CPU restatement under oracle/ ("port", OpenMP
     over the instances): a bounded sample of the workload (first instances, first steps)."""
     from oracle.oracle import Oracle  # test infrastructure: only this leg of bench.py uses it
@@ -126,7 +126,18 @@ def cpu_baseline(args, table, tcp, po, n_steps=3):
         xs, us, K, st = o.solve(refs[k], None, x0, xs, us, args.max_iter, nthreads=cores)
         iters.append(float(st["iter"].mean()))
     el = time.perf_counter() - t_start
+    # the reference's default n_threads = 1 (ocp_param_base.py:65): one instance on one thread
+    o1 = Oracle(table, po, 1)
+    x1s, u1s, x01 = xs[:1].copy(), us[:1].copy(), xs[:1, 0].copy()
+    o1.solve(refs[0][:1], None, x01, x1s, u1s, 1, nthreads=1)
+    t1 = time.perf_counter()
+    n1 = 0
+    for k in range(min(n_steps, 8)):
+        o1.solve(refs[k][:1], None, x01, x1s, u1s, args.max_iter, nthreads=1)
+        n1 += 1
+    el1 = time.perf_counter() - t1
     return {
+        "single_thread": {"value": n1 / el1, "unit": "MPC steps/s", "cores": 1, "sample": f"1 instance x {n1} solves"},
         "value": B * n_steps / el,
         "unit": "MPC steps/s",
         "cores": cores,
@@ -153,7 +164,7 @@ def main():
     B, T, dt = args.batch, args.horizon, 0.01
     table, tcp, po = make_problem(T)
     hip = backend.HipOcp(table, po, B, device=local_rank)
-    n_points = args.warmup + args.steps + T + 2 + 10
+    n_points = args.warmup + max(args.steps, 200) + T + 2 + 10
     # per-instance seeds follow the GLOBAL instance index so every rank works on different instances
     q0, amp, puls, scale, t0 = workloads.sine_batch_params(B, seed0=1234 + rank * B, lower=table.lower_position_limit,
                                                            upper=table.upper_position_limit)
@@ -261,18 +272,35 @@ def main():
             h1 = backend.HipOcp(table, po, 1, device=local_rank)
             p1 = workloads.sine_batch_params(1, lower=table.lower_position_limit, upper=table.upper_position_limit)
             h1.sine_trajectory(n_points, dt, *p1, w["w_q"], w["w_qdot"], w["w_effort"], w["w_pose"], tcp)
+            n1 = min(200, n_points - T - 2 - args.warmup)
             for k in range(args.warmup):
                 h1.mpc_step(k, args.max_iter, first=(k == 0))
-                h1.download_first()
+                h1.download_first(copy=False)
             h1.sync()
-            t1 = time.perf_counter()
-            for k in range(args.warmup, args.warmup + args.steps):
+            lat = []
+            for k in range(args.warmup, args.warmup + n1):
+                t1 = time.perf_counter()
                 h1.mpc_step(k, args.max_iter, first=(k == 0))
-                h1.download_first()
-            h1.sync()
-            ms1 = (time.perf_counter() - t1) / args.steps * 1e3
-            result["batch1"] = {"ms_per_step": ms1, "value": 1e3 / ms1, "unit": "MPC steps/s", "workload": "same, batch = 1"}
+                h1.download_first(copy=False)
+                lat.append((time.perf_counter() - t1) * 1e3)
+            lat = np.sort(np.array(lat))
+            ms1 = float(lat.mean())
+            result["batch1"] = {"ms_per_step": ms1, "median_ms": float(np.median(lat)), "p99_ms": float(lat[int(0.99 * (len(lat) - 1))]),
+                                "steps": int(len(lat)), "value": 1e3 / ms1, "unit": "MPC steps/s",
+                                "workload": "same, batch = 1 (BASELINE.json configs[1]); per-step host wall time incl. D2H"}
             h1.close()
+        if world == 1 and not args.no_batch1:
+            # the same step with the FULL result download (xs, us, K of every node) into pageable memory
+            kf = args.warmup + args.steps + min(10, T // 2)
+            t1 = time.perf_counter()
+            nfull = 3
+            for k in range(kf, kf + nfull):
+                hip.mpc_step(k, args.max_iter, first=False)
+                hip.download()
+            msf = (time.perf_counter() - t1) / nfull * 1e3
+            result["full_download"] = {"ms_per_step": msf, "value": B / (msf * 1e-3), "unit": "MPC steps/s",
+                                       "bytes_per_step": int(8 * B * ((T + 1) * 14 + T * 7 + T * 98)),
+                                       "note": "PCIe-inclusive: xs, us, K of all nodes copied to host every step"}
         if not args.no_cpu_baseline and world == 1:
             try:
                 result["cpu_baseline"] = cpu_baseline(args, table, tcp, po)
