@@ -40,7 +40,21 @@ class CostRow(C.Structure):
         ("activation", C.c_int32),
         ("active", C.c_int32),
         ("frame", C.c_int32),
+        ("frame_b", C.c_int32),
+        ("pad_", C.c_int32),
         ("alpha", C.c_double),
+    ]
+
+
+class ConstraintRow(C.Structure):
+    _fields_ = [
+        ("kind", C.c_int32),
+        ("active", C.c_int32),
+        ("frame", C.c_int32),
+        ("frame_b", C.c_int32),
+        ("ref", c_double_p),
+        ("lower", c_double_p),
+        ("upper", c_double_p),
     ]
 
 
@@ -59,6 +73,8 @@ class ModelDesc(C.Structure):
         ("gravity", c_double_p),
         ("frame_parent", c_int32_p),
         ("frame_placement", c_double_p),
+        ("frame_radius", c_double_p),
+        ("frame_halflen", c_double_p),
     ]
 
 
@@ -77,6 +93,10 @@ class OcpDesc(C.Structure):
         ("mu_dynamic", C.c_double),
         ("mu_constraint", C.c_double),
         ("use_filter_line_search", C.c_int32),
+        ("n_running_constraints", C.c_int32),
+        ("running_constraints", C.POINTER(ConstraintRow)),
+        ("n_terminal_constraints", C.c_int32),
+        ("terminal_constraints", C.POINTER(ConstraintRow)),
     ]
 
 
@@ -174,9 +194,24 @@ class RowSpec:
     frame: int = 0
     alpha: float = 1.0
     name: str = ""
+    frame_b: int = 0
 
     def width(self, nv: int) -> int:
         return 1 + row_nref(self.kind, nv) + row_nr(self.kind, nv)
+
+
+@dataclasses.dataclass
+class ConstraintSpec:
+    """Python-side description of one constraint row: lower <= r(x, u) <= upper."""
+
+    kind: int
+    lower: T.Any = -np.inf
+    upper: T.Any = np.inf
+    ref: T.Any = None
+    active: bool = True
+    frame: int = 0
+    frame_b: int = 0
+    name: str = ""
 
 
 def row_offsets(rows: T.Sequence[RowSpec], nv: int) -> list[int]:
@@ -218,6 +253,10 @@ class PackedModel:
         self.gravity = f8(table.gravity, (3,))
         self.frame_parent = np.ascontiguousarray(np.asarray(table.frame_parent, dtype=np.int32).reshape(-1))
         self.frame_placement = f8(table.frame_placement, (max(self.nframes, 0), 12))
+        rad = getattr(table, "frame_radius", None)
+        hl = getattr(table, "frame_halflen", None)
+        self.frame_radius = f8(np.zeros(self.nframes) if rad is None else rad, (self.nframes,))
+        self.frame_halflen = f8(np.zeros(self.nframes) if hl is None else hl, (self.nframes,))
         d = ModelDesc()
         d.nv = nv
         d.nframes = self.nframes
@@ -232,6 +271,8 @@ class PackedModel:
         d.gravity = _dptr(self.gravity)
         d.frame_parent = _iptr(self.frame_parent)
         d.frame_placement = _dptr(self.frame_placement)
+        d.frame_radius = _dptr(self.frame_radius)
+        d.frame_halflen = _dptr(self.frame_halflen)
         self.desc = d
 
 
@@ -251,6 +292,8 @@ class PackedOcp:
         mu_dynamic: float = 10.0,
         mu_constraint: float = 10.0,
         use_filter_line_search: bool = False,
+        running_constraints: T.Sequence[ConstraintSpec] = (),
+        terminal_constraints: T.Sequence[ConstraintSpec] = (),
     ):
         assert len(running) <= AGX_MAX_ROWS and len(terminal) <= AGX_MAX_ROWS
         self.nv = nv
@@ -266,7 +309,28 @@ class PackedOcp:
                 arr[i].activation = r.activation
                 arr[i].active = 1 if r.active else 0
                 arr[i].frame = r.frame
+                arr[i].frame_b = r.frame_b
                 arr[i].alpha = r.alpha
+        self.running_constraints = list(running_constraints)
+        self.terminal_constraints = list(terminal_constraints)
+        self._rc = (ConstraintRow * max(len(self.running_constraints), 1))()
+        self._tc = (ConstraintRow * max(len(self.terminal_constraints), 1))()
+        self._cbuf = []  # keeps the bound / reference arrays alive
+        for arr, cons in ((self._rc, self.running_constraints), (self._tc, self.terminal_constraints)):
+            for i, c in enumerate(cons):
+                nref, nr = row_nref(c.kind, nv), row_nr(c.kind, nv)
+                lo = np.ascontiguousarray(np.broadcast_to(np.asarray(c.lower, dtype=np.float64), (nr,)).copy())
+                up = np.ascontiguousarray(np.broadcast_to(np.asarray(c.upper, dtype=np.float64), (nr,)).copy())
+                rf = np.zeros(max(nref, 1)) if c.ref is None else np.ascontiguousarray(np.asarray(c.ref, dtype=np.float64).reshape(-1))
+                assert rf.size >= nref
+                self._cbuf += [lo, up, rf]
+                arr[i].kind = c.kind
+                arr[i].active = 1 if c.active else 0
+                arr[i].frame = c.frame
+                arr[i].frame_b = c.frame_b
+                arr[i].ref = _dptr(rf)
+                arr[i].lower = _dptr(lo)
+                arr[i].upper = _dptr(up)
         d = OcpDesc()
         d.horizon = self.horizon
         d.dt = _dptr(self.dt)
@@ -281,6 +345,10 @@ class PackedOcp:
         d.mu_dynamic = mu_dynamic
         d.mu_constraint = mu_constraint
         d.use_filter_line_search = 1 if use_filter_line_search else 0
+        d.n_running_constraints = len(self.running_constraints)
+        d.running_constraints = C.cast(self._rc, C.POINTER(ConstraintRow))
+        d.n_terminal_constraints = len(self.terminal_constraints)
+        d.terminal_constraints = C.cast(self._tc, C.POINTER(ConstraintRow))
         self.desc = d
         self.stride = ref_stride(running, terminal, nv)
         self.running_offsets = row_offsets(running, nv)

@@ -8,6 +8,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <cstddef>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -107,6 +108,7 @@ void fill_rows(const agx_cost_row *rows, int n, int nv, DevRows &d) {
     d.act[r] = rows[r].activation;
     d.active[r] = rows[r].active;
     d.frame[r] = rows[r].frame;
+    d.frame_b[r] = rows[r].frame_b;
     d.alpha[r] = rows[r].alpha;
     d.nref[r] = agx_row_nref(rows[r].kind, nv);
     d.nr[r] = agx_row_nr(rows[r].kind, nv);
@@ -407,6 +409,8 @@ int agx_model_create(const agx_model_desc *d, agx_model **out) {
     h.frame_parent[f] = d->frame_parent[f];
     if (d->frame_parent[f] >= d->nv) { delete m; return fail("agx_model_create: bad frame parent"); }
     std::memcpy(h.frame_placement[f], d->frame_placement + 12 * f, sizeof(double) * 12);
+    h.frame_radius[f] = d->frame_radius ? d->frame_radius[f] : 0.0;
+    h.frame_halflen[f] = d->frame_halflen ? d->frame_halflen[f] : 0.0;
   }
   *out = m;
   return 0;
@@ -424,14 +428,25 @@ int agx_ocp_create(const agx_model *m, const agx_ocp_desc *d, int batch, int dev
   for (int r = 0; r < d->n_running_rows + d->n_terminal_rows; ++r) {
     const agx_cost_row &row = r < d->n_running_rows ? d->running_rows[r] : d->terminal_rows[r - d->n_running_rows];
     switch (row.kind) {
-      case AGX_RES_STATE: case AGX_RES_CONTROL: case AGX_RES_FRAME_PLACEMENT: case AGX_RES_FRAME_TRANSLATION: case AGX_RES_FRAME_ROTATION: break;
+      case AGX_RES_STATE: case AGX_RES_CONTROL: case AGX_RES_FRAME_PLACEMENT: case AGX_RES_FRAME_TRANSLATION: case AGX_RES_FRAME_ROTATION:
+      case AGX_RES_COLLISION: break;
       default: return fail("agx_ocp_create: residual kind " + std::to_string(row.kind) + " is not implemented on the HIP path yet");
     }
-    if (row.activation != AGX_ACT_WEIGHTED_QUAD) return fail("agx_ocp_create: only ActivationModelWeightedQuad is implemented on the HIP path yet");
+    if (row.activation != AGX_ACT_WEIGHTED_QUAD && row.kind != AGX_RES_COLLISION)
+      return fail("agx_ocp_create: ActivationModelExp / QuadExp are implemented for scalar residuals (collision distance) only");
+    if (row.activation != AGX_ACT_WEIGHTED_QUAD && !(row.alpha > 0.0)) return fail("agx_ocp_create: activation alpha must be positive");
     if ((row.kind == AGX_RES_FRAME_PLACEMENT || row.kind == AGX_RES_FRAME_TRANSLATION || row.kind == AGX_RES_FRAME_ROTATION) &&
         (row.frame < 0 || row.frame >= m->h.nframes))
       return fail("agx_ocp_create: frame id out of range");
+    if (row.kind == AGX_RES_COLLISION) {
+      if (row.frame < 0 || row.frame >= m->h.nframes || row.frame_b < 0 || row.frame_b >= m->h.nframes)
+        return fail("agx_ocp_create: collision pair refers to a geometry frame out of range");
+      if (!(m->h.frame_radius[row.frame] > 0.0) || !(m->h.frame_radius[row.frame_b] > 0.0))
+        return fail("agx_ocp_create: collision pair refers to a frame without geometry (radius 0)");
+    }
   }
+  if (d->n_running_constraints > 0 || d->n_terminal_constraints > 0)
+    return fail("agx_ocp_create: constraints (ADMM) are not implemented on the HIP path yet");
   agx_ocp *o = new agx_ocp();
   o->hm = m->h;
   o->nv = m->h.nv; o->nx = 2 * o->nv; o->nu = o->nv;
@@ -458,7 +473,13 @@ int agx_ocp_create(const agx_model *m, const agx_ocp_desc *d, int batch, int dev
         n += (r.kind[i] == AGX_RES_FRAME_PLACEMENT || r.kind[i] == AGX_RES_FRAME_TRANSLATION || r.kind[i] == AGX_RES_FRAME_ROTATION);
       return n;
     };
-    o->lanes_ok = o->stride <= agx::kLjRef && n_frame_rows(o->ho.rows[0]) <= 2 && n_frame_rows(o->ho.rows[1]) <= 2;
+    auto n_collision_rows = [](const DevRows &r) {
+      int n = 0;
+      for (int i = 0; i < r.n; ++i) n += (r.kind[i] == AGX_RES_COLLISION);
+      return n;
+    };
+    o->lanes_ok = o->stride <= agx::kLjRef && n_frame_rows(o->ho.rows[0]) <= 2 && n_frame_rows(o->ho.rows[1]) <= 2 &&
+                  n_collision_rows(o->ho.rows[0]) + n_collision_rows(o->ho.rows[1]) == 0;
   }
   // probe that a kernel instantiation exists
   if (dispatch(o->nv, o->chain, [](auto, auto) -> int { return 0; })) { delete o; return -1; }
@@ -551,6 +572,18 @@ int agx_ocp_set_stream(agx_ocp *o, void *hip_stream) {
 int agx_ocp_sync(agx_ocp *o) {
   if (!o) return fail("null handle");
   if (set_device(o)) return -1;
+  HIPCHK(hipStreamSynchronize(o->stream));
+  return 0;
+}
+
+int agx_ocp_set_geom_placement(agx_ocp *o, int frame, const double *se3) {
+  if (!o || !se3) return fail("agx_ocp_set_geom_placement: null argument");
+  if (frame < 0 || frame >= o->hm.nframes) return fail("agx_ocp_set_geom_placement: frame out of range");
+  if (set_device(o)) return -1;
+  std::memcpy(o->hm.frame_placement[frame], se3, sizeof(double) * 12);
+  // in-stream update of the one placement inside the resident model
+  HIPCHK(hipMemcpyAsync((char *)o->d_model + offsetof(DevModel, frame_placement) + sizeof(double) * 12 * frame, o->hm.frame_placement[frame],
+                        sizeof(double) * 12, hipMemcpyHostToDevice, o->stream));
   HIPCHK(hipStreamSynchronize(o->stream));
   return 0;
 }

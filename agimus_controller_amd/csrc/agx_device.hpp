@@ -31,11 +31,12 @@ struct DevModel {
   double gravity[3];
   int frame_parent[AGX_MAX_FRAMES];
   double frame_placement[AGX_MAX_FRAMES][12];
+  double frame_radius[AGX_MAX_FRAMES], frame_halflen[AGX_MAX_FRAMES];  // collision geometry carried by frames
 };
 
 struct DevRows {
   int n;
-  int kind[AGX_MAX_ROWS], act[AGX_MAX_ROWS], active[AGX_MAX_ROWS], frame[AGX_MAX_ROWS];
+  int kind[AGX_MAX_ROWS], act[AGX_MAX_ROWS], active[AGX_MAX_ROWS], frame[AGX_MAX_ROWS], frame_b[AGX_MAX_ROWS];
   int off[AGX_MAX_ROWS], nref[AGX_MAX_ROWS], nr[AGX_MAX_ROWS];
   double alpha[AGX_MAX_ROWS];
 };
@@ -635,6 +636,77 @@ struct TileOff {
 // Cost accumulators of one node.  Every supported residual depends on q only
 // through the frame placement, on v and u only diagonally, so the Hessian is
 // {dense qq block, diagonal vv, diagonal uu} and Lxu = 0.
+// Activation of a scalar residual: value, first and second derivative.
+// WeightedQuad a = w r^2 / 2; colmpc QuadExp a = exp(-r^2 / alpha), Exp a = exp(-|r| / alpha)
+// (ocp_croco_generic.py:98-143; the colmpc forms restated from recall).
+AGX_DEV void activation1(int act, double alpha, double w, double r, double &a, double &ar, double &arr) {
+  if (act == AGX_ACT_QUAD_EXP) {
+    a = exp(-r * r / alpha);
+    ar = -2.0 * r * a / alpha;
+    arr = (-2.0 / alpha + 4.0 * r * r / (alpha * alpha)) * a;
+  } else if (act == AGX_ACT_EXP) {
+    a = exp(-fabs(r) / alpha);
+    ar = (r > 0.0 ? -1.0 : (r < 0.0 ? 1.0 : 0.0)) * a / alpha;
+    arr = a / (alpha * alpha);
+  } else {
+    a = 0.5 * w * r * r;
+    ar = w * r;
+    arr = w;
+  }
+}
+
+// Closest points of two segments (Ericson 5.1.9; capsule / capsule narrow phase behind
+// colmpc.ResidualDistanceCollision): parameters s, t in [0, 1].
+AGX_DEV double clamp01(double x) { return x < 0.0 ? 0.0 : (x > 1.0 ? 1.0 : x); }
+AGX_DEV void closest_seg_seg(const double *a0, const double *a1, const double *b0, const double *b1, double &s, double &t) {
+  const double eps = 1e-14;
+  double d1[3], d2[3], r[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) { d1[k] = a1[k] - a0[k]; d2[k] = b1[k] - b0[k]; r[k] = a0[k] - b0[k]; }
+  const double a = dot3(d1, d1), e = dot3(d2, d2), f = dot3(d2, r);
+  if (a <= eps && e <= eps) { s = 0.0; t = 0.0; return; }
+  if (a <= eps) { s = 0.0; t = clamp01(f / e); return; }
+  const double c = dot3(d1, r);
+  if (e <= eps) { t = 0.0; s = clamp01(-c / a); return; }
+  const double b = dot3(d1, d2);
+  const double denom = a * e - b * b;
+  s = (denom > eps * a * e) ? clamp01((b * f - c * e) / denom) : 0.0;
+  t = (b * s + f) / e;
+  if (t < 0.0) { t = 0.0; s = clamp01(-c / a); }
+  else if (t > 1.0) { t = 1.0; s = clamp01((b - c) / a); }
+}
+
+// Signed distance of two capsule / sphere geometry frames and the witness points on the segments:
+//   d = |ca - cb| - ra - rb,  n = (ca - cb) / |ca - cb|;  d'(q) = n' (Ja(ca) - Jb(cb)).
+template <int NV>
+AGX_DEV double collision_distance(const DevModel &m, const Kin<NV> &k, int fa, int fb, double *ca, double *cb, double *n,
+                                  int *ja, int *jb) {
+  double Ra[9], pa[3], Rb[9], pb[3];
+  frame_world<NV>(m, k, fa, Ra, pa, ja);
+  frame_world<NV>(m, k, fb, Rb, pb, jb);
+  const double ha = m.frame_halflen[fa], hb = m.frame_halflen[fb];
+  double a0[3], a1[3], b0[3], b1[3];
+#pragma unroll
+  for (int e = 0; e < 3; ++e) {
+    a0[e] = pa[e] - ha * Ra[3 * e + 2]; a1[e] = pa[e] + ha * Ra[3 * e + 2];
+    b0[e] = pb[e] - hb * Rb[3 * e + 2]; b1[e] = pb[e] + hb * Rb[3 * e + 2];
+  }
+  double sa, sb;
+  closest_seg_seg(a0, a1, b0, b1, sa, sb);
+  double d2 = 0.0;
+#pragma unroll
+  for (int e = 0; e < 3; ++e) {
+    ca[e] = pa[e] + ((2.0 * sa - 1.0) * ha) * Ra[3 * e + 2];
+    cb[e] = pb[e] + ((2.0 * sb - 1.0) * hb) * Rb[3 * e + 2];
+    n[e] = ca[e] - cb[e];
+    d2 += n[e] * n[e];
+  }
+  const double dn = sqrt(d2), inv = dn > 0.0 ? 1.0 / dn : 0.0;
+#pragma unroll
+  for (int e = 0; e < 3; ++e) n[e] *= inv;
+  return dn - (m.frame_radius[fa] + m.frame_radius[fb]);
+}
+
 template <int NV>
 struct CostAcc {
   double cost;
@@ -779,6 +851,34 @@ AGX_DEV void node_costs(const DevModel &m, const DevRows &rows, const Kin<NV> &k
               for (int j = 0; j <= i; ++j) c.Lqq[i][j] += we * J[e][i] * J[e][j];
             }
           }
+        }
+      }
+    } else if (kind == AGX_RES_COLLISION) {
+      // colmpc.ResidualDistanceCollision (ocp_croco_generic.py:524-533) with a scalar activation
+      double ca[3], cb[3], n[3];
+      int ja, jb;
+      const double d = collision_distance<NV>(m, k, rows.frame[r], rows.frame_b[r], ca, cb, n, &ja, &jb);
+      double a, ar, arr;
+      activation1(rows.act[r], rows.alpha[r], aw[0], d, a, ar, arr);
+      c.cost += wi * a;
+      if (DIFF) {
+        double g[NV];
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+          const bool ona = (ja >= 0) && (CHAIN ? (j <= ja) : ((m.anc[ja >= 0 ? ja : 0] >> j) & 1u));
+          const bool onb = (jb >= 0) && (CHAIN ? (j <= jb) : ((m.anc[jb >= 0 ? jb : 0] >> j) & 1u));
+          double da[3], db[3], ta[3], tb[3];
+#pragma unroll
+          for (int e = 0; e < 3; ++e) { da[e] = ca[e] - k.p[j][e]; db[e] = cb[e] - k.p[j][e]; }
+          cross3(k.S[j] + 3, da, ta);
+          cross3(k.S[j] + 3, db, tb);
+          g[j] = (ona ? dot3(n, ta) : 0.0) - (onb ? dot3(n, tb) : 0.0);
+        }
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+          c.Lq[i] += wi * ar * g[i];
+#pragma unroll
+          for (int j = 0; j <= i; ++j) c.Lqq[i][j] += wi * arr * g[i] * g[j];
         }
       }
     }

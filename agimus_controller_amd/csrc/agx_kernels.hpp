@@ -1129,6 +1129,15 @@ __global__ void k_residuals(const DevModel *__restrict__ mp, const DevOcp *__res
       log3(Rrel, res);
       for (int e = 0; e < 3; ++e) dst[e] = res[e];
     }
+  } else if (kind == AGX_RES_COLLISION) {
+    double ql[NV];
+#pragma unroll
+    for (int e = 0; e < NV; ++e) ql[e] = x[e];
+    Kin<NV> k;
+    kinematics<NV, CHAIN>(m, ql, k);
+    double ca[3], cb[3], n[3];
+    int ja, jb;
+    dst[0] = collision_distance<NV>(m, k, rows.frame[row], rows.frame_b[row], ca, cb, n, &ja, &jb);
   } else {
     for (int i = 0; i < nr; ++i) dst[i] = 0.0;
   }

@@ -41,6 +41,36 @@ class TableModel:
         return np.zeros(self.nq)
 
 
+class TableGeometryModel:
+    """pinocchio.GeometryModel look-alike over the geometry frames of a RobotTable (capsules /
+    spheres; what factory/robot_model.py:261-302 of the reference leaves in the collision model)."""
+
+    def __init__(self, table: robot_tables.RobotTable, collision_pairs=()):
+        self.table = table
+        self.collisionPairs = []
+        for a, b in collision_pairs:
+            self.addCollisionPair((self.getGeometryId(a), self.getGeometryId(b)))
+
+    def existGeometryName(self, name: str) -> bool:
+        if name not in self.table.frame_names or self.table.frame_radius is None:
+            return False
+        return float(self.table.frame_radius[self.table.frame_names.index(name)]) > 0.0
+
+    def getGeometryId(self, name: str) -> int:
+        assert self.existGeometryName(name), f"Geometry object '{name}' not found."
+        return self.table.frame_names.index(name)
+
+    def existCollisionPair(self, pair) -> bool:
+        return tuple(pair) in self.collisionPairs
+
+    def addCollisionPair(self, pair) -> None:
+        if not self.existCollisionPair(pair):
+            self.collisionPairs.append(tuple(pair))
+
+    def findCollisionPair(self, pair) -> int:
+        return self.collisionPairs.index(tuple(pair))
+
+
 @dataclasses.dataclass
 class RobotModelParameters:
     """Subset of the reference's parameters that is meaningful without a URDF loader.
@@ -53,6 +83,7 @@ class RobotModelParameters:
     armature: np.ndarray = dataclasses.field(default_factory=lambda: np.array([], dtype=np.float64))
     collision_as_capsule: bool = False
     self_collision: bool = False
+    collision_pairs: T.List[T.Tuple[str, str]] = dataclasses.field(default_factory=list)
 
     def __post_init__(self):
         if self.free_flyer:
@@ -78,6 +109,8 @@ class RobotModels:
         self._table = param.table.with_armature(param.armature)
         self._robot_model = TableModel(self._table)
         self._q0 = param.q0
+        has_geom = self._table.frame_radius is not None and np.any(np.asarray(self._table.frame_radius) > 0.0)
+        self._collision_model = TableGeometryModel(self._table, param.collision_pairs) if has_geom else None
 
     @property
     def params(self) -> RobotModelParameters:
@@ -93,7 +126,7 @@ class RobotModels:
 
     @property
     def collision_model(self):
-        return None
+        return self._collision_model
 
     @property
     def visual_model(self):

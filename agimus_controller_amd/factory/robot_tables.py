@@ -82,6 +82,10 @@ class RobotTable:
     frame_parent: np.ndarray  # [nframes] int
     frame_placement: np.ndarray  # [nframes,12]
     gravity: np.ndarray = dataclasses.field(default_factory=lambda: np.array([0.0, 0.0, -9.81]))
+    # collision geometry: a geometry object is a frame with a radius (> 0) and a half length
+    # (capsule segment along the frame's z axis; 0 = sphere).  None = no frame carries geometry.
+    frame_radius: np.ndarray | None = None
+    frame_halflen: np.ndarray | None = None
 
     @property
     def nv(self) -> int:
@@ -97,6 +101,24 @@ class RobotTable:
             return int(name)
         assert name in self.frame_names, f"Frame '{name}' does not exist!"
         return self.frame_names.index(name)
+
+    def with_geometry(self, name, parent, placement12, radius, halflen=0.0) -> "RobotTable":
+        """Copy with one more geometry frame: capsule (coal.Capsule(radius, halfLength), the shape
+        factory/robot_model.py:261-302 converts cylinders to) or sphere, attached to joint `parent`
+        (-1 = world, e.g. an obstacle of the environment)."""
+        assert name not in self.frame_names, f"frame '{name}' exists"
+        n = len(self.frame_names)
+        rad = np.zeros(n) if self.frame_radius is None else np.asarray(self.frame_radius, dtype=float)
+        hl = np.zeros(n) if self.frame_halflen is None else np.asarray(self.frame_halflen, dtype=float)
+        return dataclasses.replace(
+            self,
+            frame_names=list(self.frame_names) + [name],
+            frame_parent=np.append(np.asarray(self.frame_parent, dtype=np.int32), np.int32(parent)),
+            frame_placement=np.vstack([np.asarray(self.frame_placement, dtype=float).reshape(n, 12),
+                                       np.asarray(placement12, dtype=float).reshape(1, 12)]),
+            frame_radius=np.append(rad, float(radius)),
+            frame_halflen=np.append(hl, float(halflen)),
+        )
 
     def with_armature(self, armature) -> "RobotTable":
         arm = np.broadcast_to(np.asarray(armature, dtype=float), (self.nv,)).copy()
@@ -179,6 +201,29 @@ def panda_table(armature=0.1) -> RobotTable:
         frame_parent=np.array(frame_parent, dtype=np.int32),
         frame_placement=np.stack(frame_placement),
     )
+
+
+# Capsules of the arm links (joint frame, segment along the capsule frame's z) and the capsule
+# obstacle of the reference's test environment.  The link capsules are SYNTHETIC stand-ins for what
+# factory/robot_model.py:261-302 derives from the URDF cylinders (the URDF is not available here):
+# name -> (parent joint, placement R|p in the joint frame, radius, half length).
+PANDA_CAPSULES = {
+    "panda_link2_capsule_0": (1, se3(_rx(np.pi / 2), [0.0, -0.07, 0.0]), 0.06, 0.07),
+    "panda_link3_capsule_0": (2, se3(None, [0.0, 0.0, -0.10]), 0.06, 0.08),
+    "panda_link4_capsule_0": (3, se3(_rx(np.pi / 2), [-0.0825, 0.06, 0.0]), 0.06, 0.06),
+    "panda_link5_capsule_0": (4, se3(None, [0.0, 0.03, -0.18]), 0.055, 0.12),
+    "panda_link7_capsule_0": (6, se3(None, [0.0, 0.0, 0.12]), 0.05, 0.08),
+}
+
+
+def panda_collision_table(armature=0.1, obstacle_xyz=(1.535, 0.0, 0.43), obstacle_radius=0.1, obstacle_length=0.4) -> RobotTable:
+    """panda_table plus link capsules and the capsule obstacle `obstacle` of the reference's
+    tests/resources/environment.xacro:23-24 (xyz 1.535 0 0.43, direction x, radius 0.1, length 0.4)."""
+    t = panda_table(armature)
+    for name, (parent, placement, radius, halflen) in PANDA_CAPSULES.items():
+        t = t.with_geometry(name, parent, placement, radius, halflen)
+    # capsule axis (local z) along world x
+    return t.with_geometry("obstacle", -1, se3(_ry(np.pi / 2), list(obstacle_xyz)), obstacle_radius, obstacle_length / 2)
 
 
 def _random_body(rng, mass_range=(0.5, 4.0), size=0.15):

@@ -425,8 +425,30 @@ class ResidualModelVisualServoing(ResidualModel):
 
 @dataclasses.dataclass
 class ResidualDistanceCollisionBase(ResidualModel):
-    collision_pair: T.Tuple[str, str] = ("", "")
+    # Ideally paired with ActivationModelExp (reference ocp_croco_generic.py:499-522).
+    collision_pair: T.Optional[T.Tuple[str, str]] = None
+    # the shipped ocp_traj_tracking_collision_avoidance.yaml:43-56 still uses the pair index
+    collision_pair_id: T.Optional[int] = None
     kind: T.ClassVar[int] = _abi.RES_COLLISION
+
+    def geometry_frames(self, data: "BuildData") -> T.Tuple[int, int]:
+        cmodel = data.collision_model
+        assert cmodel is not None, "the robot model carries no collision geometry"
+        if self.collision_pair is not None:
+            assert len(self.collision_pair) == 2
+            ids = []
+            for name in self.collision_pair:
+                assert cmodel.existGeometryName(name), f"Geometry object '{name}' not found."
+                ids.append(cmodel.getGeometryId(name))
+            if not cmodel.existCollisionPair(ids):
+                cmodel.addCollisionPair(ids)
+            return ids[0], ids[1]
+        assert self.collision_pair_id is not None, "collision_pair (or collision_pair_id) is required"
+        assert 0 <= int(self.collision_pair_id) < len(cmodel.collisionPairs)
+        return tuple(cmodel.collisionPairs[int(self.collision_pair_id)])
+
+    def reference(self, data: "BuildData"):
+        return np.zeros(0)
 
 
 @_yaml_class
@@ -547,12 +569,19 @@ class DifferentialActionModelFreeFwdDynamics(DifferentialActionModel):
         for item in self.costs:
             res, act = item.cost.residual, item.cost.activation
             kind = res.kind
-            if kind in (_abi.RES_CONTROL_GRAV, _abi.RES_FRAME_VELOCITY, _abi.RES_COLLISION):
+            if kind in (_abi.RES_CONTROL_GRAV, _abi.RES_FRAME_VELOCITY):
                 raise NotImplementedError(f"cost '{item.name}': {type(res).__name__} is not implemented on the HIP path yet")
-            if act is not None and act.kind != _abi.ACT_WEIGHTED_QUAD:
-                raise NotImplementedError(f"cost '{item.name}': {type(act).__name__} is not implemented on the HIP path yet")
-            rows.append(_abi.RowSpec(kind=kind, activation=_abi.ACT_WEIGHTED_QUAD, active=bool(item.active),
-                                     frame=res.frame(data), alpha=1.0, name=item.name))  # fmt: skip
+            act_kind = _abi.ACT_WEIGHTED_QUAD if act is None else act.kind
+            alpha = 1.0 if act is None or act_kind == _abi.ACT_WEIGHTED_QUAD else act.alpha_value
+            if act_kind != _abi.ACT_WEIGHTED_QUAD and kind != _abi.RES_COLLISION:
+                raise NotImplementedError(f"cost '{item.name}': {type(act).__name__} is implemented for scalar residuals (collision distance) only")
+            if kind == _abi.RES_COLLISION:
+                fa, fb = res.geometry_frames(data)
+                rows.append(_abi.RowSpec(kind=kind, activation=act_kind, active=bool(item.active), frame=fa, frame_b=fb,
+                                         alpha=alpha, name=item.name))  # fmt: skip
+                continue
+            rows.append(_abi.RowSpec(kind=kind, activation=act_kind, active=bool(item.active),
+                                     frame=res.frame(data), alpha=alpha, name=item.name))  # fmt: skip
         return rows
 
 

@@ -79,7 +79,14 @@ class OCPBaseCroco(OCPBase):
         pass
 
     def update_geometry_placement(self, geometry_name: str, placement, geometry_type=None):
-        raise RuntimeError(f"Unknown geometry name '{geometry_name}' in collision model!")
+        """Updates placement of the obstacles (reference ocp_base_croco.py:110-132): `placement` is an
+        SE3 (or 12 doubles R|p) in the geometry's parent joint frame, world for environment objects."""
+        cmodel = self._robot_models.collision_model
+        if cmodel is None or not cmodel.existGeometryName(geometry_name):
+            raise RuntimeError(f"Unknown geometry name '{geometry_name}' in collision model!")
+        from .se3 import as_se3_12
+
+        self._hip.set_geom_placement(cmodel.getGeometryId(geometry_name), as_se3_12(placement))
 
     def fill_debug_data(self, res: bool, ocp_results: OCPResults) -> None:
         st = self._last_status

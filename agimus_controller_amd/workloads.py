@@ -38,6 +38,16 @@ def regulation_rows():
     return running, terminal
 
 
+def collision_avoidance_rows(table, frame: int, pair=("panda_link7_capsule_0", "obstacle"), activation=_abi.ACT_QUAD_EXP, alpha=1e-4):
+    """Cost rows of agimus_controller/agimus_controller/ocp/ocp_traj_tracking_collision_avoidance.yaml:
+    control_reg, state_reg, goal_tracking, distance (QuadExp alpha = 1e-4 on the pair's signed distance);
+    terminal the same minus control_reg.  (Its `collision` constraint is a constraint row, not a cost.)"""
+    fa, fb = table.frame_id(pair[0]), table.frame_id(pair[1])
+    dist = dict(activation=activation, alpha=alpha, frame=fa, frame_b=fb, name="distance")
+    running, terminal = goal_reaching_rows(frame)
+    return running + [_abi.RowSpec(_abi.RES_COLLISION, **dist)], terminal + [_abi.RowSpec(_abi.RES_COLLISION, **dist)]
+
+
 def golden_problem():
     """The reference's only golden case, agimus_controller/tests/test_ocp_croco_base.py:14-155:
     Panda, T = 9, Euler step 1e-3, stateReg 0.1 / ctrlReg 1e-4 / placement 1.0 to (1,1,1),
@@ -75,7 +85,14 @@ def random_goal_problem(table, T, dt, B, seed, frame=None, rows="goal", timestep
     rng = np.random.default_rng(seed)
     if frame is None:
         frame = len(table.frame_names) - 1
-    running, terminal = goal_reaching_rows(frame) if rows == "goal" else regulation_rows()
+    if rows == "goal":
+        running, terminal = goal_reaching_rows(frame)
+    elif rows == "collision":
+        running, terminal = collision_avoidance_rows(table, frame, alpha=0.05)
+    elif rows == "collision_exp":
+        running, terminal = collision_avoidance_rows(table, frame, activation=_abi.ACT_EXP, alpha=0.1)
+    else:
+        running, terminal = regulation_rows()
     ts = [dt] * T if timesteps is None else list(timesteps)
     po = _abi.PackedOcp(nv, ts, running, terminal)
     ref = po.new_ref_tile(B)
@@ -91,6 +108,8 @@ def random_goal_problem(table, T, dt, B, seed, frame=None, rows="goal", timestep
             if r.kind == _abi.RES_STATE:
                 rr[..., :nv] = qc + rng.normal(0, 0.05, (B, n, nv))
                 rr[..., nv:] = rng.normal(0, 0.1, (B, n, nv))
+            elif r.kind == _abi.RES_COLLISION:
+                wi[...] = rng.uniform(0.05, 0.2, (B, n))  # w_collision_avoidance
             elif r.kind == _abi.RES_CONTROL:
                 rr[...] = rng.normal(0, 2.0, rr.shape)
                 aw[...] = rng.uniform(1e-3, 1e-2, aw.shape)

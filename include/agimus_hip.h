@@ -61,9 +61,26 @@ typedef struct agx_cost_row {
   int32_t kind;       /* agx_residual_kind                                      */
   int32_t activation; /* agx_activation_kind                                    */
   int32_t active;     /* CostModelSumItem.active                                */
-  int32_t frame;      /* default frame id (may be overridden per node)          */
+  int32_t frame;      /* default frame id (may be overridden per node); collision: first geometry frame */
+  int32_t frame_b;    /* collision: second geometry frame of the pair (:499-533) */
+  int32_t pad_;
   double alpha;       /* Exp / QuadExp parameter                                */
 } agx_cost_row;
+
+/* One ConstraintListItem (ocp_croco_generic.py:554-647) lowered to a row:
+ *   lower <= r(x, u) <= upper   with r one of the residual kinds above.
+ * ConstraintModelControlLimit (:624-640) is the AGX_RES_CONTROL row with zero
+ * reference and -/+ effort limit.  Constraints are not updated per node
+ * (:720-721), so reference and bounds are static.                              */
+typedef struct agx_constraint_row {
+  int32_t kind;        /* agx_residual_kind                                     */
+  int32_t active;      /* ConstraintListItem.active                             */
+  int32_t frame;
+  int32_t frame_b;
+  const double *ref;   /* [agx_row_nref(kind)] or NULL = zeros                  */
+  const double *lower; /* [agx_row_nr(kind)], -inf allowed                      */
+  const double *upper; /* [agx_row_nr(kind)], +inf allowed                      */
+} agx_constraint_row;
 
 /* Robot description: what factory/robot_model.py:88-351 extracts from the URDF
  * (reduced model, armature :346-351), as a flat table.                         */
@@ -81,6 +98,11 @@ typedef struct agx_model_desc {
   const double *gravity;         /* [3]      linear gravity, world              */
   const int32_t *frame_parent;   /* [nframes] parent joint, -1 = world          */
   const double *frame_placement; /* [nframes][12] in parent joint frame         */
+  /* Collision geometry (factory/robot_model.py:261-302: cylinders become coal.Capsule(radius,
+   * halfLength)): a geometry object is a frame (parent joint + placement) whose local z axis
+   * carries the capsule segment; halflen = 0 is a sphere.  NULL = no geometry.  */
+  const double *frame_radius;    /* [nframes]                                   */
+  const double *frame_halflen;   /* [nframes]                                   */
 } agx_model_desc;
 
 /* Shooting problem + solver knobs:
@@ -99,6 +121,10 @@ typedef struct agx_ocp_desc {
   double eps_abs, eps_rel;          /* ocp_param_base.py:60-61                  */
   double mu_dynamic, mu_constraint; /* merit penalties (mim_solvers defaults)   */
   int32_t use_filter_line_search;   /* ocp_param_base.py:64                     */
+  int32_t n_running_constraints;
+  const agx_constraint_row *running_constraints;
+  int32_t n_terminal_constraints;
+  const agx_constraint_row *terminal_constraints;
 } agx_ocp_desc;
 
 /* Per-instance solver report: OCPDebugData fields filled by
@@ -144,6 +170,10 @@ void agx_ocp_destroy(agx_ocp *ocp);
 /* Run the kernels on a caller-provided hipStream_t (0 = library-owned stream). */
 int agx_ocp_set_stream(agx_ocp *ocp, void *hip_stream);
 int agx_ocp_sync(agx_ocp *ocp);
+/* Replaces OCPBaseCroco.update_geometry_placement (ocp_base_croco.py:110-132): new placement
+ * (R row major 9 | p 3, in the parent joint frame; world for parent -1) of a geometry frame,
+ * e.g. a moving obstacle.  Applies to every instance of the handle.              */
+int agx_ocp_set_geom_placement(agx_ocp *ocp, int frame, const double *se3);
 
 /* Replaces OCPCrocoGeneric.set_reference_weighted_trajectory
  * (ocp_croco_generic.py:855-892): ref_tile [B][T+1][stride] host doubles,

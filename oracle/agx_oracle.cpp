@@ -83,6 +83,7 @@ struct Model {
   int nv = 0, nframes = 0;
   std::vector<int> parent, frame_parent;
   std::vector<double> placement, axis, mass, com, inertia, armature, effort_limit, frame_placement;
+  std::vector<double> frame_radius, frame_halflen;  // collision geometry carried by frames (0 = none / sphere)
   double gravity[3] = {0, 0, -9.81};
 };
 
@@ -100,6 +101,10 @@ void copy_model(const agx_model_desc *d, Model &m) {
   if (d->nframes > 0) {
     m.frame_parent.assign(d->frame_parent, d->frame_parent + d->nframes);
     m.frame_placement.assign(d->frame_placement, d->frame_placement + 12 * d->nframes);
+    m.frame_radius.assign(d->nframes, 0.0);
+    m.frame_halflen.assign(d->nframes, 0.0);
+    if (d->frame_radius) m.frame_radius.assign(d->frame_radius, d->frame_radius + d->nframes);
+    if (d->frame_halflen) m.frame_halflen.assign(d->frame_halflen, d->frame_halflen + d->nframes);
   }
 }
 
@@ -462,6 +467,57 @@ template <int N> void log3_residual(const Dual<N> *R, Dual<N> *r) {
 }
 
 // ---------------------------------------------------------------------------
+// Closest points of two segments a0 + s (a1 - a0), b0 + t (b1 - b0), s, t in [0, 1]
+// (Ericson, Real-Time Collision Detection 5.1.9 -- the capsule/capsule narrow phase of coal that
+// colmpc.ResidualDistanceCollision goes through after factory/robot_model.py:261-302 turned the
+// arm links into capsules).  Degenerate segments (spheres) are handled.
+// ---------------------------------------------------------------------------
+inline double clamp01(double x) { return x < 0.0 ? 0.0 : (x > 1.0 ? 1.0 : x); }
+void closest_seg_seg(const double *a0, const double *a1, const double *b0, const double *b1, double &s, double &t) {
+  const double eps = 1e-14;
+  double d1[3], d2[3], r[3];
+  for (int k = 0; k < 3; ++k) { d1[k] = a1[k] - a0[k]; d2[k] = b1[k] - b0[k]; r[k] = a0[k] - b0[k]; }
+  const double a = d1[0] * d1[0] + d1[1] * d1[1] + d1[2] * d1[2];
+  const double e = d2[0] * d2[0] + d2[1] * d2[1] + d2[2] * d2[2];
+  const double f = d2[0] * r[0] + d2[1] * r[1] + d2[2] * r[2];
+  if (a <= eps && e <= eps) { s = 0.0; t = 0.0; return; }
+  if (a <= eps) { s = 0.0; t = clamp01(f / e); return; }
+  const double c = d1[0] * r[0] + d1[1] * r[1] + d1[2] * r[2];
+  if (e <= eps) { t = 0.0; s = clamp01(-c / a); return; }
+  const double b = d1[0] * d2[0] + d1[1] * d2[1] + d1[2] * d2[2];
+  const double denom = a * e - b * b;
+  s = (denom > eps * a * e) ? clamp01((b * f - c * e) / denom) : 0.0;
+  t = (b * s + f) / e;
+  if (t < 0.0) { t = 0.0; s = clamp01(-c / a); }
+  else if (t > 1.0) { t = 1.0; s = clamp01((b - c) / a); }
+}
+
+// signed distance of two capsule / sphere geometry frames: |pa - pb| - ra - rb with pa, pb the
+// closest points of the segments; the segment parameters are held fixed while differentiating,
+// which gives exactly  d'(q) = n' (Ja(pa) - Jb(pb))  (App. A.6).
+template <class S> S collision_distance(const Model &m, int fa, int fb, const S *q) {
+  S Ra[9], pa[3], Rb[9], pb[3];
+  frame_placement(m, fa, q, Ra, pa);
+  frame_placement(m, fb, q, Rb, pb);
+  const double ha = m.frame_halflen[fa], hb = m.frame_halflen[fb];
+  double a0[3], a1[3], b0[3], b1[3];
+  for (int k = 0; k < 3; ++k) {
+    a0[k] = val(pa[k]) - ha * val(Ra[3 * k + 2]); a1[k] = val(pa[k]) + ha * val(Ra[3 * k + 2]);
+    b0[k] = val(pb[k]) - hb * val(Rb[3 * k + 2]); b1[k] = val(pb[k]) + hb * val(Rb[3 * k + 2]);
+  }
+  double sa, sb;
+  closest_seg_seg(a0, a1, b0, b1, sa, sb);
+  S d2 = S(0.0);
+  for (int k = 0; k < 3; ++k) {
+    S ca = pa[k] + ((2.0 * sa - 1.0) * ha) * Ra[3 * k + 2];
+    S cb = pb[k] + ((2.0 * sb - 1.0) * hb) * Rb[3 * k + 2];
+    S e = ca - cb;
+    d2 = d2 + e * e;
+  }
+  return sqrt(d2) - (m.frame_radius[fa] + m.frame_radius[fb]);
+}
+
+// ---------------------------------------------------------------------------
 // problem description
 // ---------------------------------------------------------------------------
 struct Ocp {
@@ -615,17 +671,45 @@ void node_eval(const Model &m, const Ocp &o, bool terminal, double dt, const S *
         matmul3(Rt, R, Rrel);
         log3_residual(Rrel, r.data());
       } break;
+      case AGX_RES_COLLISION:
+        // colmpc.ResidualDistanceCollision (ocp_croco_generic.py:524-533): signed distance of the pair
+        r[0] = collision_distance(m, row.frame, row.frame_b, q);
+        break;
       default:
         for (int i = 0; i < nr; ++i) r[i] = S(0.0);
         break;
     }
     double a_val = 0.0;
-    for (int j = 0; j < nr; ++j) {
-      double rv = val(r[j]);
-      // ActivationModelWeightedQuad: a = 1/2 sum w r^2 (tests/test_ocp_croco_generic.py:70-72)
-      a_val += 0.5 * aw[j] * rv * rv;
-      act_r.push_back(aw[j] * rv);
-      act_rr.push_back(aw[j]);
+    if (row.activation == AGX_ACT_WEIGHTED_QUAD) {
+      for (int j = 0; j < nr; ++j) {
+        double rv = val(r[j]);
+        // ActivationModelWeightedQuad: a = 1/2 sum w r^2 (tests/test_ocp_croco_generic.py:70-72)
+        a_val += 0.5 * aw[j] * rv * rv;
+        act_r.push_back(aw[j] * rv);
+        act_rr.push_back(aw[j]);
+      }
+    } else {
+      // colmpc activations (ocp_croco_generic.py:118-143), restated from recall (parity
+      // unpinned): QuadExp a = exp(-|r|^2 / alpha), Exp a = exp(-|r| / alpha); diagonal second derivative.
+      double n2 = 0.0;
+      for (int j = 0; j < nr; ++j) n2 += val(r[j]) * val(r[j]);
+      const double al = row.alpha;
+      if (row.activation == AGX_ACT_QUAD_EXP) {
+        a_val = std::exp(-n2 / al);
+        for (int j = 0; j < nr; ++j) {
+          const double rv = val(r[j]);
+          act_r.push_back(-2.0 * rv * a_val / al);
+          act_rr.push_back((-2.0 / al + 4.0 * rv * rv / (al * al)) * a_val);
+        }
+      } else {
+        const double n = std::sqrt(n2);
+        a_val = std::exp(-n / al);
+        for (int j = 0; j < nr; ++j) {
+          const double rv = val(r[j]);
+          act_r.push_back(n > 0.0 ? -a_val / al * rv / n : 0.0);
+          act_rr.push_back(a_val / (al * al));
+        }
+      }
     }
     const bool active = row.active != 0;
     row_w.push_back(active ? w_item : 0.0);
