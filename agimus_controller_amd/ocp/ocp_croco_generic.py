@@ -569,7 +569,7 @@ class DifferentialActionModelFreeFwdDynamics(DifferentialActionModel):
         for item in self.costs:
             res, act = item.cost.residual, item.cost.activation
             kind = res.kind
-            if kind in (_abi.RES_CONTROL_GRAV, _abi.RES_FRAME_VELOCITY):
+            if kind in (_abi.RES_CONTROL_GRAV, _abi.RES_FRAME_VELOCITY) or isinstance(res, ResidualDistanceCollision2):
                 raise NotImplementedError(f"cost '{item.name}': {type(res).__name__} is not implemented on the HIP path yet")
             act_kind = _abi.ACT_WEIGHTED_QUAD if act is None else act.kind
             alpha = 1.0 if act is None or act_kind == _abi.ACT_WEIGHTED_QUAD else act.alpha_value
