@@ -556,13 +556,35 @@ class DifferentialActionModelFreeFwdDynamics(DifferentialActionModel):
         residuals = [c.cost.residual for c in self.costs] + [c.constraint.residual for c in self.constraints or []]
         return any(r.needs_colmpc_freefwd_dynamics() for r in residuals)
 
+    def lower_constraints(self, data: BuildData, terminal: bool) -> list[_abi.ConstraintSpec]:
+        """ConstraintListItem list -> constraint rows (the counterpart of building a
+        crocoddyl.ConstraintModelManager, reference ocp_croco_generic.py:700-711)."""
+        out = []
+        for item in self.constraints or []:
+            con = item.constraint
+            res = con.residual
+            kind = res.kind
+            if kind in (_abi.RES_CONTROL_GRAV, _abi.RES_FRAME_VELOCITY) or isinstance(res, ResidualDistanceCollision2):
+                raise NotImplementedError(f"constraint '{item.name}': {type(res).__name__} is not implemented on the HIP path yet")
+            nr = _abi.row_nr(kind, data.nv)
+            if isinstance(con, ConstraintModelControlLimit):
+                lim = np.asarray(data.model.effortLimit, dtype=float)
+                lo, up = -lim, lim
+            else:
+                lo, up = con.bounds(nr)
+            active = bool(item.active) and not (terminal and (kind == _abi.RES_CONTROL or not con.active_on_terminal_node))
+            fa = fb = 0
+            if kind == _abi.RES_COLLISION:
+                fa, fb = res.geometry_frames(data)
+                ref = None
+            else:
+                fa = res.frame(data)
+                ref = np.asarray(res.reference(data), dtype=float).reshape(-1)
+            out.append(_abi.ConstraintSpec(kind=kind, lower=lo, upper=up, ref=ref, active=active, frame=fa, frame_b=fb, name=item.name))
+        return out
+
     def lower(self, data: BuildData) -> list[_abi.RowSpec]:
         """Cost items -> row table (the counterpart of building a crocoddyl.CostModelSum)."""
-        if any(c.active for c in self.constraints or []):
-            raise NotImplementedError(
-                "constraints (ConstraintModelManager / ADMM) are not implemented on the HIP path yet: "
-                + ", ".join(c.name for c in self.constraints)
-            )
         if len(self.costs) > _abi.AGX_MAX_ROWS:
             raise ValueError(f"at most {_abi.AGX_MAX_ROWS} cost items per node are supported")
         rows = []
@@ -642,6 +664,10 @@ class OCPCrocoGeneric(OCPBaseCroco):
 
     def create_terminal_model(self) -> list[_abi.RowSpec]:
         return self._data.terminal_model.differential.lower(self._build_data_obj)
+
+    def create_constraint_lists(self):
+        return (self._data.running_model.differential.lower_constraints(self._build_data_obj, False),
+                self._data.terminal_model.differential.lower_constraints(self._build_data_obj, True))
 
     # -- reference tile -------------------------------------------------------
     def _items(self, terminal: bool) -> list[CostModelSumItem]:

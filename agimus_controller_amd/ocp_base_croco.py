@@ -36,11 +36,14 @@ class OCPBaseCroco(OCPBase):
         # one row table per node type; every running node shares the table, its time step is per node
         self._running_rows = self.create_running_model_list()
         self._terminal_rows = self.create_terminal_model()
+        running_cons, terminal_cons = self.create_constraint_lists()
         self._packed = _abi.PackedOcp(
             nv,
             ocp_params.timesteps,
             self._running_rows,
             self._terminal_rows,
+            running_constraints=running_cons,
+            terminal_constraints=terminal_cons,
             termination_tolerance=ocp_params.termination_tolerance,
             max_qp_iters=ocp_params.qp_iters,
             eps_abs=ocp_params.eps_abs,
@@ -74,6 +77,10 @@ class OCPBaseCroco(OCPBase):
 
     @abc.abstractmethod
     def create_terminal_model(self) -> list[_abi.RowSpec]: ...
+
+    def create_constraint_lists(self):
+        """(running, terminal) lists of _abi.ConstraintSpec; none by default."""
+        return [], []
 
     def set_reference_weighted_trajectory(self, reference_weighted_trajectory=None):
         pass

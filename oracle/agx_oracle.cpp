@@ -528,6 +528,11 @@ struct Ocp {
   int stride = 0;
   double tol = 1e-3, mu_dyn = 10.0, mu_con = 10.0;
   int max_qp = 200;
+  double eps_abs = 1e-6, eps_rel = 0.0;
+  // ConstraintListItem rows (lower <= r(x,u) <= upper), 0 running / 1 terminal
+  struct ConRow { int kind, frame, frame_b; std::vector<double> ref, lower, upper; };
+  std::vector<ConRow> cons[2];
+  int nc[2] = {0, 0};
 };
 
 }  // namespace
@@ -584,6 +589,28 @@ void copy_ocp(const agx_ocp_desc *d, int nv, Ocp &o) {
   o.mu_dyn = d->mu_dynamic;
   o.mu_con = d->mu_constraint;
   o.max_qp = d->max_qp_iters;
+  o.eps_abs = d->eps_abs;
+  o.eps_rel = d->eps_rel;
+  for (int s = 0; s < 2; ++s) {
+    const int n = s == 0 ? d->n_running_constraints : d->n_terminal_constraints;
+    const agx_constraint_row *rows = s == 0 ? d->running_constraints : d->terminal_constraints;
+    o.cons[s].clear();
+    o.nc[s] = 0;
+    for (int i = 0; i < n; ++i) {
+      if (!rows[i].active) continue;
+      Ocp::ConRow c;
+      c.kind = rows[i].kind; c.frame = rows[i].frame; c.frame_b = rows[i].frame_b;
+      const int nref = agx_row_nref(c.kind, nv), nr = agx_row_nr(c.kind, nv);
+      c.ref.assign(nref, 0.0);
+      if (rows[i].ref) c.ref.assign(rows[i].ref, rows[i].ref + nref);
+      if (c.kind == AGX_RES_FRAME_PLACEMENT || c.kind == AGX_RES_FRAME_ROTATION)
+        if (!rows[i].ref) { c.ref[0] = c.ref[4] = c.ref[8] = 1.0; }
+      c.lower.assign(rows[i].lower, rows[i].lower + nr);
+      c.upper.assign(rows[i].upper, rows[i].upper + nr);
+      o.nc[s] += nr;
+      o.cons[s].push_back(c);
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -595,6 +622,64 @@ struct NodeOut {  // plain doubles
   double cost = 0.0;
   std::vector<double> residuals;  // concatenated per-row residual values
 };
+
+// One residual of the YAML schema (ocp_croco_generic.py:147-550) at (x, u): shared by cost rows and
+// constraint rows.  r has agx_row_nr(kind) entries.
+template <class S>
+void eval_residual(const Model &m, int kind, int frame, int frame_b, const double *rref, bool terminal, const S *x,
+                   const S *u, S *rout) {
+  const int nv = m.nv;
+  const S *q = x;
+  const int nr = agx_row_nr(kind, nv);
+  S *r = rout;
+    switch (kind) {
+      case AGX_RES_STATE:
+        for (int i = 0; i < 2 * nv; ++i) r[i] = x[i] - rref[i];
+        break;
+      case AGX_RES_CONTROL:
+        for (int i = 0; i < nv; ++i) r[i] = terminal ? S(0.0) : (u[i] - rref[i]);
+        break;
+      case AGX_RES_CONTROL_GRAV: {
+        std::vector<S> zero(nv, S(0.0)), g(nv);
+        rnea(m, q, zero.data(), zero.data(), g.data(), true);
+        for (int i = 0; i < nv; ++i) r[i] = terminal ? S(0.0) : (u[i] - g[i]);
+      } break;
+      case AGX_RES_FRAME_PLACEMENT: {
+        S R[9], p[3];
+        frame_placement(m, frame, q, R, p);
+        S Rr[9], pr[3];
+        for (int k = 0; k < 9; ++k) Rr[k] = S(rref[k]);
+        for (int k = 0; k < 3; ++k) pr[k] = S(rref[9 + k]);
+        // rMf = Mref^-1 * oMf
+        S Rt[9] = {Rr[0], Rr[3], Rr[6], Rr[1], Rr[4], Rr[7], Rr[2], Rr[5], Rr[8]};
+        S Rrel[9], d[3], prel[3];
+        matmul3(Rt, R, Rrel);
+        for (int k = 0; k < 3; ++k) d[k] = p[k] - pr[k];
+        matvec3(Rt, d, prel);
+        log6_residual(Rrel, prel, r);
+      } break;
+      case AGX_RES_FRAME_TRANSLATION: {
+        S R[9], p[3];
+        frame_placement(m, frame, q, R, p);
+        for (int k = 0; k < 3; ++k) r[k] = p[k] - rref[k];
+      } break;
+      case AGX_RES_FRAME_ROTATION: {
+        S R[9], p[3];
+        frame_placement(m, frame, q, R, p);
+        S Rt[9] = {S(rref[0]), S(rref[3]), S(rref[6]), S(rref[1]), S(rref[4]), S(rref[7]), S(rref[2]), S(rref[5]), S(rref[8])};
+        S Rrel[9];
+        matmul3(Rt, R, Rrel);
+        log3_residual(Rrel, r);
+      } break;
+      case AGX_RES_COLLISION:
+        // colmpc.ResidualDistanceCollision (ocp_croco_generic.py:524-533): signed distance of the pair
+        r[0] = collision_distance(m, frame, frame_b, q);
+        break;
+      default:
+        for (int i = 0; i < nr; ++i) r[i] = S(0.0);
+        break;
+    }
+}
 
 template <class S>
 void node_eval(const Model &m, const Ocp &o, bool terminal, double dt, const S *x, const S *u,
@@ -632,53 +717,7 @@ void node_eval(const Model &m, const Ocp &o, bool terminal, double dt, const S *
     if (frame < 0) frame = row.frame;
     static thread_local std::vector<S> r;
     r.resize(nr);
-    switch (row.kind) {
-      case AGX_RES_STATE:
-        for (int i = 0; i < 2 * nv; ++i) r[i] = x[i] - rref[i];
-        break;
-      case AGX_RES_CONTROL:
-        for (int i = 0; i < nv; ++i) r[i] = terminal ? S(0.0) : (u[i] - rref[i]);
-        break;
-      case AGX_RES_CONTROL_GRAV: {
-        std::vector<S> zero(nv, S(0.0)), g(nv);
-        rnea(m, q, zero.data(), zero.data(), g.data(), true);
-        for (int i = 0; i < nv; ++i) r[i] = terminal ? S(0.0) : (u[i] - g[i]);
-      } break;
-      case AGX_RES_FRAME_PLACEMENT: {
-        S R[9], p[3];
-        frame_placement(m, frame, q, R, p);
-        S Rr[9], pr[3];
-        for (int k = 0; k < 9; ++k) Rr[k] = S(rref[k]);
-        for (int k = 0; k < 3; ++k) pr[k] = S(rref[9 + k]);
-        // rMf = Mref^-1 * oMf
-        S Rt[9] = {Rr[0], Rr[3], Rr[6], Rr[1], Rr[4], Rr[7], Rr[2], Rr[5], Rr[8]};
-        S Rrel[9], d[3], prel[3];
-        matmul3(Rt, R, Rrel);
-        for (int k = 0; k < 3; ++k) d[k] = p[k] - pr[k];
-        matvec3(Rt, d, prel);
-        log6_residual(Rrel, prel, r.data());
-      } break;
-      case AGX_RES_FRAME_TRANSLATION: {
-        S R[9], p[3];
-        frame_placement(m, frame, q, R, p);
-        for (int k = 0; k < 3; ++k) r[k] = p[k] - rref[k];
-      } break;
-      case AGX_RES_FRAME_ROTATION: {
-        S R[9], p[3];
-        frame_placement(m, frame, q, R, p);
-        S Rt[9] = {S(rref[0]), S(rref[3]), S(rref[6]), S(rref[1]), S(rref[4]), S(rref[7]), S(rref[2]), S(rref[5]), S(rref[8])};
-        S Rrel[9];
-        matmul3(Rt, R, Rrel);
-        log3_residual(Rrel, r.data());
-      } break;
-      case AGX_RES_COLLISION:
-        // colmpc.ResidualDistanceCollision (ocp_croco_generic.py:524-533): signed distance of the pair
-        r[0] = collision_distance(m, row.frame, row.frame_b, q);
-        break;
-      default:
-        for (int i = 0; i < nr; ++i) r[i] = S(0.0);
-        break;
-    }
+    eval_residual(m, row.kind, frame, row.frame_b, rref, terminal, x, u, r.data());
     double a_val = 0.0;
     if (row.activation == AGX_ACT_WEIGHTED_QUAD) {
       for (int j = 0; j < nr; ++j) {
@@ -762,6 +801,70 @@ void node_calc_diff_n(const Model &m, const Ocp &o, bool terminal, double dt, co
       }
     }
   }
+}
+
+// ---------------------------------------------------------------------------
+// Constraints of one node: g(x,u) stacked over the active ConstraintListItem rows, bounds, and
+// (DIFF) the Jacobians Gx [nc][nx], Gu [nc][nu]  (crocoddyl ConstraintModelManager; ocp_croco_generic.py:554-647).
+// ---------------------------------------------------------------------------
+struct ConNode {
+  int nc = 0;
+  std::vector<double> g, Gx, Gu, lb, ub;
+};
+template <class S>
+void eval_constraints(const Model &m, const Ocp &o, bool terminal, const S *x, const S *u, std::vector<S> &g) {
+  const auto &rows = o.cons[terminal ? 1 : 0];
+  g.clear();
+  static thread_local std::vector<S> r;
+  for (const auto &c : rows) {
+    const int nr = agx_row_nr(c.kind, m.nv);
+    r.resize(nr);
+    eval_residual(m, c.kind, c.frame, c.frame_b, c.ref.data(), terminal, x, u, r.data());
+    for (int j = 0; j < nr; ++j) g.push_back(r[j]);
+  }
+}
+void con_bounds(const Ocp &o, bool terminal, ConNode &n) {
+  n.lb.clear(); n.ub.clear();
+  for (const auto &c : o.cons[terminal ? 1 : 0]) {
+    n.lb.insert(n.lb.end(), c.lower.begin(), c.lower.end());
+    n.ub.insert(n.ub.end(), c.upper.begin(), c.upper.end());
+  }
+  n.nc = (int)n.lb.size();
+}
+template <int N>
+void node_constraints_diff_n(const Model &m, const Ocp &o, bool terminal, const double *x, const double *u, ConNode &n) {
+  typedef Dual<N> D;
+  const int nv = m.nv, nx = 2 * nv, nu = nv;
+  static thread_local std::vector<D> xd, ud, g;
+  xd.resize(nx); ud.resize(nu);
+  for (int i = 0; i < nx; ++i) { xd[i] = D(x[i]); xd[i].d[i] = 1.0; }
+  for (int i = 0; i < nu; ++i) { ud[i] = D(terminal ? 0.0 : u[i]); ud[i].d[nx + i] = 1.0; }
+  eval_constraints<D>(m, o, terminal, xd.data(), ud.data(), g);
+  con_bounds(o, terminal, n);
+  n.g.resize(n.nc); n.Gx.assign((size_t)n.nc * nx, 0.0); n.Gu.assign((size_t)n.nc * nu, 0.0);
+  for (int k = 0; k < n.nc; ++k) {
+    n.g[k] = g[k].v;
+    for (int j = 0; j < nx; ++j) n.Gx[(size_t)k * nx + j] = g[k].d[j];
+    for (int j = 0; j < nu; ++j) n.Gu[(size_t)k * nu + j] = terminal ? 0.0 : g[k].d[nx + j];
+  }
+}
+void node_constraints_diff(const Model &m, const Ocp &o, bool terminal, const double *x, const double *u, ConNode &n) {
+  const int nd = 3 * m.nv;
+  if (nd <= 8) node_constraints_diff_n<8>(m, o, terminal, x, u, n);
+  else if (nd <= 24) node_constraints_diff_n<24>(m, o, terminal, x, u, n);
+  else node_constraints_diff_n<96>(m, o, terminal, x, u, n);
+}
+// l1 norm of the violation of lb <= g <= ub at one node (mim_solvers SolverCSQP::calc / tryStep)
+double node_constraint_violation(const Model &m, const Ocp &o, bool terminal, const double *x, const double *u) {
+  if (o.nc[terminal ? 1 : 0] == 0) return 0.0;
+  static thread_local std::vector<double> g, uz;
+  static thread_local ConNode n;
+  uz.assign(m.nv, 0.0);
+  eval_constraints<double>(m, o, terminal, x, terminal ? uz.data() : u, g);
+  con_bounds(o, terminal, n);
+  double v = 0.0;
+  for (int k = 0; k < n.nc; ++k) v += std::max(n.lb[k] - g[k], 0.0) + std::max(g[k] - n.ub[k], 0.0);
+  return v;
 }
 
 void node_calc_diff(const Model &m, const Ocp &o, bool terminal, double dt, const double *x,
@@ -896,21 +999,196 @@ bool direction(int nv, int T, const double *tiles, Direction &d, double sigma = 
 }
 
 // ---------------------------------------------------------------------------
+// Constrained QP direction: mim_solvers::SolverCSQP::computeDirection restated from recall
+// (no fixture of the reference covers it: parity UNPINNED).
+//   equality-QP initial guess (plain LQR) -> prox centres (dx, du);
+//   ADMM iterations: backward pass on  H + sigma I + G' rho G,  g + G'(y - rho z) - sigma (centre),
+//   forward pass, then per node
+//     z_rel = alpha C d + (1 - alpha) z,  z = clip(z_rel + y / rho, lb - g, ub - g),  y += rho (z_rel - z)
+//   rho adapted every 25 iterations from the primal / dual residual ratio; stop when both residuals
+//   are below eps_abs + eps_rel * scale.  Duals y and rho persist across SQP iterations and solves
+//   (reset_y = reset_rho = false, the solver defaults).  The backward pass is redone in full at every
+//   iteration here; the reference re-factorises only when rho changed, which is the same arithmetic.
+// ---------------------------------------------------------------------------
+struct Admm {
+  std::vector<std::vector<double>> y, z, rho;  // per node
+  double rho_sparse = 1e-1;
+  bool init = false;
+  int qp_iters = 0;
+};
+const double kRhoMin = 1e-6, kRhoMax = 1e3, kAdaptiveRhoTol = 5.0, kAlphaRelax = 1.6, kSigma = 1e-6;
+const int kRhoInterval = 25;
+
+void admm_apply_rho(const std::vector<ConNode> &cn, Admm &a) {
+  for (size_t t = 0; t < cn.size(); ++t) {
+    a.rho[t].resize(cn[t].nc);
+    for (int k = 0; k < cn[t].nc; ++k) {
+      const double lb = cn[t].lb[k], ub = cn[t].ub[k];
+      if (lb == -INFINITY && ub == INFINITY) a.rho[t][k] = kRhoMin;
+      else if (std::fabs(lb - ub) <= 1e-6) a.rho[t][k] = 1e3 * a.rho_sparse;
+      else a.rho[t][k] = a.rho_sparse;
+    }
+  }
+}
+
+bool direction_admm(int nv, int T, const double *tiles, const std::vector<ConNode> &cn, const Ocp &o, Admm &a,
+                    double preg, double dreg, Direction &d, std::vector<double> &aug) {
+  const int nx = 2 * nv, nu = nv, TILE = AGX_TILE_DOUBLES(nv);
+  const int oLx = nx * nx + nx * nu + nx, oLu = oLx + nx, oLxx = oLu + nu, oLxu = oLxx + nx * nx, oLuu = oLxu + nx * nu;
+  if (!a.init || (int)a.y.size() != T + 1) {
+    a.y.assign(T + 1, {}); a.z.assign(T + 1, {}); a.rho.assign(T + 1, {});
+    a.rho_sparse = 1e-1;
+    a.init = true;
+  }
+  for (int t = 0; t <= T; ++t) {
+    if ((int)a.y[t].size() != cn[t].nc) a.y[t].assign(cn[t].nc, 0.0);
+    a.z[t].assign(cn[t].nc, 0.0);  // reset_params(): z = 0, y kept
+  }
+  admm_apply_rho(cn, a);
+  // equality-constrained QP initial guess
+  Direction d0;
+  bool ok = direction(nv, T, tiles, d0, 0.0, preg, dreg);
+  std::vector<double> cx = d0.dx, cu = d0.du;
+  aug.assign(tiles, tiles + (size_t)(T + 1) * TILE);
+  std::vector<double> Cd, zprev, zrel, h;
+  a.qp_iters = o.max_qp;
+  for (int iter = 1; iter <= o.max_qp; ++iter) {
+    // augmented tiles
+    for (int t = 0; t <= T; ++t) {
+      const ConNode &n = cn[t];
+      if (n.nc == 0) continue;
+      const double *src = tiles + (size_t)t * TILE;
+      double *dst = aug.data() + (size_t)t * TILE;
+      std::memcpy(dst + oLx, src + oLx, sizeof(double) * (TILE - oLx));
+      h.resize(n.nc);
+      for (int k = 0; k < n.nc; ++k) h[k] = a.y[t][k] - a.rho[t][k] * a.z[t][k];
+      for (int k = 0; k < n.nc; ++k) {
+        const double rk = a.rho[t][k];
+        const double *gx = &n.Gx[(size_t)k * nx], *gu = &n.Gu[(size_t)k * nu];
+        for (int i = 0; i < nx; ++i) {
+          dst[oLx + i] += gx[i] * h[k];
+          for (int j = 0; j < nx; ++j) dst[oLxx + i * nx + j] += rk * gx[i] * gx[j];
+          if (t < T) for (int j = 0; j < nu; ++j) dst[oLxu + i * nu + j] += rk * gx[i] * gu[j];
+        }
+        if (t < T)
+          for (int i = 0; i < nu; ++i) {
+            dst[oLu + i] += gu[i] * h[k];
+            for (int j = 0; j < nu; ++j) dst[oLuu + i * nu + j] += rk * gu[i] * gu[j];
+          }
+      }
+    }
+    ok = direction(nv, T, aug.data(), d, kSigma, preg, dreg, cx.data(), cu.data()) && ok;
+    // update_lagrangian_parameters
+    double norm_primal = 0.0, norm_dual = 0.0, norm_primal_rel = 0.0, norm_dual_rel = 0.0;
+    for (int t = 0; t <= T; ++t) {
+      const ConNode &n = cn[t];
+      if (n.nc == 0) continue;
+      const double *dx = &d.dx[(size_t)t * nx], *du = t < T ? &d.du[(size_t)t * nu] : nullptr;
+      Cd.assign(n.nc, 0.0); zprev = a.z[t]; zrel.resize(n.nc);
+      for (int k = 0; k < n.nc; ++k) {
+        double c = 0.0;
+        for (int j = 0; j < nx; ++j) c += n.Gx[(size_t)k * nx + j] * dx[j];
+        if (du) for (int j = 0; j < nu; ++j) c += n.Gu[(size_t)k * nu + j] * du[j];
+        Cd[k] = c;
+        zrel[k] = kAlphaRelax * c + (1.0 - kAlphaRelax) * a.z[t][k];
+        double zn = zrel[k] + a.y[t][k] / a.rho[t][k];
+        zn = std::min(std::max(zn, n.lb[k] - n.g[k]), n.ub[k] - n.g[k]);
+        a.z[t][k] = zn;
+        a.y[t][k] += a.rho[t][k] * (zrel[k] - zn);
+        norm_primal = std::max(norm_primal, std::fabs(c - zn));
+        norm_primal_rel = std::max(norm_primal_rel, std::max(std::fabs(c), std::fabs(zn)));
+      }
+      for (int j = 0; j < nx; ++j) {
+        double s1 = 0.0, s2 = 0.0;
+        for (int k = 0; k < n.nc; ++k) { s1 += n.Gx[(size_t)k * nx + j] * a.rho[t][k] * (a.z[t][k] - zprev[k]); s2 += n.Gx[(size_t)k * nx + j] * a.y[t][k]; }
+        norm_dual = std::max(norm_dual, std::fabs(s1)); norm_dual_rel = std::max(norm_dual_rel, std::fabs(s2));
+      }
+      if (du)
+        for (int j = 0; j < nu; ++j) {
+          double s1 = 0.0, s2 = 0.0;
+          for (int k = 0; k < n.nc; ++k) { s1 += n.Gu[(size_t)k * nu + j] * a.rho[t][k] * (a.z[t][k] - zprev[k]); s2 += n.Gu[(size_t)k * nu + j] * a.y[t][k]; }
+          norm_dual = std::max(norm_dual, std::fabs(s1)); norm_dual_rel = std::max(norm_dual_rel, std::fabs(s2));
+        }
+    }
+    cx = d.dx; cu = d.du;
+    // update_rho_vec
+    {
+      double scale = std::sqrt((norm_primal * norm_dual_rel) / (norm_dual * norm_primal_rel));
+      double est = scale * a.rho_sparse;
+      est = std::min(std::max(est, kRhoMin), kRhoMax);
+      if (iter % kRhoInterval == 0 && iter > 1)
+        if (est > a.rho_sparse * kAdaptiveRhoTol || est < a.rho_sparse / kAdaptiveRhoTol) {
+          a.rho_sparse = est;
+          admm_apply_rho(cn, a);
+        }
+    }
+    if (norm_primal <= o.eps_abs + o.eps_rel * norm_primal_rel && norm_dual <= o.eps_abs + o.eps_rel * norm_dual_rel) {
+      a.qp_iters = iter;
+      break;
+    }
+  }
+  // KKT with the constraint multipliers (checkKKTConditions): stationarity with + G' y
+  const int oFx = 0, oFu = nx * nx, of = oFu + nx * nu;
+  double kkt = 0.0;
+  for (int t = 0; t < T; ++t) {
+    const double *n = tiles + (size_t)t * TILE;
+    const double *Fx = n + oFx, *Fu = n + oFu, *f = n + of, *Lx = n + oLx, *Lu = n + oLu;
+    const double *ln = &d.lag[(size_t)(t + 1) * nx], *lt = &d.lag[(size_t)t * nx];
+    const ConNode &c = cn[t];
+    if (t > 0)
+      for (int i = 0; i < nx; ++i) {
+        double s = Lx[i] - lt[i];
+        for (int k = 0; k < nx; ++k) s += Fx[k * nx + i] * ln[k];
+        for (int k = 0; k < c.nc; ++k) s += c.Gx[(size_t)k * nx + i] * a.y[t][k];
+        kkt = std::max(kkt, std::fabs(s));
+      }
+    for (int i = 0; i < nu; ++i) {
+      double s = Lu[i];
+      for (int k = 0; k < nx; ++k) s += Fu[k * nu + i] * ln[k];
+      for (int k = 0; k < c.nc; ++k) s += c.Gu[(size_t)k * nu + i] * a.y[t][k];
+      kkt = std::max(kkt, std::fabs(s));
+    }
+    for (int i = 0; i < nx; ++i) kkt = std::max(kkt, std::fabs(f[i]));
+  }
+  {
+    const double *Lx = tiles + (size_t)T * TILE + oLx;
+    const double *lt = &d.lag[(size_t)T * nx];
+    const ConNode &c = cn[T];
+    for (int i = 0; i < nx; ++i) {
+      double s = Lx[i] - lt[i];
+      for (int k = 0; k < c.nc; ++k) s += c.Gx[(size_t)k * nx + i] * a.y[T][k];
+      kkt = std::max(kkt, std::fabs(s));
+    }
+  }
+  d.kkt = kkt;
+  return ok;
+}
+
+// ---------------------------------------------------------------------------
 // SQP outer loop for one instance.
 // ---------------------------------------------------------------------------
 struct Workspace {
-  std::vector<double> tiles, xs_try, us_try, xn;
+  std::vector<double> tiles, xs_try, us_try, xn, aug;
   Direction dir;
   NodeOut node;
+  std::vector<ConNode> cn;
 };
 
 void eval_tiles(const Model &m, const Ocp &o, const double *xs, const double *us, const double *ref,
-                const int32_t *frames, Workspace &w, double &cost, double &gap1) {
+                const int32_t *frames, Workspace &w, double &cost, double &gap1, double *con1 = nullptr) {
   const int nv = m.nv, nx = 2 * nv, nu = nv, T = o.T, TILE = AGX_TILE_DOUBLES(nv);
   w.tiles.resize((size_t)(T + 1) * TILE);
   cost = 0.0; gap1 = 0.0;
+  const bool has_con = o.nc[0] + o.nc[1] > 0;
+  if (has_con) w.cn.resize(T + 1);
+  if (con1) *con1 = 0.0;
   for (int t = 0; t <= T; ++t) {
     const bool term = (t == T);
+    if (has_con) {
+      ConNode &c = w.cn[t];
+      node_constraints_diff(m, o, term, xs + (size_t)t * nx, term ? nullptr : us + (size_t)t * nu, c);
+      if (con1) for (int k = 0; k < c.nc; ++k) *con1 += std::max(c.lb[k] - c.g[k], 0.0) + std::max(c.g[k] - c.ub[k], 0.0);
+    }
     node_calc_diff(m, o, term, term ? 0.0 : o.dt[t], xs + (size_t)t * nx, term ? nullptr : us + (size_t)t * nu,
                    ref + (size_t)t * o.stride, frames ? frames + (size_t)t * AGX_MAX_ROWS : nullptr, w.node);
     pack_tile(nv, w.node, term ? nullptr : xs + (size_t)(t + 1) * nx, &w.tiles[(size_t)t * TILE]);
@@ -921,8 +1199,9 @@ void eval_tiles(const Model &m, const Ocp &o, const double *xs, const double *us
 
 void solve_one(const Model &m, const Ocp &o, const double *ref, const int32_t *frames, const double *x0,
                const double *xs_ws, const double *us_ws, int max_iter, double max_time, double *xs, double *us,
-               double *K, agx_status *st, Workspace &w) {
+               double *K, agx_status *st, Workspace &w, Admm *admm = nullptr) {
   const int nv = m.nv, nx = 2 * nv, nu = nv, T = o.T;
+  const bool has_con = (o.nc[0] + o.nc[1] > 0) && admm != nullptr;
   auto t_start = std::chrono::steady_clock::now();
   std::memcpy(xs, xs_ws, sizeof(double) * (T + 1) * nx);
   std::memcpy(us, us_ws, sizeof(double) * T * nu);
@@ -938,18 +1217,26 @@ void solve_one(const Model &m, const Ocp &o, const double *ref, const int32_t *f
   double preg = reg_min, dreg = reg_min;
   Direction dirK;
   auto final_gains = [&]() {
+    if (has_con) return;  // constrained: K already holds the gains of the last ADMM backward pass
     // K reported by the solver comes from the sigma-regularised ADMM backward pass
     direction(nv, T, w.tiles.data(), dirK, sigma, preg, dreg, w.dir.dx.data(), w.dir.du.data());
     std::memcpy(K, dirK.K.data(), sizeof(double) * T * nu * nx);
   };
   bool have_dir = false;
   for (; it < max_iter; ++it) {
-    double cost, gap1;
-    eval_tiles(m, o, xs, us, ref, frames, w, cost, gap1);
-    const double merit = cost + o.mu_dyn * gap1;
-    bool ok = direction(nv, T, w.tiles.data(), w.dir, 0.0, preg, dreg);
+    double cost, gap1, con1 = 0.0;
+    eval_tiles(m, o, xs, us, ref, frames, w, cost, gap1, &con1);
+    const double merit = cost + o.mu_dyn * gap1 + o.mu_con * con1;
+    bool ok;
+    if (has_con) {
+      ok = direction_admm(nv, T, w.tiles.data(), w.cn, o, *admm, preg, dreg, w.dir, w.aug);
+      w.dir.kkt = std::max(w.dir.kkt, con1);  // checkKKTConditions: KKT = max(KKT, constraint_norm)
+      std::memcpy(K, w.dir.K.data(), sizeof(double) * T * nu * nx);
+    } else {
+      ok = direction(nv, T, w.tiles.data(), w.dir, 0.0, preg, dreg);
+    }
     have_dir = true;
-    st->kkt = w.dir.kkt; st->cost = cost; st->merit = merit; st->gap_norm = gap1; st->qp_iters = 1;
+    st->kkt = w.dir.kkt; st->cost = cost; st->merit = merit; st->gap_norm = gap1; st->qp_iters = has_con ? admm->qp_iters : 1;
     if (!ok) st->flags |= 1;
     if (w.dir.kkt <= o.tol) { st->solved = 1; break; }
     // merit line search, alpha = 2^-n, n = 0..9, no rollout
@@ -959,7 +1246,7 @@ void solve_one(const Model &m, const Ocp &o, const double *ref, const int32_t *f
       used = alpha;
       for (size_t i = 0; i < (size_t)(T + 1) * nx; ++i) w.xs_try[i] = xs[i] + alpha * w.dir.dx[i];
       for (size_t i = 0; i < (size_t)T * nu; ++i) w.us_try[i] = us[i] + alpha * w.dir.du[i];
-      double cost_try = 0.0, gap_try = 0.0;
+      double cost_try = 0.0, gap_try = 0.0, con_try = 0.0;
       for (int t = 0; t <= T; ++t) {
         const bool term = (t == T);
         double c;
@@ -967,8 +1254,9 @@ void solve_one(const Model &m, const Ocp &o, const double *ref, const int32_t *f
                   ref + (size_t)t * o.stride, frames ? frames + (size_t)t * AGX_MAX_ROWS : nullptr, w.xn.data(), c);
         cost_try += c;
         if (!term) for (int i = 0; i < nx; ++i) gap_try += std::fabs(w.xn[i] - w.xs_try[(size_t)(t + 1) * nx + i]);
+        if (has_con) con_try += node_constraint_violation(m, o, term, &w.xs_try[(size_t)t * nx], term ? nullptr : &w.us_try[(size_t)t * nu]);
       }
-      const double merit_try = cost_try + o.mu_dyn * gap_try;
+      const double merit_try = cost_try + o.mu_dyn * gap_try + o.mu_con * con_try;
       if (merit > merit_try) { accepted = true; break; }
     }
     const bool last = (it + 1 == max_iter);
@@ -998,6 +1286,7 @@ struct OrcOcp {
   Model m;
   Ocp o;
   int B;
+  std::vector<Admm> admm;  // per instance; duals and rho persist across solves like the solver object's
 };
 
 thread_local std::string g_err;
@@ -1014,6 +1303,7 @@ int orc_ocp_create(const agx_model_desc *md, const agx_ocp_desc *od, int batch, 
   copy_model(md, p->m);
   copy_ocp(od, md->nv, p->o);
   p->B = batch;
+  p->admm.resize(batch);
   *out = p;
   return 0;
 }
@@ -1123,8 +1413,27 @@ int orc_solve(void *h, const double *ref, const int32_t *frames, const double *x
     Workspace w;
     solve_one(p->m, p->o, ref + (size_t)b * (T + 1) * p->o.stride, frames ? frames + (size_t)b * (T + 1) * AGX_MAX_ROWS : nullptr,
               x0 + (size_t)b * nx, xs_ws + (size_t)b * (T + 1) * nx, us_ws + (size_t)b * T * nu, max_iter, max_time,
-              xs + (size_t)b * (T + 1) * nx, us + (size_t)b * T * nu, K + (size_t)b * T * nu * nx, st + b, w);
+              xs + (size_t)b * (T + 1) * nx, us + (size_t)b * T * nu, K + (size_t)b * T * nu * nx, st + b, w, &p->admm[b]);
   }
+  return 0;
+}
+
+// forget the constraint multipliers and rho of every instance (a freshly constructed solver)
+int orc_reset_duals(void *h) {
+  OrcOcp *p = static_cast<OrcOcp *>(h);
+  for (auto &a : p->admm) a = Admm();
+  return 0;
+}
+
+// constraint values of one node: g [nc], and the node's bounds (test hook)
+int orc_node_constraints(void *h, int terminal, const double *x, const double *u, double *g, double *Gx, double *Gu, int *nc) {
+  OrcOcp *p = static_cast<OrcOcp *>(h);
+  ConNode n;
+  node_constraints_diff(p->m, p->o, terminal != 0, x, u, n);
+  if (nc) *nc = n.nc;
+  if (g) std::memcpy(g, n.g.data(), sizeof(double) * n.nc);
+  if (Gx) std::memcpy(Gx, n.Gx.data(), sizeof(double) * n.Gx.size());
+  if (Gu) std::memcpy(Gu, n.Gu.data(), sizeof(double) * n.Gu.size());
   return 0;
 }
 

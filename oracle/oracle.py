@@ -169,6 +169,20 @@ class Oracle:
         )
         return xs, us, K, st
 
+    def reset_duals(self):
+        lib().orc_reset_duals(self._h)
+
+    def node_constraints(self, terminal, x, u):
+        x = _f8(x)
+        u = _f8(u) if u is not None else np.zeros(self.nu)
+        g = np.zeros(4 * self.nx + 16)
+        Gx = np.zeros((g.size, self.nx))
+        Gu = np.zeros((g.size, self.nu))
+        nc = C.c_int(0)
+        lib().orc_node_constraints(self._h, int(terminal), _p(x), _p(u), _p(g), _p(Gx), _p(Gu), C.byref(nc))
+        n = nc.value
+        return g[:n], Gx.reshape(-1)[: n * self.nx].reshape(n, self.nx), Gu.reshape(-1)[: n * self.nu].reshape(n, self.nu)
+
     def shift_warmstart(self, xs, us):
         xs, us = _f8(xs).copy(), _f8(us).copy()
         lib().orc_shift_warmstart(self._h, _p(xs), _p(us))

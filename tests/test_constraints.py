@@ -1,0 +1,112 @@
+"""Constraints through ADMM (SolverCSQP.computeDirection; section 8 a-1 / a-6 / f-2).
+
+No fixture of the reference exercises constraints and mim_solvers is absent: parity with the reference
+binaries is UNPINNED for this path.  These tests pin the CPU checker's constrained solve through
+properties (feasibility, KKT, agreement with the unconstrained solve when no bound is active) and the
+HIP path against the CPU checker.
+"""
+import numpy as np
+import pytest
+
+from agimus_controller_amd import _abi, workloads
+from agimus_controller_amd.factory import robot_tables as rt
+
+
+def _oracle(table, po, B=1):
+    from oracle.oracle import Oracle
+
+    return Oracle(table, po, B)
+
+
+def _control_limit_problem(limit, T=16, B=2, seed=3, max_qp=200):
+    table = rt.panda_table(0.1)
+    tcp = table.frame_id("panda_hand_tcp")
+    running, terminal = workloads.goal_reaching_rows(tcp)
+    cons = [] if limit is None else [_abi.ConstraintSpec(_abi.RES_CONTROL, lower=-np.asarray(limit), upper=np.asarray(limit), name="ulim")]
+    po = _abi.PackedOcp(7, [0.01] * T, running, terminal, max_qp_iters=max_qp, running_constraints=cons)
+    _, ref, x0, xs, us = workloads.random_goal_problem(table, T, 0.01, B, seed, frame=tcp)
+    return table, po, ref, x0, xs, us
+
+
+def test_inactive_control_limits_reproduce_the_unconstrained_solve():
+    table, po0, ref, x0, xs, us = _control_limit_problem(None)
+    r0 = _oracle(table, po0, 2).solve(ref, None, x0, xs, us, 30)
+    _, po1, *_ = _control_limit_problem(np.full(7, 1e3))
+    r1 = _oracle(table, po1, 2).solve(ref, None, x0, xs, us, 30)
+    assert np.array_equal(r0[3]["iter"], r1[3]["iter"])
+    np.testing.assert_allclose(r1[0], r0[0], atol=1e-6)
+    np.testing.assert_allclose(r1[1], r0[1], atol=1e-4)
+    assert np.all(r1[3]["qp_iters"] < 200)
+
+
+def test_active_control_limits_are_respected_and_converge():
+    lim = np.full(7, 15.0)
+    table, po, ref, x0, xs, us = _control_limit_problem(lim, max_qp=400)
+    xs_c, us_c, K, st = _oracle(table, po, 2).solve(ref, None, x0, xs, us, 40)
+    assert np.all(st["solved"] == 1)
+    assert np.abs(us_c).max() <= 15.0 + 1e-4
+    assert np.all(st["kkt"] <= 1e-3)
+    # the unconstrained optimum needs more torque than allowed: the bound really is active
+    _, po0, *_ = _control_limit_problem(None)
+    us_u = _oracle(table, po0, 2).solve(ref, None, x0, xs, us, 40)[1]
+    assert np.abs(us_u).max() > 30.0
+
+
+def test_duals_persist_across_solves_like_the_solver_object():
+    """reset_y = reset_rho = false: a second solve from the same warm start starts from the
+    multipliers of the first one and needs no more QP iterations than the first."""
+    lim = np.full(7, 15.0)
+    table, po, ref, x0, xs, us = _control_limit_problem(lim, B=1, max_qp=400)
+    o = _oracle(table, po, 1)
+    r1 = o.solve(ref[:1], None, x0[:1], xs[:1], us[:1], 40)
+    r2 = o.solve(ref[:1], None, x0[:1], r1[0], r1[1], 40)
+    assert r2[3]["iter"][0] <= 1  # warm start at the solution: converged immediately or after one step
+    o.reset_duals()
+    r3 = o.solve(ref[:1], None, x0[:1], xs[:1], us[:1], 40)
+    np.testing.assert_allclose(r3[0], r1[0], atol=1e-9)
+
+
+def test_collision_constraint_keeps_the_pair_apart():
+    """ocp_traj_tracking_collision_avoidance.yaml:48-56: distance >= lower on the collision pair."""
+    table = rt.panda_collision_table(0.1, obstacle_xyz=(0.45, 0.1, 0.45), obstacle_radius=0.08, obstacle_length=0.3)
+    tcp = table.frame_id("panda_hand_tcp")
+    T, B = 12, 2
+    running, terminal = workloads.goal_reaching_rows(tcp)
+    fa, fb = table.frame_id("panda_link7_capsule_0"), table.frame_id("obstacle")
+    con = [_abi.ConstraintSpec(_abi.RES_COLLISION, lower=0.05, upper=np.inf, frame=fa, frame_b=fb, name="collision")]
+    po = _abi.PackedOcp(7, [0.01] * T, running, terminal, max_qp_iters=400, running_constraints=con, terminal_constraints=con)
+    _, ref, x0, xs, us = workloads.random_goal_problem(table, T, 0.01, B, 23, frame=tcp)
+    o = _oracle(table, po, B)
+    xs_c, us_c, K, st = o.solve(ref, None, x0, xs, us, 60)
+    for b in range(B):
+        for t in range(1, T + 1):
+            g, Gx, Gu = o.node_constraints(t == T, xs_c[b, t], None if t == T else us_c[b, min(t, T - 1)])
+            assert g[0] >= 0.05 - 2e-3, (b, t, g[0])
+    assert np.all(np.isfinite(K))
+
+
+def test_yaml_constraints_lower_to_rows():
+    from agimus_controller_amd.ocp import ocp_croco_generic as g
+    from agimus_controller_amd.factory.robot_model import RobotModelParameters, RobotModels
+
+    table = rt.panda_collision_table(0.1)
+    rm = RobotModels(RobotModelParameters(table=table, armature=table.armature, collision_pairs=[("panda_link7_capsule_0", "obstacle")]))
+    diff = g.create_croco_dataclasses({
+        "class": "DifferentialActionModelFreeFwdDynamics",
+        "costs": [{"name": "state_reg", "cost": {"class": "CostModelResidual", "residual": {"class": "ResidualModelState"}}}],
+        "constraints": [
+            {"name": "collision", "constraint": {"class": "ConstraintModelResidual", "lower": 0.01, "upper": "inf",
+                                                   "residual": {"class": "ResidualDistanceCollision", "collision_pair_id": 0}}},
+            {"name": "torque", "constraint": {"class": "ConstraintModelControlLimit"}},
+        ],
+    })
+    data = g.BuildData(rm.robot_model, 7, rm.collision_model)
+    run = diff.lower_constraints(data, False)
+    assert [c.kind for c in run] == [_abi.RES_COLLISION, _abi.RES_CONTROL]
+    assert float(np.asarray(run[0].lower).reshape(-1)[0]) == pytest.approx(0.01) and np.isinf(np.asarray(run[0].upper)).all()
+    np.testing.assert_allclose(run[1].upper, table.effort_limit)
+    np.testing.assert_allclose(run[1].lower, -table.effort_limit)
+    term = diff.lower_constraints(data, True)
+    assert term[0].active and not term[1].active  # no control at the terminal node
+    po = _abi.PackedOcp(7, [0.01] * 4, diff.lower(data), diff.lower(data), running_constraints=run, terminal_constraints=term)
+    assert po.desc.n_running_constraints == 2 and po.desc.n_terminal_constraints == 2
