@@ -190,8 +190,10 @@ def test_yaml_unknown_class_and_unsupported_components():
         {"name": "torque", "constraint": {"class": "ConstraintModelControlLimit"}}]
     sp = gen.ShootingProblem(**bad)
     assert isinstance(sp.running_model.differential.constraints[0].constraint.residual, gen.ResidualModelControl)
-    with pytest.raises(NotImplementedError, match="constraints"):
-        sp.running_model.differential.lower(gen.BuildData(panda_robot_models().robot_model, 7))
+    bd = gen.BuildData(panda_robot_models().robot_model, 7)
+    cons = sp.running_model.differential.lower_constraints(bd, False)
+    assert len(cons) == 1 and cons[0].kind == _abi.RES_CONTROL and cons[0].active
+    np.testing.assert_allclose(cons[0].upper, panda_robot_models().robot_model.effortLimit)
     coll = yaml.safe_load(REFERENCE_STYLE_YAML)
     coll["running_model"]["differential"]["costs"].append(
         {"name": "col", "cost": {"class": "CostModelResidual", "residual": {"class": "ResidualDistanceCollision2", "collision_pair": ["a", "b"]},
