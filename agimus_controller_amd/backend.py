@@ -25,7 +25,7 @@ EXPORTED_SYMBOLS = [
     "agx_last_error", "agx_device_count", "agx_row_nref", "agx_row_nr", "agx_ref_stride",
     "agx_model_create", "agx_model_destroy", "agx_ocp_create", "agx_ocp_destroy", "agx_ocp_set_stream",
     "agx_ocp_sync", "agx_ocp_set_refs", "agx_ocp_set_refs_device", "agx_ocp_solve", "agx_ocp_upload_x0",
-    "agx_ocp_upload_warmstart", "agx_ocp_solve_resident", "agx_ocp_download", "agx_ocp_download_first", "agx_ocp_first_packed", "agx_ocp_set_geom_placement",
+    "agx_ocp_upload_warmstart", "agx_ocp_solve_resident", "agx_ocp_download", "agx_ocp_download_first", "agx_ocp_first_packed", "agx_ocp_set_geom_placement", "agx_ocp_reset_duals",
     "agx_ocp_shift_warmstart", "agx_ocp_x0_from_prediction", "agx_ocp_integrate", "agx_model_rnea",
     "agx_model_frame_placement", "agx_ocp_get_residuals", "agx_ocp_calc_diff", "agx_ocp_direction",
     "agx_ocp_time_kernel", "agx_ocp_profile", "agx_traj_sine_create", "agx_traj_set_window",
@@ -205,6 +205,9 @@ class HipOcp:
     def set_geom_placement(self, frame: int, se3_12):
         """OCPBaseCroco.update_geometry_placement (ocp_base_croco.py:110-132) for a geometry frame."""
         _chk(lib().agx_ocp_set_geom_placement(self._h, int(frame), _p(_f8(se3_12).reshape(12))))
+
+    def reset_duals(self):
+        _chk(lib().agx_ocp_reset_duals(self._h))
 
     def shift_warmstart(self):
         _chk(lib().agx_ocp_shift_warmstart(self._h))

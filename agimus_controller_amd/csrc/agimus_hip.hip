@@ -50,6 +50,10 @@ struct agx_ocp {
   double *d_dt = nullptr, *d_xs = nullptr, *d_us = nullptr, *d_x0 = nullptr, *d_tiles = nullptr;
   double *d_Kws = nullptr, *d_kws = nullptr, *d_Kout = nullptr, *d_dx = nullptr, *d_du = nullptr;
   double *d_qt = nullptr, *d_aux = nullptr, *d_w = nullptr, *d_nodestat = nullptr;  // QP tiles, aux tiles, acceleration steps
+  // constrained problems (agx_admm.hpp): augmented tiles, constraint values / collision Jacobians,
+  // multipliers y (persistent across solves), slack z, prox centre, per-node residual norms
+  bool has_con = false;
+  double *d_qt2 = nullptr, *d_cg = nullptr, *d_cjac = nullptr, *d_y = nullptr, *d_z = nullptr, *d_cx = nullptr, *d_admmstat = nullptr;
   int qt_size = 0, aux_size = 0;
   bool k1_lanes = true;  // AGX_K1_LANES=0 selects the one-lane-per-node derivative kernel
   bool lanes_ok = true;  // problem fits the LDS staging of the 8-lanes-per-node kernel
@@ -115,6 +119,37 @@ void fill_rows(const agx_cost_row *rows, int n, int nv, DevRows &d) {
     d.off[r] = off;
     off += 1 + d.nref[r] + d.nr[r];
   }
+}
+
+int fill_cons(const agx_constraint_row *rows, int n, int nv, const DevModel &m, DevCons &d) {
+  std::memset(&d, 0, sizeof(d));
+  int off = 0;
+  for (int r = 0; r < n; ++r) {
+    const agx_constraint_row &c = rows[r];
+    if (!c.active) continue;
+    if (d.n >= AGX_MAX_CONS) return fail("agx_ocp_create: at most 4 active constraint rows per node type");
+    if (c.kind != AGX_RES_STATE && c.kind != AGX_RES_CONTROL && c.kind != AGX_RES_COLLISION)
+      return fail("agx_ocp_create: constraints are implemented for State, Control (ControlLimit) and collision-distance residuals");
+    const int nr = agx_row_nr(c.kind, nv), nref = agx_row_nref(c.kind, nv);
+    if (off + nr > AGX_MAX_NC) return fail("agx_ocp_create: more than 32 constraint components per node");
+    if (!c.lower || !c.upper) return fail("agx_ocp_create: constraint bounds missing");
+    const int i = d.n++;
+    d.kind[i] = c.kind; d.frame[i] = c.frame; d.frame_b[i] = c.frame_b; d.off[i] = off; d.nr[i] = nr;
+    for (int k = 0; k < nref; ++k) d.ref[i][k] = c.ref ? c.ref[k] : 0.0;
+    for (int k = 0; k < nr; ++k) {
+      d.lb[off + k] = c.lower[k]; d.ub[off + k] = c.upper[k];
+      if (!(c.lower[k] <= c.upper[k])) return fail("agx_ocp_create: constraint with lower > upper");
+    }
+    if (c.kind == AGX_RES_COLLISION) {
+      if (c.frame < 0 || c.frame >= m.nframes || c.frame_b < 0 || c.frame_b >= m.nframes || !(m.frame_radius[c.frame] > 0.0) ||
+          !(m.frame_radius[c.frame_b] > 0.0))
+        return fail("agx_ocp_create: collision constraint refers to a frame without geometry");
+      d.coll_slot[i] = d.ncoll++;
+    }
+    off += nr;
+  }
+  d.nc = off;
+  return 0;
 }
 
 // ---- dispatch over the compiled (NV, CHAIN) instantiations --------------------
@@ -188,28 +223,31 @@ int launch_calc_qp(agx_ocp *o, bool running_only = false, bool term_only = false
 }
 
 // K2: direction sweep; with `pair` the speculative gains sweep of SQP iteration `iter` rides in the same launch
-int launch_riccati(agx_ocp *o, int forward, bool pair = false, int iter = 0) {
+int launch_riccati(agx_ocp *o, int forward, bool pair = false, int iter = 0, const double *tiles = nullptr) {
   return dispatch(o->nv, o->chain, [&](auto NVc, auto CHc) -> int {
     constexpr int NV = decltype(NVc)::value;
+    const double *qt = tiles ? tiles : o->d_qt;
     if (pair)
       hipLaunchKernelGGL((agx::k_riccati_pair<NV>), dim3(2 * o->B), dim3(64), 0, o->stream, o->d_ocp, o->d_dt, o->d_qt, o->d_aux,
                          o->d_Kws, o->d_kws, o->d_dx, o->d_w, o->d_du, o->d_Kout, o->d_state, iter);
     else
-      hipLaunchKernelGGL((agx::k_riccati<NV, false>), dim3(o->B), dim3(64), 0, o->stream, o->d_ocp, o->d_dt, o->d_qt, o->d_aux,
+      hipLaunchKernelGGL((agx::k_riccati<NV, false>), dim3(o->B), dim3(64), 0, o->stream, o->d_ocp, o->d_dt, qt, o->d_aux,
                          o->d_Kws, o->d_kws, o->d_dx, o->d_w, o->d_du, o->d_Kout, o->d_state, forward, 0);
     HIPCHK(hipGetLastError());
     return 0;
   });
 }
 
-int launch_step(agx_ocp *o, int iter, int max_iter, int mode) {
+int launch_step(agx_ocp *o, int iter, int max_iter, int mode, bool with_node_kkt = true, bool with_step = true) {
   if (o->T + 1 > 512) return fail("step kernel supports horizons up to 511 nodes");
   return dispatch(o->nv, o->chain, [&](auto NVc, auto CHc) -> int {
     constexpr int NV = decltype(NVc)::value;
     constexpr bool CH = decltype(CHc)::value;
     const long long nodes = (long long)o->B * (o->T + 1);
-    hipLaunchKernelGGL((agx::k_node_kkt<NV>), dim3((int)((nodes * 8 + 255) / 256)), dim3(256), 0, o->stream, o->d_ocp, o->d_qt, o->d_aux,
-                       o->d_dx, o->d_w, o->d_du, o->d_nodestat, o->d_state);
+    if (with_node_kkt)
+      hipLaunchKernelGGL((agx::k_node_kkt<NV>), dim3((int)((nodes * 8 + 255) / 256)), dim3(256), 0, o->stream, o->d_ocp, o->d_qt, o->d_aux,
+                         o->d_dx, o->d_w, o->d_du, o->d_nodestat, o->d_state);
+    if (!with_step) { HIPCHK(hipGetLastError()); return 0; }
     hipLaunchKernelGGL((agx::k_step<NV, CH>), dim3(o->B), dim3(128), 0, o->stream, o->d_model, o->d_ocp, o->d_dt, o->d_xs, o->d_us,
                        o->rv, o->d_qt, o->d_aux, o->d_dx, o->d_nodestat, o->d_du, o->d_state, iter, max_iter, mode, o->d_ndone);
     HIPCHK(hipGetLastError());
@@ -282,6 +320,60 @@ int wait_stamp(agx_ocp *o, int slot_seq, int seq) {
   }
 }
 
+// stream-ordered read of one device int (polled stamp or copy + synchronize)
+int read_int(agx_ocp *o, const int *d_value, int slot_value, int slot_seq, int *out) {
+  const int seq = ++o->seq;
+  if (o->poll) {
+    if (publish(o, slot_value, slot_seq, d_value, seq)) return -1;
+    if (wait_stamp(o, slot_seq, seq)) return -1;
+  } else {
+    HIPCHK(hipMemcpyAsync(o->h_ndone + slot_value, d_value, sizeof(int), hipMemcpyDeviceToHost, o->stream));
+    HIPCHK(hipStreamSynchronize(o->stream));
+  }
+  *out = __atomic_load_n(o->h_ndone + slot_value, __ATOMIC_ACQUIRE);
+  return 0;
+}
+
+// Constrained direction of one SQP iteration (SolverCSQP::computeDirection): the plain LQR pass has
+// run (equality-QP initial guess: dx, w); now du, the constraint data and the ADMM loop.
+int admm_direction(agx_ocp *o) {
+  return dispatch(o->nv, o->chain, [&](auto NVc, auto CHc) -> int {
+    constexpr int NV = decltype(NVc)::value;
+    constexpr bool CH = decltype(CHc)::value;
+    const long long nodes = (long long)o->B * (o->T + 1);
+    const int g8 = (int)((nodes * 8 + 255) / 256), g8b = (int)((nodes * 8 + 127) / 128), g1 = (int)((nodes + 255) / 256);
+    if (launch_step(o, 0, 0, 0, true, false)) return -1;  // du of the initial guess (k_node_kkt)
+    HIPCHK(hipMemsetAsync(o->d_ndone + 1, 0, sizeof(int), o->stream));
+    hipLaunchKernelGGL((agx::k_admm_init<NV>), dim3(g1), dim3(256), 0, o->stream, o->d_ocp, o->d_dx, o->d_cx, o->d_z, o->d_state,
+                       o->d_ndone + 1);
+    hipLaunchKernelGGL((agx::k_con_eval<NV, CH>), dim3((int)((nodes + 63) / 64)), dim3(64), 0, o->stream, o->d_model, o->d_ocp, o->d_xs,
+                       o->d_us, o->d_cg, o->d_cjac, o->d_nodestat, o->d_state);
+    HIPCHK(hipGetLastError());
+    const int max_qp = o->ho.max_qp;
+    for (int iter = 1; iter <= max_qp; ++iter) {
+      hipLaunchKernelGGL((agx::k_admm_tile<NV>), dim3(g8b), dim3(128), 0, o->stream, o->d_ocp, o->d_qt, o->d_qt2, o->d_aux, o->d_cx,
+                         o->d_du, o->d_cjac, o->d_y, o->d_z, o->d_state);
+      if (launch_riccati(o, 1, false, 0, o->d_qt2)) return -1;
+      hipLaunchKernelGGL((agx::k_admm_update<NV>), dim3(g8), dim3(256), 0, o->stream, o->d_ocp, o->d_qt, o->d_aux, o->d_dx, o->d_w,
+                         o->d_du, o->d_cx, o->d_cg, o->d_cjac, o->d_y, o->d_z, o->d_nodestat, o->d_admmstat, o->d_state);
+      hipLaunchKernelGGL(agx::k_admm_reduce, dim3(o->B), dim3(128), 0, o->stream, o->d_ocp, o->d_admmstat, o->d_state, iter,
+                         o->d_ndone + 1);
+      HIPCHK(hipGetLastError());
+      if (iter % 4 == 0 || iter == max_qp) {
+        int n_conv = 0;
+        if (read_int(o, o->d_ndone + 1, 4, 5, &n_conv)) return -1;
+        if (n_conv >= o->B) break;
+      }
+    }
+    // the gains the solver reports: those of the last ADMM backward pass, in u-space
+    const long long units = (long long)o->B * o->T * 16;
+    hipLaunchKernelGGL((agx::k_gains_to_u<NV>), dim3((int)((units + 255) / 256)), dim3(256), 0, o->stream, o->d_ocp, o->d_aux, o->d_Kws,
+                       o->d_Kout, o->d_state);
+    HIPCHK(hipGetLastError());
+    return 0;
+  });
+}
+
 // The SQP loop of SolverCSQP::solve on the resident buffers.
 int solve_resident(agx_ocp *o, int max_iter, double max_time) {
   if (max_iter <= 0) max_iter = 1000;
@@ -304,10 +396,11 @@ int solve_resident(agx_ocp *o, int max_iter, double max_time) {
     if (launch_calc_qp(o, false, true)) return -1;  // terminal nodes
     if (prof_mark(o, 1, true)) return -1;
     // from the second iteration on (where warm-started MPC steps converge) the gains sweep rides along
-    if (launch_riccati(o, 1, o->speculate && it >= 1, it)) return -1;
+    if (launch_riccati(o, 1, o->speculate && it >= 1 && !o->has_con, it)) return -1;
+    if (o->has_con && admm_direction(o)) return -1;
     if (prof_mark(o, 1, false)) return -1;
     if (prof_mark(o, 2, true)) return -1;
-    if (launch_step(o, it, max_iter, 1)) return -1;
+    if (launch_step(o, it, max_iter, 1, !o->has_con, true)) return -1;
     if (prof_mark(o, 2, false)) return -1;
     if (it + 1 == max_iter) break;
     // early exit once every instance has finished (one 4-byte read back)
@@ -331,7 +424,7 @@ int solve_resident(agx_ocp *o, int max_iter, double max_time) {
       if (el > max_time) break;
     }
   }
-  if (launch_gains(o, 2)) return -1;  // instances whose last direction has no gains sweep yet
+  if (!o->has_con && launch_gains(o, 2)) return -1;  // instances whose last direction has no gains sweep yet
   return prof_collect(o);
 }
 
@@ -445,8 +538,6 @@ int agx_ocp_create(const agx_model *m, const agx_ocp_desc *d, int batch, int dev
         return fail("agx_ocp_create: collision pair refers to a frame without geometry (radius 0)");
     }
   }
-  if (d->n_running_constraints > 0 || d->n_terminal_constraints > 0)
-    return fail("agx_ocp_create: constraints (ADMM) are not implemented on the HIP path yet");
   agx_ocp *o = new agx_ocp();
   o->hm = m->h;
   o->nv = m->h.nv; o->nx = 2 * o->nv; o->nu = o->nv;
@@ -466,6 +557,14 @@ int agx_ocp_create(const agx_model *m, const agx_ocp_desc *d, int batch, int dev
   o->ho.tol = d->termination_tolerance;
   o->ho.mu_dyn = d->mu_dynamic;
   o->ho.mu_con = d->mu_constraint;
+  if (fill_cons(d->running_constraints, d->n_running_constraints, o->nv, m->h, o->ho.cons[0]) ||
+      fill_cons(d->terminal_constraints, d->n_terminal_constraints, o->nv, m->h, o->ho.cons[1])) { delete o; return -1; }
+  o->has_con = o->ho.cons[0].nc + o->ho.cons[1].nc > 0;
+  o->ho.has_con = o->has_con ? 1 : 0;
+  o->ho.max_qp = d->max_qp_iters > 0 ? d->max_qp_iters : 1000;
+  o->ho.eps_abs = d->eps_abs;
+  o->ho.eps_rel = d->eps_rel;
+  if (o->has_con && o->nv > 7) { delete o; return fail("agx_ocp_create: constraints need the register Riccati kernel (nv <= 7)"); }
   {
     auto n_frame_rows = [](const DevRows &r) {
       int n = 0;
@@ -509,10 +608,19 @@ int agx_ocp_create(const agx_model *m, const agx_ocp_desc *d, int batch, int dev
   ALLOC(o->d_ref, B * (T + 1) * (size_t)o->stride);
   ALLOC(o->d_frames, B * (T + 1) * AGX_MAX_ROWS);
   ALLOC(o->d_state, B);
-  ALLOC(o->d_ndone, 1);
+  ALLOC(o->d_ndone, 2);  // [0] finished instances, [1] instances whose ADMM loop has ended
+  if (o->has_con) {
+    ALLOC(o->d_qt2, B * (T + 1) * (size_t)o->qt_size);
+    ALLOC(o->d_cg, B * (T + 1) * AGX_MAX_NC);
+    ALLOC(o->d_cjac, B * (T + 1) * AGX_MAX_CONS * 8);
+    ALLOC(o->d_y, B * (T + 1) * AGX_MAX_NC);
+    ALLOC(o->d_z, B * (T + 1) * AGX_MAX_NC);
+    ALLOC(o->d_cx, B * (T + 1) * nx);
+    ALLOC(o->d_admmstat, B * (T + 1) * 4);
+  }
 #undef ALLOC
-  if (hipHostMalloc((void **)&o->h_ndone, 4 * sizeof(int), hipHostMallocMapped) != hipSuccess) { agx_ocp_destroy(o); return fail("hipHostMalloc failed"); }
-  std::memset(o->h_ndone, 0, 4 * sizeof(int));
+  if (hipHostMalloc((void **)&o->h_ndone, 8 * sizeof(int), hipHostMallocMapped) != hipSuccess) { agx_ocp_destroy(o); return fail("hipHostMalloc failed"); }
+  std::memset(o->h_ndone, 0, 8 * sizeof(int));
   if (hipHostGetDevicePointer((void **)&o->h_ndone_dev, o->h_ndone, 0) != hipSuccess) o->poll = false;
   if (const char *e = getenv("AGX_HOST_POLL")) o->poll = o->poll && (e[0] != '0');
   if (hipMemcpy(o->d_model, &o->hm, sizeof(DevModel), hipMemcpyHostToDevice) != hipSuccess ||
@@ -541,7 +649,8 @@ void agx_ocp_destroy(agx_ocp *o) {
   (void)hipSetDevice(o->device);
   if (o->stream) (void)hipStreamSynchronize(o->stream);
   void *ptrs[] = {o->d_model, o->d_ocp, o->d_dt, o->d_xs, o->d_us, o->d_x0, o->d_tiles, o->d_Kws, o->d_kws, o->d_Kout, o->d_dx,
-                  o->d_du, o->d_ref, o->d_frames, o->d_state, o->d_ndone, o->d_scratch, o->d_traj, o->d_pts, o->d_sine, o->d_qt, o->d_aux, o->d_w, o->d_nodestat};
+                  o->d_du, o->d_ref, o->d_frames, o->d_state, o->d_ndone, o->d_scratch, o->d_traj, o->d_pts, o->d_sine, o->d_qt, o->d_aux, o->d_w, o->d_nodestat,
+                  o->d_qt2, o->d_cg, o->d_cjac, o->d_y, o->d_z, o->d_cx, o->d_admmstat};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
   if (o->h_ndone) (void)hipHostFree(o->h_ndone);
@@ -572,6 +681,16 @@ int agx_ocp_set_stream(agx_ocp *o, void *hip_stream) {
 int agx_ocp_sync(agx_ocp *o) {
   if (!o) return fail("null handle");
   if (set_device(o)) return -1;
+  HIPCHK(hipStreamSynchronize(o->stream));
+  return 0;
+}
+
+int agx_ocp_reset_duals(agx_ocp *o) {
+  if (!o) return fail("null handle");
+  if (set_device(o)) return -1;
+  if (o->has_con) HIPCHK(hipMemsetAsync(o->d_y, 0, sizeof(double) * (size_t)o->B * (o->T + 1) * AGX_MAX_NC, o->stream));
+  hipLaunchKernelGGL(agx::k_reset_rho, dim3((o->B + 255) / 256), dim3(256), 0, o->stream, o->d_state, o->B);
+  HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(o->stream));
   return 0;
 }

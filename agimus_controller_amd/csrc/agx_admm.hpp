@@ -1,0 +1,387 @@
+// agimus_controller_amd -- constrained QP direction: the ADMM loop of mim_solvers::SolverCSQP
+// (computeDirection / backwardPass / forwardPass / update_lagrangian_parameters / update_rho_vec),
+// restated from recall (parity with the reference binaries unpinned, checked against
+// the CPU restatement under oracle/).  Correctness-first layout: every ADMM iteration is
+//
+//   k_admm_tile    node parallel   QP tile + sigma / rho / y / z / prox-centre terms -> augmented tile
+//   k_riccati      one wave / instance (the production kernel, unchanged) on the augmented tile
+//   k_admm_update  node parallel   du, C d, z / y update, residual norms, the node's KKT share
+//   k_admm_reduce  one block / instance: norms, rho adaptation, convergence
+//
+// Supported constraint kinds: Control (ConstraintModelControlLimit), State, collision distance.
+// In the acceleration-input coordinates of the QP tiles (du = M w + taux dx) a constraint row with
+// Jacobians (Gx, Gu) has the row  c = [Gx + Gu taux | Gu M]  on (dx, w).
+//
+// (included at the end of agx_kernels.hpp)
+#pragma once
+
+namespace agx {
+
+constexpr double kAlphaRelax = 1.6;  // SolverCSQP alpha
+constexpr double kRhoMin = 1e-6, kRhoMax = 1e3, kAdaptiveRhoTol = 5.0;
+constexpr int kRhoInterval = 25;
+
+// g, collision Jacobians and the l1 violation of every node at the current (xs, us).
+// One lane per node.  cg [B][T+1][AGX_MAX_NC], cjac [B][T+1][AGX_MAX_CONS][8].
+template <int NV, bool CHAIN>
+__global__ void __launch_bounds__(64) k_con_eval(const DevModel *__restrict__ mp, const DevOcp *__restrict__ op,
+                                                 const double *__restrict__ xs, const double *__restrict__ us,
+                                                 double *__restrict__ cg, double *__restrict__ cjac,
+                                                 double *__restrict__ nodestat, const DevState *__restrict__ st) {
+  constexpr int NX = 2 * NV, NU = NV;
+  const DevModel &m = *mp;
+  const DevOcp &o = *op;
+  const int T = o.T;
+  const long long node = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (node >= (long long)o.B * (T + 1)) return;
+  const int b = (int)(node / (T + 1)), t = (int)(node % (T + 1));
+  if (st[b].done) return;
+  const DevCons &c = o.cons[t == T ? 1 : 0];
+  double x[NX], u[NU], g[AGX_MAX_NC], cj[AGX_MAX_CONS][8];
+#pragma unroll
+  for (int i = 0; i < NX; ++i) x[i] = xs[node * NX + i];
+#pragma unroll
+  for (int i = 0; i < NU; ++i) u[i] = (t < T) ? us[((long long)b * T + t) * NU + i] : 0.0;
+  for (int k = 0; k < AGX_MAX_NC; ++k) g[k] = 0.0;
+  constraints_eval<NV, CHAIN, true>(m, c, x, u, g, cj);
+  for (int k = 0; k < c.nc; ++k) cg[node * AGX_MAX_NC + k] = g[k];
+  for (int r = 0; r < c.ncoll; ++r)
+    for (int j = 0; j < 8; ++j) cjac[(node * AGX_MAX_CONS + r) * 8 + j] = (j < NV) ? cj[r][j] : 0.0;
+  nodestat[node * 4 + 3] = violation_l1(c, g);
+}
+
+// Start of the ADMM loop of one SQP iteration (reset_params + equality-QP initial guess): prox centre
+// cx <- dx of the plain LQR pass (du was written by k_node_kkt), z <- 0, y kept.
+template <int NV>
+__global__ void __launch_bounds__(256) k_admm_init(const DevOcp *__restrict__ op, const double *__restrict__ dxs,
+                                                   double *__restrict__ cxs, double *__restrict__ zs, DevState *__restrict__ st,
+                                                   int *__restrict__ n_conv) {
+  constexpr int NX = 2 * NV;
+  const DevOcp &o = *op;
+  const int T = o.T;
+  const long long node = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (node >= (long long)o.B * (T + 1)) return;
+  const int b = (int)(node / (T + 1)), t = (int)(node % (T + 1));
+  DevState &S = st[b];
+  if (S.done) {
+    if (t == 0) atomicAdd(n_conv, 1);  // finished instances count as converged: the host waits for B
+    return;
+  }
+  for (int i = 0; i < NX; ++i) cxs[node * NX + i] = dxs[node * NX + i];
+  for (int k = 0; k < AGX_MAX_NC; ++k) zs[node * AGX_MAX_NC + k] = 0.0;
+  if (t == 0) {
+    S.admm_conv = 0;
+    S.admm_iter = o.max_qp;
+    if (!(S.rho_sparse > 0.0)) S.rho_sparse = 1e-1;  // rho_sparse_base of a fresh solver
+  }
+}
+
+// Augmented QP tile of one node: 8 lanes per node, lane j owns column j of every block.
+//   H  += [taux M]' diag(sigma + rho_u) [taux M] + sigma I_x + rho_x (state rows) + rho g g' (collision)
+//   g  += [taux M]' (h_u - sigma du_c) - sigma dx_c + h_x + h g,      h = y - rho z
+template <int NV>
+__global__ void __launch_bounds__(128) k_admm_tile(const DevOcp *__restrict__ op, const double *__restrict__ qts,
+                                                   double *__restrict__ qt2s, const double *__restrict__ auxs,
+                                                   const double *__restrict__ cxs, const double *__restrict__ dus,
+                                                   const double *__restrict__ cjac, const double *__restrict__ ys,
+                                                   const double *__restrict__ zs, const DevState *__restrict__ st) {
+  constexpr int NX = 2 * NV, LD = 8, B2 = NV * LD;
+  typedef QT<NV> Q;
+  typedef AUX<NV> A;
+  __shared__ double lds[16][3 * B2 + 2];
+  const DevOcp &o = *op;
+  const int T = o.T;
+  const int l8 = threadIdx.x & 7, grp = threadIdx.x >> 3;
+  const long long n_nodes = (long long)o.B * (T + 1);
+  const long long node = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 3;
+  const bool ok = node < n_nodes;
+  const long long unit = ok ? node : 0;
+  const int b = (int)(unit / (T + 1)), t = (int)(unit % (T + 1));
+  const DevState &S = st[b];
+  const bool live = ok && !S.done && !S.admm_conv;
+  const double *qt = qts + unit * Q::SIZE;
+  double *q2 = qt2s + unit * Q::SIZE;
+  const double *ax = auxs + unit * A::SIZE;
+  const double *cx = cxs + unit * NX;
+  const double *y = ys + unit * AGX_MAX_NC, *z = zs + unit * AGX_MAX_NC;
+  const DevCons &c = o.cons[t == T ? 1 : 0];
+  const double sig = kSigma, rs = S.rho_sparse;
+  const bool jl = l8 < NV, wr = live && jl;
+  const int j = jl ? l8 : 0;
+  // stage M | tq | tv (contiguous in the aux tile)
+  double *sh = lds[grp];
+  for (int e = l8; e < 3 * B2; e += 8) sh[e] = ax[A::M + e];
+  __syncthreads();
+  // copy the base tile
+  if (live)
+    for (int e = l8; e < Q::SIZE; e += 8) q2[e] = qt[e];
+  __syncthreads();
+  // per-row weights on u (control rows) and the state / collision terms
+  double wu[NV], hu[NV];
+#pragma unroll
+  for (int l = 0; l < NV; ++l) { wu[l] = sig; hu[l] = 0.0; }
+  double add_qq_diag = sig, add_vv_diag = sig, gq = -sig * cx[j], gv = -sig * cx[NV + j];
+  for (int r = 0; r < c.n; ++r) {
+    const int off = c.off[r];
+    if (c.kind[r] == AGX_RES_CONTROL) {
+#pragma unroll
+      for (int l = 0; l < NV; ++l) {
+        const double rho = admm_rho(c.lb[off + l], c.ub[off + l], rs);
+        wu[l] += rho;
+        hu[l] += y[off + l] - rho * z[off + l];
+      }
+    } else if (c.kind[r] == AGX_RES_STATE) {
+      const double rq = admm_rho(c.lb[off + j], c.ub[off + j], rs), rv = admm_rho(c.lb[off + NV + j], c.ub[off + NV + j], rs);
+      add_qq_diag += rq; add_vv_diag += rv;
+      gq += y[off + j] - rq * z[off + j];
+      gv += y[off + NV + j] - rv * z[off + NV + j];
+    }
+  }
+  if (wr) {
+    q2[Q::Hqq + j * Q::LD + j] += add_qq_diag;
+    q2[Q::Hvv + j * Q::LD + j] += add_vv_diag;
+  }
+  // collision rows: rank one on the qq block
+  for (int r = 0; r < c.n; ++r) {
+    if (c.kind[r] != AGX_RES_COLLISION) continue;
+    const int off = c.off[r];
+    const double *gj = cjac + (unit * AGX_MAX_CONS + c.coll_slot[r]) * 8;
+    const double rho = admm_rho(c.lb[off], c.ub[off], rs);
+    const double h = y[off] - rho * z[off];
+    gq += h * gj[j];
+    if (wr)
+      for (int i = 0; i < NV; ++i) q2[Q::Hqq + i * Q::LD + j] += rho * gj[i] * gj[j];
+  }
+  double gwv = 0.0;
+  if (t < T) {
+    const double *du = dus + ((long long)b * T + t) * NV;
+    const double *Mm = sh, *tq = sh + B2, *tv = sh + 2 * B2;
+    double Mc[NV], tqc[NV], tvc[NV];
+#pragma unroll
+    for (int l = 0; l < NV; ++l) {
+      Mc[l] = Mm[l * LD + j]; tqc[l] = tq[l * LD + j]; tvc[l] = tv[l * LD + j];
+      const double e = hu[l] - sig * du[l];
+      gwv += Mc[l] * e; gq += tqc[l] * e; gv += tvc[l] * e;
+    }
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      double hww = 0.0, hqw = 0.0, hvw = 0.0, hqq = 0.0, hqv = 0.0, hvv = 0.0;
+#pragma unroll
+      for (int l = 0; l < NV; ++l) {
+        const double Mli = Mm[l * LD + i] * wu[l], tqli = tq[l * LD + i] * wu[l], tvli = tv[l * LD + i] * wu[l];
+        hww += Mli * Mc[l]; hqw += tqli * Mc[l]; hvw += tvli * Mc[l];
+        hqq += tqli * tqc[l]; hqv += tqli * tvc[l]; hvv += tvli * tvc[l];
+      }
+      if (wr) {
+        q2[Q::Hww + i * Q::LD + j] += hww;
+        q2[Q::Hqw + i * Q::LD + j] += hqw;
+        q2[Q::Hvw + i * Q::LD + j] += hvw;
+        q2[Q::Hqq + i * Q::LD + j] += hqq;
+        q2[Q::Hqv + i * Q::LD + j] += hqv;
+        q2[Q::Hvv + i * Q::LD + j] += hvv;
+      }
+    }
+  }
+  if (wr) {
+    if (t < T) q2[Q::gw + j] += gwv;
+    q2[Q::gx + j] += gq;
+    q2[Q::gx + NV + j] += gv;
+  }
+}
+
+// After the Riccati sweep on the augmented tiles: du, the multiplier update and the node's shares of
+// the ADMM residual norms and of the KKT residual.  8 lanes per node, lane j = component j.
+//   z_rel = alpha C d + (1 - alpha) z;  z = clip(z_rel + y / rho, lb - g, ub - g);  y += rho (z_rel - z)
+// KKT share through the optimality identity of the augmented QP (constraints):
+//   Lu + Fu' lam' + Gu' y = -[(Luu + preg) du + sigma (du - du_c) + Gu' (rho C d + h - y)]
+//   Lx + Fx' lam' - lam + Gx' y = -[(Lxx + dreg) dx + sigma (dx - dx_c) + Gx' (rho C d + h - y)],  h = y_old - rho z_old
+template <int NV>
+__global__ void __launch_bounds__(256) k_admm_update(const DevOcp *__restrict__ op, const double *__restrict__ qts,
+                                                     const double *__restrict__ auxs, const double *__restrict__ dxs,
+                                                     const double *__restrict__ wss, double *__restrict__ dus,
+                                                     double *__restrict__ cxs, const double *__restrict__ cg,
+                                                     const double *__restrict__ cjac, double *__restrict__ ys,
+                                                     double *__restrict__ zs, double *__restrict__ nodestat,
+                                                     double *__restrict__ admmstat, const DevState *__restrict__ st) {
+  constexpr int NX = 2 * NV;
+  typedef QT<NV> Q;
+  typedef AUX<NV> A;
+  const DevOcp &o = *op;
+  const int T = o.T;
+  const int l8 = threadIdx.x & 7;
+  const long long n_nodes = (long long)o.B * (T + 1);
+  const long long node = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 3;
+  const bool ok = node < n_nodes;
+  const long long nid = ok ? node : 0;
+  const int b = (int)(nid / (T + 1)), t = (int)(nid % (T + 1));
+  const DevState &S = st[b];
+  const bool act = ok && !S.done && !S.admm_conv;
+  if (!__any(act)) return;
+  const double preg = S.preg, dreg = S.dreg, rs = S.rho_sparse, sig = kSigma;
+  const bool jl = l8 < NV;
+  const int jj = jl ? l8 : 0;
+  const double *qt = qts + nid * Q::SIZE;
+  const double *ax = auxs + nid * A::SIZE;
+  const double *dx = dxs + nid * NX;
+  double *cx = cxs + nid * NX;
+  double *y = ys + nid * AGX_MAX_NC, *z = zs + nid * AGX_MAX_NC;
+  const double *g = cg + nid * AGX_MAX_NC;
+  const DevCons &c = o.cons[t == T ? 1 : 0];
+  const double dq = jl ? dx[jj] : 0.0, dv = jl ? dx[NV + jj] : 0.0;
+  const double cq = jl ? cx[jj] : 0.0, cv = jl ? cx[NV + jj] : 0.0;
+  double du = 0.0, duc = 0.0, kkt = 0.0, gap = 0.0;
+  if (t < T) {
+    const double wj = jl ? wss[((long long)b * T + t) * NV + jj] : 0.0;
+    const double fq = jl ? qt[Q::f + jj] : 0.0, fv = jl ? qt[Q::f + NV + jj] : 0.0;
+    kkt = fmax(fabs(fq), fabs(fv));
+    gap = fabs(fq) + fabs(fv);
+    double pr[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+      pr[i] = (i < NV) ? ax[A::M + i * A::LD + l8] * wj + ax[A::tq + i * A::LD + l8] * dq + ax[A::tv + i * A::LD + l8] * dv : 0.0;
+    du = transpose_reduce8(pr, l8);
+    duc = jl ? dus[((long long)b * T + t) * NV + jj] : 0.0;
+  }
+  // constraint rows: lane-local for State / Control components, group-wide for the collision scalar
+  double primal = 0.0, primal_rel = 0.0;
+  double dual_q = 0.0, dual_v = 0.0, dual_u = 0.0, drel_q = 0.0, drel_v = 0.0, drel_u = 0.0;  // (G' rho dz)_j, (G' y)_j
+  double e_q = 0.0, e_v = 0.0, e_u = 0.0;                                                   // (G' (rho C d + h - y))_j
+  auto comp = [&](int k, double Cd, double &dual, double &drel, double &e, double jac) {
+    const double rho = admm_rho(c.lb[k], c.ub[k], rs);
+    const double z0 = z[k], y0 = y[k];
+    const double zrel = kAlphaRelax * Cd + (1.0 - kAlphaRelax) * z0;
+    double zn = zrel + y0 / rho;
+    zn = fmin(fmax(zn, c.lb[k] - g[k]), c.ub[k] - g[k]);
+    const double yn = y0 + rho * (zrel - zn);
+    primal = fmax(primal, fabs(Cd - zn));
+    primal_rel = fmax(primal_rel, fmax(fabs(Cd), fabs(zn)));
+    dual += jac * rho * (zn - z0);
+    drel += jac * yn;
+    e += jac * (rho * Cd + (y0 - rho * z0) - yn);
+    return (double2){zn, yn};
+  };
+  for (int r = 0; r < c.n; ++r) {
+    const int off = c.off[r];
+    if (c.kind[r] == AGX_RES_CONTROL) {
+      if (jl && t < T) {
+        const double2 zy = comp(off + jj, du, dual_u, drel_u, e_u, 1.0);
+        if (act) { z[off + jj] = zy.x; y[off + jj] = zy.y; }
+      }
+    } else if (c.kind[r] == AGX_RES_STATE) {
+      if (jl) {
+        const double2 a = comp(off + jj, dq, dual_q, drel_q, e_q, 1.0);
+        const double2 bq = comp(off + NV + jj, dv, dual_v, drel_v, e_v, 1.0);
+        if (act) { z[off + jj] = a.x; y[off + jj] = a.y; z[off + NV + jj] = bq.x; y[off + NV + jj] = bq.y; }
+      }
+    } else if (c.kind[r] == AGX_RES_COLLISION) {
+      const double gj = jl ? cjac[(nid * AGX_MAX_CONS + c.coll_slot[r]) * 8 + jj] : 0.0;
+      double Cd = gj * dq;
+      Cd += dpp_xor4(Cd); Cd += dpp_xor2(Cd); Cd += dpp_xor1(Cd);
+      const double2 zy = comp(off, Cd, dual_q, drel_q, e_q, gj);  // identical on every lane of the group
+      if (act && l8 == 0) { z[off] = zy.x; y[off] = zy.y; }
+    }
+  }
+  // KKT shares
+  if (t < T && jl) kkt = fmax(kkt, fabs((ax[A::Luu + l8] + preg) * du + sig * (du - duc) + e_u));
+  if (t > 0) {
+    double pr[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) pr[i] = (i < NV) ? ax[A::Lqq + i * A::LD + l8] * dq : 0.0;
+    const double hq = transpose_reduce8(pr, l8);
+    if (jl) {
+      kkt = fmax(kkt, fabs(hq + dreg * dq + sig * (dq - cq) + e_q));
+      kkt = fmax(kkt, fabs((ax[A::Lvv + l8] + dreg) * dv + sig * (dv - cv) + e_v));
+    }
+  }
+  double dual = fmax(fabs(dual_q), fmax(fabs(dual_v), fabs(dual_u)));
+  double drel = fmax(fabs(drel_q), fmax(fabs(drel_v), fabs(drel_u)));
+  // group reductions (fixed order)
+  kkt = fmax(kkt, dpp_xor4(kkt)); kkt = fmax(kkt, dpp_xor2(kkt)); kkt = fmax(kkt, dpp_xor1(kkt));
+  gap += dpp_xor4(gap); gap += dpp_xor2(gap); gap += dpp_xor1(gap);
+  primal = fmax(primal, dpp_xor4(primal)); primal = fmax(primal, dpp_xor2(primal)); primal = fmax(primal, dpp_xor1(primal));
+  primal_rel = fmax(primal_rel, dpp_xor4(primal_rel)); primal_rel = fmax(primal_rel, dpp_xor2(primal_rel)); primal_rel = fmax(primal_rel, dpp_xor1(primal_rel));
+  dual = fmax(dual, dpp_xor4(dual)); dual = fmax(dual, dpp_xor2(dual)); dual = fmax(dual, dpp_xor1(dual));
+  drel = fmax(drel, dpp_xor4(drel)); drel = fmax(drel, dpp_xor2(drel)); drel = fmax(drel, dpp_xor1(drel));
+  if (act) {
+    if (jl) {
+      if (t < T) dus[((long long)b * T + t) * NV + l8] = du;
+      cx[l8] = dq; cx[NV + l8] = dv;  // prox centre of the next iteration
+    }
+    if (l8 == 0) {
+      double *ns = nodestat + nid * 4;
+      ns[0] = kkt; ns[1] = qt[Q::cost]; ns[2] = gap;
+      double *as = admmstat + nid * 4;
+      as[0] = primal; as[1] = dual; as[2] = primal_rel; as[3] = drel;
+    }
+  }
+}
+
+// Per instance: residual norms over the nodes, rho adaptation (update_rho_vec), convergence.
+__global__ void __launch_bounds__(128) k_admm_reduce(const DevOcp *__restrict__ op, const double *__restrict__ admmstat,
+                                                     DevState *__restrict__ st, int iter, int *__restrict__ n_conv) {
+  __shared__ double red[4][2];
+  const DevOcp &o = *op;
+  const int T = o.T, b = blockIdx.x, tid = threadIdx.x;
+  DevState &S = st[b];
+  if (S.done || S.admm_conv) return;
+  double v[4] = {0.0, 0.0, 0.0, 0.0};
+  for (int t = tid; t <= T; t += blockDim.x) {
+    const double *as = admmstat + ((long long)b * (T + 1) + t) * 4;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = fmax(v[k], as[k]);
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) v[k] = wave_max(v[k]);
+  if ((tid & 63) == 0)
+    for (int k = 0; k < 4; ++k) red[k][tid >> 6] = v[k];
+  __syncthreads();
+  if (tid != 0) return;
+  const double np_ = fmax(red[0][0], red[0][1]), nd = fmax(red[1][0], red[1][1]);
+  const double npr = fmax(red[2][0], red[2][1]), ndr = fmax(red[3][0], red[3][1]);
+  // update_rho_vec (std::max / std::min semantics for the 0/0 cases)
+  const double scale = sqrt((np_ * ndr) / (nd * npr));
+  double est = scale * S.rho_sparse;
+  est = (est < kRhoMin) ? kRhoMin : est;
+  est = (kRhoMax < est) ? kRhoMax : est;
+  if (iter % kRhoInterval == 0 && iter > 1)
+    if (est > S.rho_sparse * kAdaptiveRhoTol || est < S.rho_sparse / kAdaptiveRhoTol) S.rho_sparse = est;
+  const bool conv = (np_ <= o.eps_abs + o.eps_rel * npr) && (nd <= o.eps_abs + o.eps_rel * ndr);
+  if (conv || iter == o.max_qp) {
+    S.admm_conv = 1;
+    S.admm_iter = conv ? iter : o.max_qp;
+    atomicAdd(n_conv, 1);
+  }
+}
+
+// K = M Kw - taux: one lane per (node, column of K); the gains of the last ADMM backward pass
+template <int NV>
+__global__ void __launch_bounds__(256) k_gains_to_u(const DevOcp *__restrict__ op, const double *__restrict__ auxs,
+                                                    const double *__restrict__ Kws, double *__restrict__ Kout,
+                                                    const DevState *__restrict__ st) {
+  constexpr int NX = 2 * NV;
+  typedef AUX<NV> A;
+  const DevOcp &o = *op;
+  const int T = o.T;
+  const long long unit = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long node = unit >> 4;  // 16 lanes per node, NX <= 16 of them active
+  const int j = (int)(unit & 15);
+  if (node >= (long long)o.B * T || j >= NX) return;
+  const int b = (int)(node / T), t = (int)(node % T);
+  if (st[b].done) return;
+  const double *ax = auxs + ((long long)b * (T + 1) + t) * A::SIZE;
+  const double *Kw = Kws + node * NV * NX;
+  double *K = Kout + node * NV * NX;
+  const double *tx = (j < NV) ? ax + A::tq + j : ax + A::tv + (j - NV);
+  double kc[NV];
+#pragma unroll
+  for (int l = 0; l < NV; ++l) kc[l] = Kw[l * NX + j];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    double acc = -tx[i * A::LD];
+#pragma unroll
+    for (int l = 0; l < NV; ++l) acc += ax[A::M + i * A::LD + l] * kc[l];
+    K[i * NX + j] = acc;
+  }
+}
+
+}  // namespace agx

@@ -41,10 +41,24 @@ struct DevRows {
   double alpha[AGX_MAX_ROWS];
 };
 
+// ConstraintListItem rows of one node type:  lb <= g(x, u) <= ub, g stacked over the rows.
+#define AGX_MAX_CONS 4
+#define AGX_MAX_NC 32
+struct DevCons {
+  int n, nc, ncoll, pad;
+  int kind[AGX_MAX_CONS], frame[AGX_MAX_CONS], frame_b[AGX_MAX_CONS], off[AGX_MAX_CONS], nr[AGX_MAX_CONS];
+  int coll_slot[AGX_MAX_CONS];  // index of a collision row among the collision rows (Jacobian slot)
+  double ref[AGX_MAX_CONS][2 * AGX_MAX_NV];
+  double lb[AGX_MAX_NC], ub[AGX_MAX_NC];
+};
+
 struct DevOcp {
   int T, B, stride, pad;
   DevRows rows[2];  // 0 running, 1 terminal
   double tol, mu_dyn, mu_con;
+  DevCons cons[2];
+  int max_qp, has_con;
+  double eps_abs, eps_rel;
 };
 
 #define AGX_DEV __device__ __forceinline__
@@ -889,6 +903,63 @@ AGX_DEV void node_costs(const DevModel &m, const DevRows &rows, const Kin<NV> &k
 #pragma unroll
       for (int j = i + 1; j < NV; ++j) c.Lqq[i][j] = c.Lqq[j][i];
   }
+}
+
+// Constraints of one node (ConstraintModelManager of the node's differential model): g stacked over
+// the rows; JAC also returns d(distance)/dq of every collision row (the other supported kinds have
+// identity Jacobians: State on x, Control on u).
+template <int NV, bool CHAIN, bool JAC>
+AGX_DEV void constraints_eval(const DevModel &m, const DevCons &c, const double *x, const double *u, double *g,
+                              double (*cj)[8]) {
+  Kin<NV> k;
+  if (c.ncoll > 0) kinematics<NV, CHAIN>(m, x, k);
+  for (int r = 0; r < c.n; ++r) {
+    const int kind = c.kind[r], off = c.off[r];
+    if (kind == AGX_RES_STATE) {
+#pragma unroll
+      for (int i = 0; i < 2 * NV; ++i) g[off + i] = x[i] - c.ref[r][i];
+    } else if (kind == AGX_RES_CONTROL) {
+#pragma unroll
+      for (int i = 0; i < NV; ++i) g[off + i] = u[i] - c.ref[r][i];
+    } else if (kind == AGX_RES_COLLISION) {
+      double ca[3], cb[3], n[3];
+      int ja, jb;
+      g[off] = collision_distance<NV>(m, k, c.frame[r], c.frame_b[r], ca, cb, n, &ja, &jb);
+      if (JAC) {
+        double *gj = cj[c.coll_slot[r]];
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+          const bool ona = (ja >= 0) && (CHAIN ? (j <= ja) : ((m.anc[ja >= 0 ? ja : 0] >> j) & 1u));
+          const bool onb = (jb >= 0) && (CHAIN ? (j <= jb) : ((m.anc[jb >= 0 ? jb : 0] >> j) & 1u));
+          double da[3], db[3], ta[3], tb[3];
+#pragma unroll
+          for (int e = 0; e < 3; ++e) { da[e] = ca[e] - k.p[j][e]; db[e] = cb[e] - k.p[j][e]; }
+          cross3(k.S[j] + 3, da, ta);
+          cross3(k.S[j] + 3, db, tb);
+          gj[j] = (ona ? dot3(n, ta) : 0.0) - (onb ? dot3(n, tb) : 0.0);
+        }
+      }
+    }
+  }
+}
+// l1 norm of the violation of lb <= g <= ub (SolverCSQP::calc / tryStep constraint_norm)
+AGX_DEV double violation_l1(const DevCons &c, const double *g) {
+  double v = 0.0;
+  for (int k = 0; k < c.nc; ++k) v += fmax(c.lb[k] - g[k], 0.0) + fmax(g[k] - c.ub[k], 0.0);
+  return v;
+}
+template <int NV, bool CHAIN>
+AGX_DEV double constraint_violation(const DevModel &m, const DevCons &c, const double *x, const double *u) {
+  if (c.nc == 0) return 0.0;
+  double g[AGX_MAX_NC];
+  constraints_eval<NV, CHAIN, false>(m, c, x, u, g, nullptr);
+  return violation_l1(c, g);
+}
+// ADMM penalty of one constraint component (SolverCSQP::apply_rho_update)
+AGX_DEV double admm_rho(double lb, double ub, double rho_sparse) {
+  if (lb == -INFINITY && ub == INFINITY) return 1e-6;
+  if (fabs(lb - ub) <= 1e-6) return 1e3 * rho_sparse;
+  return rho_sparse;
 }
 
 // calc of a running node: forward dynamics + semi-implicit Euler + cost

@@ -24,6 +24,10 @@ struct DevState {
   int gains_iter;  // SQP iteration whose tiles the reported gains (Kout) were swept from (-1: none)
   int dir_iter;    // SQP iteration of the last direction this instance computed
   double gains_preg, gains_dreg; // regularisation the last direction was computed with
+  // constrained problems (ADMM, agx_admm.hpp)
+  double rho_sparse;             // persists across solves (SolverCSQP reset_rho = false); 0 = not initialised
+  double con;                    // l1 norm of the constraint violation at the last evaluation
+  int admm_conv, admm_iter;      // QP converged in this SQP iteration / ADMM iterations done
 };
 
 // Addressing of the reference tiles (host tile or a window of the resident trajectory).
@@ -449,7 +453,7 @@ __device__ __forceinline__ void riccati_body(const int b, const DevOcp *__restri
   //   0  every instance (agx_ocp_direction, timing), with the regularisation of its last direction;
   //   1  speculative, launched next to the direction sweep of SQP iteration `iter`: live instances, same dreg;
   //   2  fix-up on exit: only instances whose last direction (dir_iter) has no sweep yet.
-  if (!gains_pass && S.done) return;
+  if (!gains_pass && (S.done || S.admm_conv)) return;
   if (gains_pass && gmode == 1 && S.done) return;
   if (gains_pass && gmode == 2 && S.gains_iter == S.dir_iter) return;
   const double dreg = (gains_pass && gmode != 1) ? (S.solved ? S.dreg : S.gains_dreg) : S.dreg;
@@ -785,7 +789,7 @@ __global__ void __launch_bounds__(128) k_step(const DevModel *__restrict__ mp, c
   constexpr int NX = 2 * NV, NU = NV;
   typedef QT<NV> Q;
   typedef AUX<NV> A;
-  __shared__ double red[8];
+  __shared__ double red[12];
   __shared__ int flag;
   const DevModel &m = *mp;
   const DevOcp &o = *op;
@@ -799,22 +803,27 @@ __global__ void __launch_bounds__(128) k_step(const DevModel *__restrict__ mp, c
 
   constexpr int NPT = 4;  // nodes per thread: supports T + 1 <= 4 * blockDim
   // ---- per-node KKT / cost / gap shares (k_node_kkt) -> instance totals, fixed summation order
-  double kkt = 0.0, csum = 0.0, gsum = 0.0;
+  double kkt = 0.0, csum = 0.0, gsum = 0.0, vsum = 0.0;
   for (int t = tid; t <= T; t += blockDim.x) {
     const double *ns = nodestat + ((long long)b * (T + 1) + t) * 4;
     kkt = fmax(kkt, ns[0]);
     csum += ns[1];
     gsum += ns[2];
+    if (o.has_con) vsum += ns[3];
   }
   kkt = wave_max(kkt);
   csum = wave_sum(csum);
   gsum = wave_sum(gsum);
-  if ((tid & 63) == 0) { red[tid >> 6] = kkt; red[2 + (tid >> 6)] = csum; red[4 + (tid >> 6)] = gsum; }
+  vsum = wave_sum(vsum);
+  if ((tid & 63) == 0) { red[tid >> 6] = kkt; red[2 + (tid >> 6)] = csum; red[4 + (tid >> 6)] = gsum; red[8 + (tid >> 6)] = vsum; }
   __syncthreads();
   if (tid == 0) {
-    double kk = 0.0, cc = 0.0, gg = 0.0;
-    for (int w = 0; w < nw; ++w) { kk = fmax(kk, red[w]); cc += red[2 + w]; gg += red[4 + w]; }
-    S.kkt = kk; S.cost = cc; S.gap = gg; S.merit = cc + o.mu_dyn * gg; S.qp_iters = 1;
+    double kk = 0.0, cc = 0.0, gg = 0.0, vv = 0.0;
+    for (int w = 0; w < nw; ++w) { kk = fmax(kk, red[w]); cc += red[2 + w]; gg += red[4 + w]; vv += red[8 + w]; }
+    kk = fmax(kk, vv);  // checkKKTConditions: KKT = max(KKT, constraint_norm)
+    S.kkt = kk; S.cost = cc; S.gap = gg; S.con = vv; S.merit = cc + o.mu_dyn * gg + o.mu_con * vv;
+    S.qp_iters = o.has_con ? S.admm_iter : 1;
+    S.admm_conv = 0;  // the next SQP iteration's plain LQR pass runs for this instance again
     if (!(mode & 4)) S.dir_iter = iter;
     if (!(kk == kk)) S.flags |= 1;
     const bool conv = (kk <= o.tol) && (mode & 1) && !(mode & 4);
@@ -848,10 +857,12 @@ __global__ void __launch_bounds__(128) k_step(const DevModel *__restrict__ mp, c
         for (int i = 0; i < NX; ++i)
           g += fabs(xn[i] - (X[(long long)(t + 1) * NX + i] + alpha * DX[(long long)(t + 1) * NX + i]));
         part += c + o.mu_dyn * g;
+        if (o.has_con) part += o.mu_con * constraint_violation<NV, CHAIN>(m, o.cons[0], x, u);
       } else {
         double c;
         node_calc_terminal<NV, CHAIN>(m, o.rows[1], x, ref_at(rv, b, T, T), frames_at(rv, b, T, T), &c);
         part += c;
+        if (o.has_con) part += o.mu_con * constraint_violation<NV, CHAIN>(m, o.cons[1], x, x);
       }
     }
     part = wave_sum(part);
@@ -915,6 +926,7 @@ __global__ void k_reset_state(DevState *st, int B, int *n_done) {
   if (b == 0) *n_done = 0;
   if (b >= B) return;
   DevState s;
+  s.rho_sparse = st[b].rho_sparse; s.con = 0.0; s.admm_conv = 0; s.admm_iter = 0;
   s.kkt = 0.0; s.cost = 0.0; s.merit = 0.0; s.gap = 0.0;
   s.preg = kRegMin; s.dreg = kRegMin;
   s.iter = 0; s.qp_iters = 0; s.solved = 0; s.flags = 0; s.done = 0; s.gains_iter = -1; s.dir_iter = -1;
@@ -955,6 +967,12 @@ __global__ void k_pack_first(const double *__restrict__ us, const double *__rest
     }
   }
   out[i] = v;
+}
+
+// a freshly constructed solver: rho back to its base value (the multipliers are zeroed by the host)
+__global__ void k_reset_rho(DevState *st, int B) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b < B) st[b].rho_sparse = 0.0;
 }
 
 // xs[b][0] <- x0[b]   (SolverCSQP pins xs_[0] = problem.x0)
@@ -1246,3 +1264,4 @@ __global__ void k_ws_from_ref(double *xs, double *us, double *x0, const double *
 }  // namespace agx
 
 #include "agx_k1_lanes.hpp"
+#include "agx_admm.hpp"

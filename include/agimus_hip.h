@@ -174,6 +174,10 @@ int agx_ocp_sync(agx_ocp *ocp);
  * (R row major 9 | p 3, in the parent joint frame; world for parent -1) of a geometry frame,
  * e.g. a moving obstacle.  Applies to every instance of the handle.              */
 int agx_ocp_set_geom_placement(agx_ocp *ocp, int frame, const double *se3);
+/* Constrained problems keep the ADMM multipliers y and the penalty rho between solves, as the
+ * reference's solver object does (SolverCSQP reset_y = reset_rho = false).  This forgets them:
+ * the state of a freshly constructed solver.                                      */
+int agx_ocp_reset_duals(agx_ocp *ocp);
 
 /* Replaces OCPCrocoGeneric.set_reference_weighted_trajectory
  * (ocp_croco_generic.py:855-892): ref_tile [B][T+1][stride] host doubles,

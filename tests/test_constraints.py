@@ -110,3 +110,59 @@ def test_yaml_constraints_lower_to_rows():
     assert term[0].active and not term[1].active  # no control at the terminal node
     po = _abi.PackedOcp(7, [0.01] * 4, diff.lower(data), diff.lower(data), running_constraints=run, terminal_constraints=term)
     assert po.desc.n_running_constraints == 2 and po.desc.n_terminal_constraints == 2
+
+
+@pytest.mark.gpu
+def test_hip_control_limits_match_the_checker():
+    from agimus_controller_amd import backend
+
+    lim = np.full(7, 15.0)
+    table, po, ref, x0, xs, us = _control_limit_problem(lim, T=12, B=4, max_qp=100)
+    o = _oracle(table, po, 4)
+    hb = backend.HipOcp(table, po, 4)
+    hb.set_refs(ref)
+    # one SQP iteration first: identical ADMM iteration counts, tight agreement
+    r_o = o.solve(ref, None, x0, xs, us, 1)
+    r_h = hb.solve(x0, xs, us, 1)
+    assert np.array_equal(r_h[3]["qp_iters"], r_o[3]["qp_iters"])
+    np.testing.assert_allclose(r_h[3]["kkt"], r_o[3]["kkt"], rtol=1e-6, atol=1e-9)
+    np.testing.assert_allclose(r_h[0], r_o[0], rtol=1e-8, atol=1e-9)
+    np.testing.assert_allclose(r_h[1], r_o[1], rtol=1e-7, atol=1e-7)
+    np.testing.assert_allclose(r_h[2], r_o[2], rtol=1e-6, atol=1e-6)
+    # full solve from fresh multipliers
+    o.reset_duals()
+    hb.reset_duals()
+    r_o = o.solve(ref, None, x0, xs, us, 30)
+    r_h = hb.solve(x0, xs, us, 30)
+    assert np.array_equal(r_h[3]["iter"], r_o[3]["iter"])
+    assert np.array_equal(r_h[3]["solved"], r_o[3]["solved"])
+    np.testing.assert_allclose(r_h[0], r_o[0], rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(r_h[1], r_o[1], rtol=1e-5, atol=1e-5)
+    assert np.abs(r_h[1]).max() <= 15.0 + 1e-4
+    hb.close()
+
+
+@pytest.mark.gpu
+def test_hip_collision_constraint_matches_the_checker():
+    from agimus_controller_amd import backend
+
+    table = rt.panda_collision_table(0.1, obstacle_xyz=(0.45, 0.1, 0.45), obstacle_radius=0.08, obstacle_length=0.3)
+    tcp = table.frame_id("panda_hand_tcp")
+    T, B = 10, 3
+    running, terminal = workloads.collision_avoidance_rows(table, tcp, alpha=0.05)
+    fa, fb = table.frame_id("panda_link7_capsule_0"), table.frame_id("obstacle")
+    con = [_abi.ConstraintSpec(_abi.RES_COLLISION, lower=0.05, upper=np.inf, frame=fa, frame_b=fb, name="collision"),
+           _abi.ConstraintSpec(_abi.RES_STATE, lower=-5.0, upper=5.0, name="box")]
+    po = _abi.PackedOcp(7, [0.01] * T, running, terminal, max_qp_iters=100, running_constraints=con, terminal_constraints=con)
+    _, ref, x0, xs, us = workloads.random_goal_problem(table, T, 0.01, B, 23, frame=tcp, rows="collision")
+    o = _oracle(table, po, B)
+    hb = backend.HipOcp(table, po, B)
+    hb.set_refs(ref)
+    r_o = o.solve(ref, None, x0, xs, us, 2)
+    r_h = hb.solve(x0, xs, us, 2)
+    assert np.array_equal(r_h[3]["qp_iters"], r_o[3]["qp_iters"])
+    np.testing.assert_allclose(r_h[0], r_o[0], rtol=1e-7, atol=1e-8)
+    np.testing.assert_allclose(r_h[1], r_o[1], rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(r_h[2], r_o[2], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(r_h[3]["kkt"], r_o[3]["kkt"], rtol=1e-5, atol=1e-8)
+    hb.close()
