@@ -246,3 +246,50 @@ def test_debug_references_and_residuals(hip_backend):
         assert ocp.horizon_size == T
     with pytest.raises(RuntimeError, match="Unknown geometry"):
         ocp.update_geometry_placement("obstacle", pose)
+
+
+def test_collision_avoidance_yaml_end_to_end(hip_backend):
+    """ocp_traj_tracking_collision_avoidance.yaml through the class surface: QuadExp distance cost,
+    distance >= 1 cm constraint (ADMM), w_collision_avoidance as the item weight
+    (ocp_croco_generic.py:713-719) and update_geometry_placement for a moving obstacle."""
+    from agimus_controller_amd.factory import robot_tables as rt
+    from agimus_controller_amd.factory.robot_model import RobotModelParameters, RobotModels
+
+    T, dt = 20, 0.02
+    table = rt.panda_collision_table(0.1, obstacle_xyz=(0.42, 0.05, 0.55), obstacle_radius=0.06, obstacle_length=0.2)
+    rm = RobotModels(RobotModelParameters(table=table, armature=table.armature, q0=PANDA_Q0,
+                                          collision_pairs=[("panda_link7_capsule_0", "obstacle")]))
+    seq = DTFactorsNSeq(factors=[1], n_steps=[T])
+    params = OCPParamsBaseCroco(dt=dt, horizon_size=T, dt_factor_n_seq=seq, solver_iters=30, qp_iters=100, callbacks=False)
+    ocp = OCPCrocoGeneric(rm, params, OCPCrocoGeneric.get_default_yaml_file("ocp_traj_tracking_collision_avoidance.yaml"))
+    assert ocp.problem.desc.n_running_constraints == 1 and ocp.problem.desc.n_terminal_constraints == 0
+    tcp = rm.robot_model.getFrameId("panda_hand_tcp")
+    start = ocp._hip.frame_placement(tcp, PANDA_Q0)[0]
+    goal = se3.SE3(start[:9].reshape(3, 3), start[9:] + np.array([0.12, 0.05, 0.05]))
+    pt = WeightedTrajectoryPoint(
+        TrajectoryPoint(robot_configuration=PANDA_Q0, robot_velocity=np.zeros(7), robot_effort=np.zeros(7),
+                        end_effector_poses={"panda_hand_tcp": goal}),
+        TrajectoryPointWeights(w_robot_configuration=0.01 * np.ones(7), w_robot_velocity=0.1 * np.ones(7),
+                               w_robot_effort=1e-4 * np.ones(7), w_end_effector_poses={"panda_hand_tcp": 50.0 * np.ones(6)},
+                               w_collision_avoidance=2.0))
+    ocp.set_reference_weighted_trajectory([pt] * (T + 1))
+    x0 = np.concatenate([PANDA_Q0, np.zeros(7)])
+    ocp.solve(x0, [x0] * (T + 1), [np.zeros(7)] * T)
+    res = ocp.ocp_results
+    xs = np.array(res.states)
+    # the checker agrees on the whole constrained solve
+    o = Oracle(rm.table, ocp.problem, 1)
+    xs_o, us_o, K_o, st_o = o.solve(ocp._ref_tile, ocp._frames, x0[None], np.tile(x0, (1, T + 1, 1)), np.zeros((1, T, 7)), 30)
+    assert ocp.debug_data.nb_iter == st_o["iter"][0]
+    np.testing.assert_allclose(xs, xs_o[0], rtol=1e-5, atol=1e-6)
+    assert ocp.debug_data.nb_qp_iter == st_o["qp_iters"][0]
+    # the pair stays apart along the running nodes
+    for t in range(1, T):
+        g, _, _ = o.node_constraints(False, xs[t], res.feed_forward_terms[t])
+        assert g[0] >= 0.01 - 2e-3
+    # moving the obstacle away: unknown names raise, known ones change the distances
+    with pytest.raises(RuntimeError, match="Unknown geometry name"):
+        ocp.update_geometry_placement("no_such_geometry", se3.SE3(np.eye(3), np.zeros(3)))
+    d0 = ocp._hip.residuals(3)[0, 1, 0]
+    ocp.update_geometry_placement("obstacle", se3.SE3(rt._ry(np.pi / 2), np.array([1.535, 0.0, 0.43])))
+    assert ocp._hip.residuals(3)[0, 1, 0] > d0 + 0.3
