@@ -166,3 +166,64 @@ def test_hip_collision_constraint_matches_the_checker():
     np.testing.assert_allclose(r_h[2], r_o[2], rtol=1e-5, atol=1e-5)
     np.testing.assert_allclose(r_h[3]["kkt"], r_o[3]["kkt"], rtol=1e-5, atol=1e-8)
     hb.close()
+
+
+@pytest.mark.gpu
+def test_hip_config3_full_size_properties():
+    """BASELINE.json configs[2] shape (horizon 200, batch 256, collision-avoidance costs + distance
+    constraint) on the resident sine-wave workload: after MPC steps every solved instance keeps the
+    pair apart and satisfies the KKT tolerance; a few instances are compared with the CPU checker."""
+    from agimus_controller_amd import backend
+
+    T, B, dt, lower = 200, 256, 0.01, 0.05
+    table = rt.panda_collision_table(0.1, obstacle_xyz=(0.27, 0.22, 0.70), obstacle_radius=0.06, obstacle_length=0.0)
+    tcp = table.frame_id("panda_hand_tcp")
+    running, terminal = workloads.collision_avoidance_rows(table, tcp, alpha=1e-4)
+    fa, fb = table.frame_id("panda_link7_capsule_0"), table.frame_id("obstacle")
+    con = [_abi.ConstraintSpec(_abi.RES_COLLISION, lower=lower, upper=np.inf, frame=fa, frame_b=fb, name="collision")]
+    po = _abi.PackedOcp(7, [dt] * T, running, terminal, max_qp_iters=50, running_constraints=con)
+    hb = backend.HipOcp(table, po, B)
+    q0, amp, puls, scale, t0 = workloads.sine_batch_params(B, lower=table.lower_position_limit, upper=table.upper_position_limit)
+    w = workloads.SINE_WEIGHTS
+    hb.sine_trajectory(T + 8, dt, q0, amp, puls, scale, t0, w["w_q"], w["w_qdot"], w["w_effort"], w["w_pose"], tcp)
+    for k in range(2):
+        hb.mpc_step(k, 6, first=(k == 0))
+    xs, us, K, st = hb.download()
+    assert np.all(np.isfinite(xs)) and np.all(np.isfinite(K))
+    d = hb.residuals(3)[..., 0]  # distance row of every running node at the returned trajectory
+    solved = st["solved"] == 1
+    assert solved.mean() > 0.5
+    assert np.all(st["kkt"][solved] <= 1e-3)
+    assert d[solved][:, 1:].min() >= lower - 1e-3
+    # the constraint is really active for part of the batch
+    assert (d[:, 1:].min(axis=1) < lower + 5e-3).sum() >= 3
+    # checker on three instances (the ones closest to the obstacle), same two MPC steps
+    idx = np.argsort(d[:, 1:].min(axis=1))[:3]
+    o = _oracle(table, po, 3)
+    pts = [hb.traj_point(k) for k in range(T + 2)]
+    def window(k0):
+        ref = po.new_ref_tile(3)
+        for t in range(T + 1):
+            q, dq, _, u, pose = (a[idx] for a in pts[k0 + t])
+            rows, offs = (terminal, po.terminal_offsets) if t == T else (running, po.running_offsets)
+            for r, off in zip(rows, offs):
+                seg = ref[:, t, off:]
+                seg[:, 0] = 1.0
+                if r.kind == _abi.RES_STATE:
+                    seg[:, 1:15] = np.concatenate([q, dq], 1)
+                    seg[:, 15:22], seg[:, 22:29] = w["w_q"], w["w_qdot"]
+                elif r.kind == _abi.RES_CONTROL:
+                    seg[:, 1:8], seg[:, 8:15] = u, w["w_effort"]
+                elif r.kind == _abi.RES_FRAME_PLACEMENT:
+                    seg[:, 1:13], seg[:, 13:19] = pose, w["w_pose"]
+        return ref
+    xs_c = np.stack([np.concatenate([p[0][idx], p[1][idx]], 1) for p in pts[: T + 1]], 1)
+    us_c = np.stack([p[3][idx] for p in pts[:T]], 1)
+    x0 = xs_c[:, 0].copy()
+    r = o.solve(window(0), None, x0, xs_c, us_c, 6)
+    xs_s, us_s = o.shift_warmstart(r[0], r[1])
+    r = o.solve(window(1), None, r[0][:, 1].copy(), xs_s, us_s, 6)
+    assert np.array_equal(r[3]["iter"], st["iter"][idx])
+    np.testing.assert_allclose(xs[idx], r[0], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(us[idx], r[1], rtol=1e-4, atol=1e-4)
+    hb.close()
