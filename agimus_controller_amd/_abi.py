@@ -43,6 +43,7 @@ class CostRow(C.Structure):
         ("frame_b", C.c_int32),
         ("pad_", C.c_int32),
         ("alpha", C.c_double),
+        ("weight", C.c_double),
     ]
 
 
@@ -195,6 +196,7 @@ class RowSpec:
     alpha: float = 1.0
     name: str = ""
     frame_b: int = 0
+    weight: float = 1.0
 
     def width(self, nv: int) -> int:
         return 1 + row_nref(self.kind, nv) + row_nr(self.kind, nv)
@@ -311,6 +313,7 @@ class PackedOcp:
                 arr[i].frame = r.frame
                 arr[i].frame_b = r.frame_b
                 arr[i].alpha = r.alpha
+                arr[i].weight = r.weight
         self.running_constraints = list(running_constraints)
         self.terminal_constraints = list(terminal_constraints)
         self._rc = (ConstraintRow * max(len(self.running_constraints), 1))()
@@ -364,7 +367,7 @@ class PackedOcp:
         ):
             for r, o in zip(rows, offs):
                 nref, nr = row_nref(r.kind, self.nv), row_nr(r.kind, self.nv)
-                tile[:, sl, o] = 1.0
+                tile[:, sl, o] = r.weight
                 tile[:, sl, o + 1 + nref : o + 1 + nref + nr] = 1.0
                 if r.kind in (RES_FRAME_PLACEMENT, RES_FRAME_ROTATION):
                     tile[:, sl, o + 1 : o + 10] = np.eye(3).reshape(9)

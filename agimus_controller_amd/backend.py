@@ -25,7 +25,7 @@ EXPORTED_SYMBOLS = [
     "agx_last_error", "agx_device_count", "agx_row_nref", "agx_row_nr", "agx_ref_stride",
     "agx_model_create", "agx_model_destroy", "agx_ocp_create", "agx_ocp_destroy", "agx_ocp_set_stream",
     "agx_ocp_sync", "agx_ocp_set_refs", "agx_ocp_set_refs_device", "agx_ocp_solve", "agx_ocp_upload_x0",
-    "agx_ocp_upload_warmstart", "agx_ocp_solve_resident", "agx_ocp_download", "agx_ocp_download_first", "agx_ocp_first_packed", "agx_ocp_set_geom_placement", "agx_ocp_reset_duals",
+    "agx_ocp_upload_warmstart", "agx_ocp_solve_resident", "agx_ocp_download", "agx_ocp_download_first", "agx_ocp_first_packed", "agx_ocp_set_geom_placement", "agx_ocp_reset_duals", "agx_traj_generic_create",
     "agx_ocp_shift_warmstart", "agx_ocp_x0_from_prediction", "agx_ocp_integrate", "agx_model_rnea",
     "agx_model_frame_placement", "agx_ocp_get_residuals", "agx_ocp_calc_diff", "agx_ocp_direction",
     "agx_ocp_time_kernel", "agx_ocp_profile", "agx_traj_sine_create", "agx_traj_set_window",
@@ -276,6 +276,15 @@ class HipOcp:
         args = [bc(q0, (B, nv)), bc(amp, (B, nv)), bc(pulsation, (B, nv)), bc(scale_duration, (B, nv)), bc(t0, (B,)),
                 bc(w_q, (nv,)), bc(w_qdot, (nv,)), bc(w_effort, (nv,)), bc(w_pose, (6,))]  # fmt: skip
         _chk(lib().agx_traj_sine_create(self._h, int(n_points), C.c_double(dt), *[_p(a) for a in args], int(frame)))
+
+    def generic_trajectory(self, q, dq, ddq, w_q, w_qdot, w_effort, w_pose, frame):
+        """Resident trajectory from samples q, dq, ddq [B][n_points][nv] (GenericTrajectory upstream)."""
+        B, nv = self.B, self.nv
+        q, dq, ddq = (_f8(a).reshape(B, -1, nv) for a in (q, dq, ddq))
+        assert q.shape == dq.shape == ddq.shape
+        bc = lambda a, shape: np.ascontiguousarray(np.broadcast_to(np.asarray(a, dtype=np.float64), shape))  # noqa: E731
+        _chk(lib().agx_traj_generic_create(self._h, int(q.shape[1]), _p(q), _p(dq), _p(ddq), _p(bc(w_q, (nv,))), _p(bc(w_qdot, (nv,))),
+                                           _p(bc(w_effort, (nv,))), _p(bc(w_pose, (6,))), int(frame)))
 
     def set_window(self, k0: int):
         _chk(lib().agx_traj_set_window(self._h, int(k0)))

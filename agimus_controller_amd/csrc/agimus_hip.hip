@@ -114,6 +114,7 @@ void fill_rows(const agx_cost_row *rows, int n, int nv, DevRows &d) {
     d.frame[r] = rows[r].frame;
     d.frame_b[r] = rows[r].frame_b;
     d.alpha[r] = rows[r].alpha;
+    d.weight[r] = rows[r].weight;
     d.nref[r] = agx_row_nref(rows[r].kind, nv);
     d.nr[r] = agx_row_nr(rows[r].kind, nv);
     d.off[r] = off;
@@ -1057,6 +1058,43 @@ int agx_traj_sine_create(agx_ocp *o, int n_points, double dt, const double *q0, 
   for (size_t i = 0; i < nv; ++i) { sp.w_q[i] = w_q[i]; sp.w_qdot[i] = w_qdot[i]; sp.w_effort[i] = w_effort[i]; }
   for (int i = 0; i < 6; ++i) sp.w_pose[i] = w_pose[i];
   sp.dt = dt; sp.n_points = n_points; sp.frame = frame;
+  o->n_points = n_points;
+  int rc = dispatch(o->nv, o->chain, [&](auto NVc, auto CHc) -> int {
+    constexpr int NV = decltype(NVc)::value;
+    constexpr bool CH = decltype(CHc)::value;
+    const long long units = (long long)B * n_points;
+    hipLaunchKernelGGL((agx::k_sine_fill<NV, CH>), dim3((int)((units + 63) / 64)), dim3(64), 0, o->stream, o->d_model, o->d_ocp, sp, o->d_traj, o->d_pts);
+    HIPCHK(hipGetLastError());
+    return 0;
+  });
+  if (rc) return rc;
+  HIPCHK(hipStreamSynchronize(o->stream));
+  return agx_traj_set_window(o, 0);
+}
+
+int agx_traj_generic_create(agx_ocp *o, int n_points, const double *q, const double *dq, const double *ddq, const double *w_q,
+                            const double *w_qdot, const double *w_effort, const double *w_pose, int frame) {
+  if (!o || !q || !dq || !ddq || !w_q || !w_qdot || !w_effort || !w_pose) return fail("agx_traj_generic_create: null argument");
+  if (n_points < o->T + 1) return fail("agx_traj_generic_create: trajectory shorter than the horizon");
+  if (frame < 0 || frame >= o->hm.nframes) return fail("agx_traj_generic_create: frame id out of range");
+  if (set_device(o)) return -1;
+  const size_t B = o->B, nv = o->nv, n = B * (size_t)n_points * nv;
+  if (o->d_traj) { (void)hipFree(o->d_traj); o->d_traj = nullptr; }
+  if (o->d_pts) { (void)hipFree(o->d_pts); o->d_pts = nullptr; }
+  if (o->d_sine) { (void)hipFree(o->d_sine); o->d_sine = nullptr; }
+  HIPCHK(hipMalloc((void **)&o->d_traj, sizeof(double) * B * n_points * 2 * o->stride));
+  HIPCHK(hipMalloc((void **)&o->d_pts, sizeof(double) * B * n_points * (4 * nv + 12)));
+  HIPCHK(hipMalloc((void **)&o->d_sine, sizeof(double) * 3 * n));
+  double *d = o->d_sine;
+  HIPCHK(hipMemcpyAsync(d, q, sizeof(double) * n, hipMemcpyHostToDevice, o->stream));
+  HIPCHK(hipMemcpyAsync(d + n, dq, sizeof(double) * n, hipMemcpyHostToDevice, o->stream));
+  HIPCHK(hipMemcpyAsync(d + 2 * n, ddq, sizeof(double) * n, hipMemcpyHostToDevice, o->stream));
+  agx::SineParams sp;
+  std::memset(&sp, 0, sizeof(sp));
+  sp.gq = d; sp.gdq = d + n; sp.gddq = d + 2 * n;
+  for (size_t i = 0; i < nv; ++i) { sp.w_q[i] = w_q[i]; sp.w_qdot[i] = w_qdot[i]; sp.w_effort[i] = w_effort[i]; }
+  for (int i = 0; i < 6; ++i) sp.w_pose[i] = w_pose[i];
+  sp.dt = 0.0; sp.n_points = n_points; sp.frame = frame;
   o->n_points = n_points;
   int rc = dispatch(o->nv, o->chain, [&](auto NVc, auto CHc) -> int {
     constexpr int NV = decltype(NVc)::value;

@@ -38,7 +38,7 @@ struct DevRows {
   int n;
   int kind[AGX_MAX_ROWS], act[AGX_MAX_ROWS], active[AGX_MAX_ROWS], frame[AGX_MAX_ROWS], frame_b[AGX_MAX_ROWS];
   int off[AGX_MAX_ROWS], nref[AGX_MAX_ROWS], nr[AGX_MAX_ROWS];
-  double alpha[AGX_MAX_ROWS];
+  double alpha[AGX_MAX_ROWS], weight[AGX_MAX_ROWS];
 };
 
 // ConstraintListItem rows of one node type:  lb <= g(x, u) <= ub, g stacked over the rows.

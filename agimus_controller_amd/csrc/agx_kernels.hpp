@@ -1170,6 +1170,9 @@ __global__ void k_residuals(const DevModel *__restrict__ mp, const DevOcp *__res
 // ---------------------------------------------------------------------------
 struct SineParams {
   const double *q0, *amp, *puls, *scale, *t0;  // [B][nv] (t0: [B])
+  // generic trajectory (trajectories/generic_trajectory.py:37-70): samples given by the caller,
+  // [B][n_points][nv] each; when set they replace the sine formula
+  const double *gq, *gdq, *gddq;
   double w_q[AGX_MAX_NV], w_qdot[AGX_MAX_NV], w_effort[AGX_MAX_NV], w_pose[6];
   double dt;
   int n_points, frame;
@@ -1185,6 +1188,10 @@ __global__ void k_sine_fill(const DevModel *__restrict__ mp, const DevOcp *__res
   const int b = (int)(unit / sp.n_points), kk = (int)(unit % sp.n_points);
   const double t = sp.t0[b] + kk * sp.dt;
   double q[NV], dq[NV], ddq[NV], u[NV];
+  if (sp.gq) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) { q[i] = sp.gq[unit * NV + i]; dq[i] = sp.gdq[unit * NV + i]; ddq[i] = sp.gddq[unit * NV + i]; }
+  } else
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
     const double sd = sp.scale[(long long)b * NV + i], w = sp.puls[(long long)b * NV + i], A = sp.amp[(long long)b * NV + i];
@@ -1221,7 +1228,7 @@ __global__ void k_sine_fill(const DevModel *__restrict__ mp, const DevOcp *__res
     double *tile = traj + unit * 2 * o.stride + layout * o.stride;
     for (int r = 0; r < rows.n; ++r) {
       double *tr = tile + rows.off[r];
-      tr[0] = 1.0;
+      tr[0] = rows.weight[r];
       double *rr = tr + 1, *aw = rr + rows.nref[r];
       const int kind = rows.kind[r];
       if (kind == AGX_RES_STATE) {

@@ -600,10 +600,10 @@ class DifferentialActionModelFreeFwdDynamics(DifferentialActionModel):
             if kind == _abi.RES_COLLISION:
                 fa, fb = res.geometry_frames(data)
                 rows.append(_abi.RowSpec(kind=kind, activation=act_kind, active=bool(item.active), frame=fa, frame_b=fb,
-                                         alpha=alpha, name=item.name))  # fmt: skip
+                                         alpha=alpha, name=item.name, weight=float(item.weight)))  # fmt: skip
                 continue
             rows.append(_abi.RowSpec(kind=kind, activation=act_kind, active=bool(item.active),
-                                     frame=res.frame(data), alpha=alpha, name=item.name))  # fmt: skip
+                                     frame=res.frame(data), alpha=alpha, name=item.name, weight=float(item.weight)))  # fmt: skip
         return rows
 
 

@@ -30,11 +30,11 @@ def goal_reaching_rows(frame: int):
     return running, terminal
 
 
-def regulation_rows():
+def regulation_rows(terminal_weight: float = 1.0):
     """Row tables of the pick-and-place example's ocp_definition_file.yaml
     (control_reg + state_reg; terminal state_reg)."""
     running = [_abi.RowSpec(_abi.RES_CONTROL, name="control_reg"), _abi.RowSpec(_abi.RES_STATE, name="state_reg")]
-    terminal = [_abi.RowSpec(_abi.RES_STATE, name="state_reg")]
+    terminal = [_abi.RowSpec(_abi.RES_STATE, name="state_reg", weight=terminal_weight)]
     return running, terminal
 
 
@@ -148,6 +148,22 @@ def sine_batch_params(B: int, nv: int = 7, seed0: int = 1234, q0=None, lower=Non
             qq = np.clip(qq, lower + a, upper - a)
         out_q0[b], amp[b], puls[b], t0[b] = qq, a, 2.0 * np.pi / period, tt
     return out_q0, amp, puls, scale, t0
+
+
+def generic_batch_arrays(B: int, n_points: int, dt: float, nv: int = 7, seed0: int = 1234, q0=None, accel=2.0):
+    """q, dq, ddq [B][n_points][nv] as the reference's generic-trajectory test builds them
+    (tests/test_generic_trajectory.py:147-160 upstream): uniform random accelerations integrated to
+    dq and q with the Euler rule; instance b draws from default_rng(seed0 + b)."""
+    q0 = np.tile(PANDA_Q0, (B, 1)) if q0 is None else np.asarray(q0, dtype=float).reshape(B, nv)
+    ddq = np.empty((B, n_points, nv))
+    for b in range(B):
+        ddq[b] = accel * (np.random.default_rng(seed0 + b).random((n_points, nv)) - 0.5)
+    dq = np.zeros_like(ddq)
+    dq[:, 1:] = np.cumsum(ddq[:, :-1], axis=1) * dt
+    q = np.empty_like(ddq)
+    q[:, 0] = q0
+    q[:, 1:] = q0[:, None, :] + np.cumsum(dq[:, 1:], axis=1) * dt
+    return q, dq, ddq
 
 
 # Weights of the reference's sine-wave test (tests/test_sin_wave_configuration_space.py:138-144).

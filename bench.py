@@ -47,13 +47,15 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-batch1", action="store_true", help="skip the batch = 1 latency leg (profiling runs)")
     ap.add_argument("--cpu-instances", type=int, default=0, help="instances of the CPU sample (0 = 2 per core)")
+    ap.add_argument("--workload", choices=("sine", "generic"), default="sine",
+                    help="sine: BASELINE configs[1] (the headline); generic: configs[3] generic_trajectory + pick-and-place costs")
     return ap.parse_args()
 
 
-def make_problem(T):
+def make_problem(T, workload="sine"):
     table = rt.panda_table(0.1)
     tcp = table.frame_id("panda_hand_tcp")
-    running, terminal = workloads.goal_reaching_rows(tcp)
+    running, terminal = workloads.goal_reaching_rows(tcp) if workload == "sine" else workloads.regulation_rows(terminal_weight=0.0)
     po = _abi.PackedOcp(7, [0.01] * T, running, terminal, termination_tolerance=1e-3, max_qp_iters=100)
     return table, tcp, po
 
@@ -162,14 +164,23 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     B, T, dt = args.batch, args.horizon, 0.01
-    table, tcp, po = make_problem(T)
+    table, tcp, po = make_problem(T, args.workload)
     hip = backend.HipOcp(table, po, B, device=local_rank)
     n_points = args.warmup + max(args.steps, 200) + T + 2 + 10
     # per-instance seeds follow the GLOBAL instance index so every rank works on different instances
     q0, amp, puls, scale, t0 = workloads.sine_batch_params(B, seed0=1234 + rank * B, lower=table.lower_position_limit,
                                                            upper=table.upper_position_limit)
     w = workloads.SINE_WEIGHTS
-    hip.sine_trajectory(n_points, dt, q0, amp, puls, scale, t0, w["w_q"], w["w_qdot"], w["w_effort"], w["w_pose"], tcp)
+    if args.workload == "sine":
+        hip.sine_trajectory(n_points, dt, q0, amp, puls, scale, t0, w["w_q"], w["w_qdot"], w["w_effort"], w["w_pose"], tcp)
+        workload_name = "Panda 7-DoF sine_wave_configuration_space, ocp_goal_reaching.yaml costs"
+    else:
+        # BASELINE configs[3]: q/dq/ddq arrays from seeded smooth random accelerations (tests/test_generic_trajectory.py:147-160
+        # upstream), pick-and-place cost set and weights (trajectory_weigths_params.yaml:4-9)
+        w = dict(w_q=3.0, w_qdot=0.12, w_effort=8e-4, w_pose=0.0)
+        gq, gdq, gddq = workloads.generic_batch_arrays(B, n_points, dt, seed0=1234 + rank * B, q0=q0)
+        hip.generic_trajectory(gq, gdq, gddq, w["w_q"], w["w_qdot"], w["w_effort"], w["w_pose"], tcp)
+        workload_name = "Panda 7-DoF generic_trajectory (seeded smooth random accelerations), pick-and-place costs (control_reg + state_reg)"
 
     def step(k):
         hip.mpc_step(k, args.max_iter, first=(k == 0))
@@ -242,7 +253,7 @@ def main():
             "dtype": "f64",
             "data": "synthetic",
             "config": {
-                "workload": f"Panda 7-DoF sine_wave_configuration_space, ocp_goal_reaching.yaml costs, horizon={T}, "
+                "workload": f"{workload_name}, horizon={T}, "
                             f"dt=0.01, batch={B} independent MPC instances per GPU (seed 1234+b), closed loop on own prediction",
                 "horizon": T,
                 "batch_per_gpu": B,
@@ -267,7 +278,7 @@ def main():
             },
             "kernels": kernels,
         }
-        if world == 1 and not args.no_batch1:
+        if world == 1 and not args.no_batch1 and args.workload == "sine":
             # BASELINE.json configs[1]: the same workload at batch = 1 (latency of one controller)
             h1 = backend.HipOcp(table, po, 1, device=local_rank)
             p1 = workloads.sine_batch_params(1, lower=table.lower_position_limit, upper=table.upper_position_limit)
@@ -301,7 +312,7 @@ def main():
             result["full_download"] = {"ms_per_step": msf, "value": B / (msf * 1e-3), "unit": "MPC steps/s",
                                        "bytes_per_step": int(8 * B * ((T + 1) * 14 + T * 7 + T * 98)),
                                        "note": "PCIe-inclusive: xs, us, K of all nodes copied to host every step"}
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline and world == 1 and args.workload == "sine":
             try:
                 result["cpu_baseline"] = cpu_baseline(args, table, tcp, po)
             except Exception as e:  # the GPU numbers stand on their own

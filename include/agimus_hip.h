@@ -65,6 +65,8 @@ typedef struct agx_cost_row {
   int32_t frame_b;    /* collision: second geometry frame of the pair (:499-533) */
   int32_t pad_;
   double alpha;       /* Exp / QuadExp parameter                                */
+  double weight;      /* CostModelSumItem.weight of the YAML: the item weight the device-resident
+                         reference generators write (host tiles carry their own per node) */
 } agx_cost_row;
 
 /* One ConstraintListItem (ocp_croco_generic.py:554-647) lowered to a row:
@@ -266,6 +268,11 @@ int agx_traj_sine_create(agx_ocp *ocp, int n_points, double dt, const double *q0
                          const double *pulsation, const double *scale_duration, const double *t0,
                          const double *w_q, const double *w_qdot, const double *w_effort,
                          const double *w_pose, int frame);
+/* Same resident trajectory from caller-given samples q, dq, ddq [B][n_points][nv]
+ * (GenericTrajectory.build_trajectory_from_q_dq_ddq_arrays, trajectories/generic_trajectory.py:37-70):
+ * feed-forward effort by RNEA and end-effector pose by FK on the device.          */
+int agx_traj_generic_create(agx_ocp *ocp, int n_points, const double *q, const double *dq, const double *ddq,
+                            const double *w_q, const double *w_qdot, const double *w_effort, const double *w_pose, int frame);
 /* Point the solver at the horizon window starting at sample `k0` of the
  * resident trajectory (TrajectoryBuffer.horizon, trajectory.py:218-222, with
  * uniform horizon indexes).                                                    */
