@@ -25,7 +25,7 @@ EXPORTED_SYMBOLS = [
     "agx_last_error", "agx_device_count", "agx_row_nref", "agx_row_nr", "agx_ref_stride",
     "agx_model_create", "agx_model_destroy", "agx_ocp_create", "agx_ocp_destroy", "agx_ocp_set_stream",
     "agx_ocp_sync", "agx_ocp_set_refs", "agx_ocp_set_refs_device", "agx_ocp_solve", "agx_ocp_upload_x0",
-    "agx_ocp_upload_warmstart", "agx_ocp_solve_resident", "agx_ocp_download", "agx_ocp_download_first", "agx_ocp_first_packed", "agx_ocp_set_geom_placement", "agx_ocp_reset_duals", "agx_traj_generic_create",
+    "agx_ocp_upload_warmstart", "agx_ocp_solve_resident", "agx_ocp_download", "agx_ocp_download_first", "agx_ocp_first_packed", "agx_ocp_set_geom_placement", "agx_ocp_reset_duals", "agx_traj_generic_create", "agx_traj_set_horizon_indexes",
     "agx_ocp_shift_warmstart", "agx_ocp_x0_from_prediction", "agx_ocp_integrate", "agx_model_rnea",
     "agx_model_frame_placement", "agx_ocp_get_residuals", "agx_ocp_calc_diff", "agx_ocp_direction",
     "agx_ocp_time_kernel", "agx_ocp_profile", "agx_traj_sine_create", "agx_traj_set_window",
@@ -285,6 +285,11 @@ class HipOcp:
         bc = lambda a, shape: np.ascontiguousarray(np.broadcast_to(np.asarray(a, dtype=np.float64), shape))  # noqa: E731
         _chk(lib().agx_traj_generic_create(self._h, int(q.shape[1]), _p(q), _p(dq), _p(ddq), _p(bc(w_q, (nv,))), _p(bc(w_qdot, (nv,))),
                                            _p(bc(w_effort, (nv,))), _p(bc(w_pose, (6,))), int(frame)))
+
+    def set_horizon_indexes(self, idx):
+        """TrajectoryBuffer.horizon_indexes for the resident trajectory (None = uniform)."""
+        a = None if idx is None else np.ascontiguousarray(np.asarray(idx, dtype=np.int32).reshape(self.T + 1))
+        _chk(lib().agx_traj_set_horizon_indexes(self._h, _p(a)))
 
     def set_window(self, k0: int):
         _chk(lib().agx_traj_set_window(self._h, int(k0)))

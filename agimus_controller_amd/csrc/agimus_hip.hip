@@ -76,6 +76,10 @@ struct agx_ocp {
   double *d_traj = nullptr, *d_pts = nullptr;
   double *d_sine = nullptr;  // q0, amp, puls, scale, t0
   int n_points = 0;
+  // non-uniform horizon indexes (TrajectoryBuffer): empty = node t looks at sample k0 + t
+  std::vector<int> hidx;
+  int *d_hidx = nullptr;
+  int win_k0 = 0;
   hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_done = nullptr;
   int last_max_iter = 0;
   // in-situ kernel timing (agx_ocp_profile): event pairs around the launches of the SQP loop
@@ -651,7 +655,7 @@ void agx_ocp_destroy(agx_ocp *o) {
   if (o->stream) (void)hipStreamSynchronize(o->stream);
   void *ptrs[] = {o->d_model, o->d_ocp, o->d_dt, o->d_xs, o->d_us, o->d_x0, o->d_tiles, o->d_Kws, o->d_kws, o->d_Kout, o->d_dx,
                   o->d_du, o->d_ref, o->d_frames, o->d_state, o->d_ndone, o->d_scratch, o->d_traj, o->d_pts, o->d_sine, o->d_qt, o->d_aux, o->d_w, o->d_nodestat,
-                  o->d_qt2, o->d_cg, o->d_cjac, o->d_y, o->d_z, o->d_cx, o->d_admmstat};
+                  o->d_qt2, o->d_cg, o->d_cjac, o->d_y, o->d_z, o->d_cx, o->d_admmstat, o->d_hidx};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
   if (o->h_ndone) (void)hipHostFree(o->h_ndone);
@@ -1031,6 +1035,23 @@ int agx_ocp_profile(agx_ocp *o, int enable, double *ms_sum, long long *count) {
   return 0;
 }
 
+// The resident generators track ONE end-effector frame: frame-based cost rows look at it on every node
+// (what the host path does per node with `obj.id = ...`, ocp_croco_generic.py:208).
+static int traj_frames(agx_ocp *o, int frame) {
+  std::vector<int> fr((size_t)o->B * (o->T + 1) * AGX_MAX_ROWS, -1);
+  for (int b = 0; b < o->B; ++b)
+    for (int t = 0; t <= o->T; ++t) {
+      const DevRows &rows = o->ho.rows[t == o->T ? 1 : 0];
+      for (int r = 0; r < rows.n; ++r)
+        if (rows.kind[r] == AGX_RES_FRAME_PLACEMENT || rows.kind[r] == AGX_RES_FRAME_TRANSLATION || rows.kind[r] == AGX_RES_FRAME_ROTATION)
+          fr[((size_t)b * (o->T + 1) + t) * AGX_MAX_ROWS + r] = frame;
+    }
+  HIPCHK(hipMemcpyAsync(o->d_frames, fr.data(), sizeof(int) * fr.size(), hipMemcpyHostToDevice, o->stream));
+  HIPCHK(hipStreamSynchronize(o->stream));
+  o->frames_set = true;
+  return 0;
+}
+
 int agx_traj_sine_create(agx_ocp *o, int n_points, double dt, const double *q0, const double *amp, const double *pulsation,
                          const double *scale_duration, const double *t0, const double *w_q, const double *w_qdot,
                          const double *w_effort, const double *w_pose, int frame) {
@@ -1069,6 +1090,7 @@ int agx_traj_sine_create(agx_ocp *o, int n_points, double dt, const double *q0, 
   });
   if (rc) return rc;
   HIPCHK(hipStreamSynchronize(o->stream));
+  if (traj_frames(o, frame)) return -1;
   return agx_traj_set_window(o, 0);
 }
 
@@ -1106,18 +1128,51 @@ int agx_traj_generic_create(agx_ocp *o, int n_points, const double *q, const dou
   });
   if (rc) return rc;
   HIPCHK(hipStreamSynchronize(o->stream));
+  if (traj_frames(o, frame)) return -1;
   return agx_traj_set_window(o, 0);
+}
+
+int agx_traj_set_horizon_indexes(agx_ocp *o, const int32_t *idx) {
+  if (!o) return fail("null handle");
+  if (set_device(o)) return -1;
+  o->hidx.clear();
+  if (!idx) return 0;  // back to uniform
+  bool uniform = true;
+  for (int t = 0; t <= o->T; ++t) {
+    if (idx[t] < 0 || (t > 0 && idx[t] <= idx[t - 1])) return fail("agx_traj_set_horizon_indexes: indexes must be non-negative and increasing");
+    uniform = uniform && idx[t] == t;
+  }
+  if (uniform) return 0;
+  o->hidx.assign(idx, idx + o->T + 1);
+  if (!o->d_hidx) HIPCHK(hipMalloc((void **)&o->d_hidx, sizeof(int) * (o->T + 1)));
+  HIPCHK(hipMemcpyAsync(o->d_hidx, o->hidx.data(), sizeof(int) * (o->T + 1), hipMemcpyHostToDevice, o->stream));
+  HIPCHK(hipStreamSynchronize(o->stream));
+  return 0;
 }
 
 int agx_traj_set_window(agx_ocp *o, int k0) {
   if (!o) return fail("null handle");
   if (!o->d_traj) return fail("agx_traj_set_window: no resident trajectory");
-  if (k0 < 0 || k0 + o->T + 1 > o->n_points) return fail("agx_traj_set_window: window leaves the trajectory");
-  o->rv.base = o->d_traj + (long long)k0 * 2 * o->stride;
-  o->rv.bstride = (long long)o->n_points * 2 * o->stride;
-  o->rv.tstride = 2 * o->stride;
-  o->rv.term_off = o->stride;
-  o->rv.frames = nullptr;
+  const int last = o->hidx.empty() ? o->T : o->hidx[o->T];
+  if (k0 < 0 || k0 + last + 1 > o->n_points) return fail("agx_traj_set_window: window leaves the trajectory");
+  o->win_k0 = k0;
+  o->rv.frames = o->d_frames;
+  if (o->hidx.empty()) {
+    o->rv.base = o->d_traj + (long long)k0 * 2 * o->stride;
+    o->rv.bstride = (long long)o->n_points * 2 * o->stride;
+    o->rv.tstride = 2 * o->stride;
+    o->rv.term_off = o->stride;
+    return 0;
+  }
+  if (set_device(o)) return -1;
+  const long long n = (long long)o->B * (o->T + 1) * o->stride;
+  hipLaunchKernelGGL(agx::k_gather_window, dim3((int)((n + 255) / 256)), dim3(256), 0, o->stream, o->d_traj, o->d_ref, o->d_hidx, o->B, o->T,
+                     o->stride, o->n_points, k0);
+  HIPCHK(hipGetLastError());
+  o->rv.base = o->d_ref;
+  o->rv.bstride = (long long)(o->T + 1) * o->stride;
+  o->rv.tstride = o->stride;
+  o->rv.term_off = 0;
   return 0;
 }
 
@@ -1143,7 +1198,7 @@ int agx_traj_get_point(agx_ocp *o, int k, double *q, double *v, double *a, doubl
 static int ws_from_ref(agx_ocp *o, int k0, int set_x0) {
   const long long units = (long long)o->B * (o->T + 1);
   hipLaunchKernelGGL(agx::k_ws_from_ref, dim3((int)((units + 255) / 256)), dim3(256), 0, o->stream, o->d_xs, o->d_us, o->d_x0, o->d_pts,
-                     o->B, o->T, o->nv, o->n_points, k0, set_x0);
+                     o->B, o->T, o->nv, o->n_points, k0, set_x0, o->hidx.empty() ? nullptr : o->d_hidx);
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -1151,8 +1206,7 @@ static int ws_from_ref(agx_ocp *o, int k0, int set_x0) {
 int agx_traj_warmstart_from_reference(agx_ocp *o) {
   if (!o || !o->d_pts) return fail("agx_traj_warmstart_from_reference: no resident trajectory");
   if (set_device(o)) return -1;
-  const int k0 = (int)((o->rv.base - o->d_traj) / (2 * o->stride));
-  return ws_from_ref(o, k0, 1);
+  return ws_from_ref(o, o->win_k0, 1);
 }
 
 int agx_ocp_mpc_step(agx_ocp *o, int k0, int max_iter, int first) {

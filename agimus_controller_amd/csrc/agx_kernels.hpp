@@ -1251,15 +1251,30 @@ __global__ void k_sine_fill(const DevModel *__restrict__ mp, const DevOcp *__res
   }
 }
 
+// Horizon window with non-uniform sample indexes (TrajectoryBuffer.horizon_indexes, trajectory.py:181-231:
+// node t looks at sample k0 + hidx[t], e.g. [0,1,2,4,6,9,...] for dt factors 1,2,3): gathered into the
+// handle's own tile [B][T+1][stride]; the terminal node takes the terminal layout of its sample.
+__global__ void k_gather_window(const double *__restrict__ traj, double *__restrict__ ref, const int *__restrict__ hidx, int B, int T,
+                                int stride, int n_points, int k0) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long per_b = (long long)(T + 1) * stride;
+  if (i >= (long long)B * per_b) return;
+  const int b = (int)(i / per_b);
+  const int t = (int)((i % per_b) / stride), e = (int)(i % stride);
+  const double *src = traj + ((long long)b * n_points + k0 + hidx[t]) * 2 * stride + (t == T ? stride : 0);
+  ref[i] = src[e];
+}
+
 // WarmStartReference.generate on the device (warm_start_reference.py:33-96):
 // xs[t] = ref state of sample k0+t (xs[0] = x0), us[t] = ref effort of sample k0+t
 // (us[0] = RNEA at the measured state would need its acceleration: the reference
 // passes initial_state.robot_acceleration; the resident trajectory uses sample k0's).
-__global__ void k_ws_from_ref(double *xs, double *us, double *x0, const double *pts, int B, int T, int NV, int n_points, int k0, int set_x0) {
+__global__ void k_ws_from_ref(double *xs, double *us, double *x0, const double *pts, int B, int T, int NV, int n_points, int k0, int set_x0,
+                              const int *__restrict__ hidx) {
   const long long unit = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (unit >= (long long)B * (T + 1)) return;
   const int b = (int)(unit / (T + 1)), t = (int)(unit % (T + 1));
-  const double *pt = pts + ((long long)b * n_points + k0 + t) * (4 * NV + 12);
+  const double *pt = pts + ((long long)b * n_points + k0 + (hidx ? hidx[t] : t)) * (4 * NV + 12);
   const int NX = 2 * NV;
   for (int i = 0; i < NX; ++i) xs[unit * NX + i] = pt[i];
   if (t < T)

@@ -277,6 +277,10 @@ int agx_traj_generic_create(agx_ocp *ocp, int n_points, const double *q, const d
  * resident trajectory (TrajectoryBuffer.horizon, trajectory.py:218-222, with
  * uniform horizon indexes).                                                    */
 int agx_traj_set_window(agx_ocp *ocp, int k0);
+/* Non-uniform horizon (TrajectoryBuffer.compute_horizon_indexes, trajectory.py:195-216: with
+ * dt factors the node t looks at sample k0 + idx[t], pinned by tests/test_buffer.py:82-93 to
+ * [0,1,2,4,6,9,12,16,20,25,30] for factors 1..4 x 2..3 steps).  idx [T+1], NULL = uniform.  */
+int agx_traj_set_horizon_indexes(agx_ocp *ocp, const int32_t *idx);
 /* Copy trajectory sample k of every instance to the host: q,v,a,u [B][nv], pose [B][12]. */
 int agx_traj_get_point(agx_ocp *ocp, int k, double *q, double *v, double *a, double *u, double *pose);
 /* Warm start from the reference (WarmStartReference.generate,

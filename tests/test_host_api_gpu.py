@@ -338,3 +338,44 @@ def test_generic_trajectory_host_and_resident(hip_backend):
     np.testing.assert_allclose(xs_r[0], np.array(ocp.ocp_results.states), rtol=1e-9, atol=1e-10)
     np.testing.assert_allclose(us_r[0], np.array(ocp.ocp_results.feed_forward_terms), rtol=1e-8, atol=1e-9)
     hb.close()
+
+
+def test_resident_window_with_nonuniform_horizon_indexes(hip_backend):
+    """dt factors (ocp_param_base.py:67-81) + TrajectoryBuffer.horizon_indexes (trajectory.py:195-216):
+    the resident window gathered at [0,1,2,4,6,9,...] equals the host-built horizon, for the first
+    solve and after a shift."""
+    from agimus_controller_amd import backend, workloads
+
+    factors, n_steps = [1, 2, 3], [2, 2, 3]
+    T, dt = sum(n_steps), 0.01
+    rm, params, ocp = make_ocp(T, dt, iters=20, factors=factors, n_steps=n_steps)
+    buf = TrajectoryBuffer(DTFactorsNSeq(factors=factors, n_steps=n_steps))
+    idx = buf.compute_horizon_indexes()
+    assert idx == [0, 1, 2, 4, 6, 9, 12, 15]
+    sp = SinWaveParams(amplitude=np.full(7, 0.1), period=np.full(7, 4.0), scale_duration=np.full(7, 0.2))
+    w = workloads.SINE_WEIGHTS
+    gen = SinusWaveConfigurationSpace(sp, "panda_hand_tcp", w["w_q"] * np.ones(7), w["w_qdot"] * np.ones(7), 1e-6 * np.ones(7),
+                                      w["w_effort"] * np.ones(7), w["w_pose"] * np.ones(6))
+    gen.initialize(rm.robot_model, PANDA_Q0, ocp)
+    n_points = idx[-1] + 4
+    pts = [gen.get_traj_point_at_t(k * dt) for k in range(n_points)]
+    hb = backend.HipOcp(rm.table, ocp.problem, 1)
+    tcp = rm.robot_model.getFrameId("panda_hand_tcp")
+    hb.sine_trajectory(n_points, dt, PANDA_Q0, sp.amplitude, sp.pulsation, sp.scale_duration, 0.0, w["w_q"], w["w_qdot"], w["w_effort"], w["w_pose"], tcp)
+    hb.set_horizon_indexes(idx)
+    for k0 in (0, 1):
+        horizon = [pts[k0 + i] for i in idx]
+        ocp.set_reference_weighted_trajectory(horizon)
+        xs_ws = [np.concatenate([p.point.robot_configuration, p.point.robot_velocity]) for p in horizon]
+        us_ws = [p.point.robot_effort for p in horizon[:-1]]
+        ocp.solve(xs_ws[0], xs_ws, us_ws)
+        hb.set_window(k0)
+        hb.warmstart_from_reference()
+        hb.solve_resident(20)
+        xs_r, us_r, _, st_r = hb.download()
+        assert st_r["iter"][0] == ocp.debug_data.nb_iter
+        np.testing.assert_allclose(xs_r[0], np.array(ocp.ocp_results.states), rtol=1e-9, atol=1e-10)
+        np.testing.assert_allclose(us_r[0], np.array(ocp.ocp_results.feed_forward_terms), rtol=1e-8, atol=1e-9)
+    with pytest.raises(backend.HipError, match="increasing"):
+        hb.set_horizon_indexes([0, 2, 1] + list(range(3, T + 1)))
+    hb.close()
