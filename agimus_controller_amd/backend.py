@@ -25,7 +25,7 @@ EXPORTED_SYMBOLS = [
     "agx_last_error", "agx_device_count", "agx_row_nref", "agx_row_nr", "agx_ref_stride",
     "agx_model_create", "agx_model_destroy", "agx_ocp_create", "agx_ocp_destroy", "agx_ocp_set_stream",
     "agx_ocp_sync", "agx_ocp_set_refs", "agx_ocp_set_refs_device", "agx_ocp_solve", "agx_ocp_upload_x0",
-    "agx_ocp_upload_warmstart", "agx_ocp_solve_resident", "agx_ocp_download", "agx_ocp_download_first", "agx_ocp_first_packed", "agx_ocp_set_geom_placement", "agx_ocp_reset_duals", "agx_traj_generic_create", "agx_traj_set_horizon_indexes",
+    "agx_ocp_upload_warmstart", "agx_ocp_solve_resident", "agx_ocp_download", "agx_ocp_download_first", "agx_ocp_first_packed", "agx_ocp_set_geom_placement", "agx_ocp_reset_duals", "agx_traj_generic_create", "agx_traj_set_horizon_indexes", "agx_ocp_feedback_rollout", "agx_ocp_download_x0",
     "agx_ocp_shift_warmstart", "agx_ocp_x0_from_prediction", "agx_ocp_integrate", "agx_model_rnea",
     "agx_model_frame_placement", "agx_ocp_get_residuals", "agx_ocp_calc_diff", "agx_ocp_direction",
     "agx_ocp_time_kernel", "agx_ocp_profile", "agx_traj_sine_create", "agx_traj_set_window",
@@ -304,5 +304,16 @@ class HipOcp:
     def warmstart_from_reference(self):
         _chk(lib().agx_traj_warmstart_from_reference(self._h))
 
-    def mpc_step(self, k0: int, max_iter: int, first: bool):
-        _chk(lib().agx_ocp_mpc_step(self._h, int(k0), int(max_iter), 1 if first else 0))
+    def mpc_step(self, k0: int, max_iter: int, first):
+        """first: True/1 warm start from the reference, False/0 x0 <- previous xs[1], 2 x0 as set by the caller."""
+        _chk(lib().agx_ocp_mpc_step(self._h, int(k0), int(max_iter), int(first)))
+
+    def download_x0(self):
+        x0 = np.empty((self.B, self.nx))
+        _chk(lib().agx_ocp_download_x0(self._h, _p(x0)))
+        return x0
+
+    def feedback_rollout(self, n_substeps: int, dt_sub: float, disturbance=None):
+        """u = us[0] + K[0] (x0 - x) on the model for n_substeps of dt_sub; the end state becomes x0."""
+        d = None if disturbance is None else _f8(disturbance).reshape(self.B, self.nu)
+        _chk(lib().agx_ocp_feedback_rollout(self._h, int(n_substeps), C.c_double(dt_sub), _p(d)))

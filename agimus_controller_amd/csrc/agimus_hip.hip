@@ -1209,14 +1209,43 @@ int agx_traj_warmstart_from_reference(agx_ocp *o) {
   return ws_from_ref(o, o->win_k0, 1);
 }
 
+int agx_ocp_download_x0(agx_ocp *o, double *x0) {
+  if (!o || !x0) return fail("agx_ocp_download_x0: null argument");
+  if (set_device(o)) return -1;
+  HIPCHK(hipMemcpyAsync(x0, o->d_x0, sizeof(double) * o->B * o->nx, hipMemcpyDeviceToHost, o->stream));
+  HIPCHK(hipStreamSynchronize(o->stream));
+  return 0;
+}
+
+int agx_ocp_feedback_rollout(agx_ocp *o, int n_substeps, double dt_sub, const double *disturbance) {
+  if (!o) return fail("null handle");
+  if (n_substeps < 1 || !(dt_sub > 0.0)) return fail("agx_ocp_feedback_rollout: bad sub-stepping");
+  if (set_device(o)) return -1;
+  double *d_dist = nullptr;
+  if (disturbance) {
+    if (ensure_scratch(o, sizeof(double) * o->B * o->nu)) return -1;
+    d_dist = o->d_scratch;
+    HIPCHK(hipMemcpyAsync(d_dist, disturbance, sizeof(double) * o->B * o->nu, hipMemcpyHostToDevice, o->stream));
+  }
+  return dispatch(o->nv, o->chain, [&](auto NVc, auto CHc) -> int {
+    constexpr int NV = decltype(NVc)::value;
+    constexpr bool CH = decltype(CHc)::value;
+    hipLaunchKernelGGL((agx::k_feedback_rollout<NV, CH>), dim3((o->B + 63) / 64), dim3(64), 0, o->stream, o->d_model, o->d_us, o->d_Kout, o->d_x0,
+                       d_dist, o->B, o->T, n_substeps, dt_sub);
+    HIPCHK(hipGetLastError());
+    if (disturbance) HIPCHK(hipStreamSynchronize(o->stream));  // the caller may reuse its buffer
+    return 0;
+  });
+}
+
 int agx_ocp_mpc_step(agx_ocp *o, int k0, int max_iter, int first) {
   if (!o) return fail("null handle");
   if (set_device(o)) return -1;
   if (agx_traj_set_window(o, k0)) return -1;
-  if (first) {
+  if (first == 1) {
     if (ws_from_ref(o, k0, 1)) return -1;
   } else {
-    if (agx_ocp_x0_from_prediction(o)) return -1;
+    if (first == 0 && agx_ocp_x0_from_prediction(o)) return -1;  // first == 2: x0 was set by the caller / the feedback rollout
     if (agx_ocp_shift_warmstart(o)) return -1;
   }
   return solve_resident(o, max_iter, 0.0);

@@ -1066,6 +1066,47 @@ __global__ void k_integrate(const DevModel *__restrict__ mp, double dt, int n, c
   for (int e = 0; e < NX; ++e) xnext[(long long)i * NX + e] = xn[e];
 }
 
+// The consumer of an MPC step (linear feedback controller behind AgimusController.send_control_msg,
+// agimus_controller_ros/agimus_controller.py:418-426): between two MPC steps the robot is driven at
+// the control rate with  u = us[0] + K[0] (x0 - x_measured).  Here the "robot" is the model itself:
+// n_sub semi-implicit Euler steps of dt_sub per instance, optionally with a constant torque
+// disturbance, starting at x0; the end state becomes the next measured state x0.
+template <int NV, bool CHAIN>
+__global__ void k_feedback_rollout(const DevModel *__restrict__ mp, const double *__restrict__ us, const double *__restrict__ Kout,
+                                   double *__restrict__ x0, const double *__restrict__ disturbance, int B, int T, int n_sub,
+                                   double dt_sub) {
+  constexpr int NX = 2 * NV, NU = NV;
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  double xr[NX], x[NX], u0[NU], K[NU][NX], tau_d[NU];
+#pragma unroll
+  for (int e = 0; e < NX; ++e) { xr[e] = x0[(long long)b * NX + e]; x[e] = xr[e]; }
+#pragma unroll
+  for (int i = 0; i < NU; ++i) {
+    u0[i] = us[(long long)b * T * NU + i];
+    tau_d[i] = disturbance ? disturbance[(long long)b * NU + i] : 0.0;
+#pragma unroll
+    for (int e = 0; e < NX; ++e) K[i][e] = Kout[(long long)b * T * NU * NX + i * NX + e];
+  }
+  DevRows none;
+  none.n = 0;
+  for (int s = 0; s < n_sub; ++s) {
+    double u[NU], xn[NX], c;
+#pragma unroll
+    for (int i = 0; i < NU; ++i) {
+      double acc = u0[i] + tau_d[i];
+#pragma unroll
+      for (int e = 0; e < NX; ++e) acc += K[i][e] * (xr[e] - x[e]);
+      u[i] = acc;
+    }
+    node_calc_running<NV, CHAIN>(*mp, none, dt_sub, x, u, nullptr, nullptr, xn, &c);
+#pragma unroll
+    for (int e = 0; e < NX; ++e) x[e] = xn[e];
+  }
+#pragma unroll
+  for (int e = 0; e < NX; ++e) x0[(long long)b * NX + e] = x[e];
+}
+
 template <int NV, bool CHAIN>
 __global__ void k_rnea(const DevModel *__restrict__ mp, int n, const double *__restrict__ q, const double *__restrict__ v,
                        const double *__restrict__ a, double *__restrict__ tau) {

@@ -288,8 +288,19 @@ int agx_traj_get_point(agx_ocp *ocp, int k, double *q, double *v, double *a, dou
 int agx_traj_warmstart_from_reference(agx_ocp *ocp);
 
 /* One receding-horizon step, MPC.run (mpc.py:32-66), fully device resident:
- * window k0 -> shift warm start -> x0 from prediction (if k0 > first) -> solve.   */
+ * window k0, then by `first`: 1 = warm start and x0 from the reference (first step);
+ * 0 = x0 <- previous xs[1] (closed loop on the own prediction) + warm-start shift;
+ * 2 = x0 as it is (set by agx_ocp_upload_x0 / agx_ocp_feedback_rollout) + warm-start shift; then solve. */
 int agx_ocp_mpc_step(agx_ocp *ocp, int k0, int max_iter, int first);
+/* What consumes an MPC step: the linear feedback controller fed by
+ * AgimusController.send_control_msg (agimus_controller_ros/agimus_controller.py:418-426) applies
+ *   u = us[0] + K[0] (x0 - x_measured)
+ * at the control rate.  Here the plant is the model: n_substeps semi-implicit Euler steps of dt_sub
+ * from the resident x0 under that law (+ an optional constant torque disturbance [B][nu], host);
+ * the end state replaces x0, ready for agx_ocp_mpc_step(..., first = 2).           */
+int agx_ocp_feedback_rollout(agx_ocp *ocp, int n_substeps, double dt_sub, const double *disturbance);
+/* The resident initial state x0 [B][nx] (measured state of the next step).          */
+int agx_ocp_download_x0(agx_ocp *ocp, double *x0);
 
 #ifdef __cplusplus
 }

@@ -261,3 +261,34 @@ def test_full_size_properties(hip_backend, panda):
     assert (st2["iter"] == 0).all() and st2["solved"].all()
     np.testing.assert_array_equal(xs2, xs_h)
     assert rel(K2, K_h) < 1e-12
+
+
+@pytest.mark.gpu
+def test_feedback_rollout_is_the_riccati_feedback_law_on_the_model(hip_backend):
+    """u = us[0] + K[0] (x0 - x) (agimus_controller.py:418-426 feeds exactly these to the
+    linear feedback controller), integrated with the model's own semi-implicit Euler at the control rate."""
+    table = rt.panda_table(0.1)
+    tcp = table.frame_id("panda_hand_tcp")
+    B, T = 3, 10
+    po, ref, x0, xs, us = workloads.random_goal_problem(table, T, 0.01, B, 41, frame=tcp)
+    hb = hip_backend.HipOcp(table, po, B)
+    hb.set_refs(ref)
+    xs_s, us_s, K_s, st = hb.solve(x0, xs, us, 20)
+    dist = np.random.default_rng(0).normal(0, 0.5, (B, 7))
+    n_sub, dt_sub = 10, 1e-3
+    hb.feedback_rollout(n_sub, dt_sub, dist)
+    got = hb.download_x0()
+    o = Oracle(table, po, B)
+    x = x0.copy()
+    for _ in range(n_sub):
+        u = us_s[:, 0] + dist + np.einsum("bij,bj->bi", K_s[:, 0], x0 - x)
+        a = o.forward_dynamics(x[:, :7], x[:, 7:], u).reshape(B, 7)
+        v = x[:, 7:] + dt_sub * a
+        x = np.concatenate([x[:, :7] + dt_sub * v, v], 1)
+    np.testing.assert_allclose(got, x, rtol=1e-10, atol=1e-12)
+    # one sub-step of the node's own dt without disturbance is the plan itself: x0 -> xs[1] up to the
+    # dynamics gap the solver tolerates (KKT <= 1e-3)
+    hb.upload_x0(x0)
+    hb.feedback_rollout(1, 0.01, None)
+    assert np.abs(hb.download_x0() - xs_s[:, 1]).max() < 2e-3
+    hb.close()
