@@ -47,6 +47,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-batch1", action="store_true", help="skip the batch = 1 latency leg (profiling runs)")
     ap.add_argument("--cpu-instances", type=int, default=0, help="instances of the CPU sample (0 = 2 per core)")
+    ap.add_argument("--loop", choices=("prediction", "feedback"), default="prediction",
+                    help="how the next measured state is produced: previous xs[1] (the reference's dummy_mpc_test) or the Riccati "
+                         "feedback law rolled out on the model at 1 kHz (SURVEY 8(f-3))")
     ap.add_argument("--workload", choices=("sine", "generic"), default="sine",
                     help="sine: BASELINE configs[1] (the headline); generic: configs[3] generic_trajectory + pick-and-place costs")
     return ap.parse_args()
@@ -183,7 +186,11 @@ def main():
         workload_name = "Panda 7-DoF generic_trajectory (seeded smooth random accelerations), pick-and-place costs (control_reg + state_reg)"
 
     def step(k):
-        hip.mpc_step(k, args.max_iter, first=(k == 0))
+        if args.loop == "feedback" and k > 0:
+            hip.feedback_rollout(int(round(dt / 1e-3)), 1e-3)
+            hip.mpc_step(k, args.max_iter, first=2)
+        else:
+            hip.mpc_step(k, args.max_iter, first=(k == 0))
         return hip.download_first(copy=False)
 
     def sync_all():
@@ -254,7 +261,8 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": f"{workload_name}, horizon={T}, "
-                            f"dt=0.01, batch={B} independent MPC instances per GPU (seed 1234+b), closed loop on own prediction",
+                            f"dt=0.01, batch={B} independent MPC instances per GPU (seed 1234+b), "
+                            + ("closed loop on own prediction" if args.loop == "prediction" else "closed loop through the Riccati feedback rollout at 1 kHz"),
                 "horizon": T,
                 "batch_per_gpu": B,
                 "global_batch": world * B,
