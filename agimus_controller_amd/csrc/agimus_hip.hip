@@ -161,7 +161,7 @@ int fill_cons(const agx_constraint_row *rows, int n, int nv, const DevModel &m, 
 #ifdef AGX_ONLY_NV7  // development builds: one instantiation, short compile
 #define AGX_FOR_NV(MACRO) MACRO(7)
 #else
-#define AGX_FOR_NV(MACRO) MACRO(1) MACRO(2) MACRO(3) MACRO(4) MACRO(6) MACRO(7)
+#define AGX_FOR_NV(MACRO) MACRO(1) MACRO(2) MACRO(3) MACRO(4) MACRO(6) MACRO(7) MACRO(30)
 #endif
 
 template <typename F>
@@ -174,7 +174,7 @@ int dispatch(int nv, bool chain, F &&f) {
     AGX_FOR_NV(AGX_CASE)
 #undef AGX_CASE
   }
-  return fail("no kernel instantiation for nv = " + std::to_string(nv) + " (compiled: 1,2,3,4,6,7)");
+  return fail("no kernel instantiation for nv = " + std::to_string(nv) + " (compiled: 1,2,3,4,6,7,30)");
 }
 
 int ensure_canonical_tiles(agx_ocp *o) {
@@ -207,14 +207,17 @@ int launch_calc_qp(agx_ocp *o, bool running_only = false, bool term_only = false
     constexpr int NV = decltype(NVc)::value;
     constexpr bool CH = decltype(CHc)::value;
     const long long units = (long long)o->B * o->T;
-    if (CH && o->k1_lanes && o->lanes_ok) {
+    bool lanes = false;
+    if constexpr (NV <= 7) lanes = CH && o->k1_lanes && o->lanes_ok;
+    if constexpr (NV <= 7) if (lanes) {
       if (!term_only)
       hipLaunchKernelGGL((agx::k_calc_qp_lj<NV, false>), dim3((int)((units * 8 + 63) / 64)), dim3(64), 0, o->stream, o->d_model,
                          o->d_ocp, o->d_dt, o->d_xs, o->d_us, o->rv, o->d_qt, o->d_aux, o->d_state);
       if (!running_only)
         hipLaunchKernelGGL((agx::k_calc_qp_lj<NV, true>), dim3((int)(((long long)o->B * 8 + 63) / 64)), dim3(64), 0, o->stream,
                            o->d_model, o->d_ocp, o->d_dt, o->d_xs, o->d_us, o->rv, o->d_qt, o->d_aux, o->d_state);
-    } else {
+    }
+    if (!lanes) {
       if (!term_only)
       hipLaunchKernelGGL((agx::k_calc_qp<NV, CH>), dim3((int)((units + 63) / 64)), dim3(64), 0, o->stream, o->d_model, o->d_ocp,
                          o->d_dt, o->d_xs, o->d_us, o->rv, o->d_qt, o->d_aux, o->d_state);
@@ -232,12 +235,18 @@ int launch_riccati(agx_ocp *o, int forward, bool pair = false, int iter = 0, con
   return dispatch(o->nv, o->chain, [&](auto NVc, auto CHc) -> int {
     constexpr int NV = decltype(NVc)::value;
     const double *qt = tiles ? tiles : o->d_qt;
-    if (pair)
-      hipLaunchKernelGGL((agx::k_riccati_pair<NV>), dim3(2 * o->B), dim3(64), 0, o->stream, o->d_ocp, o->d_dt, o->d_qt, o->d_aux,
-                         o->d_Kws, o->d_kws, o->d_dx, o->d_w, o->d_du, o->d_Kout, o->d_state, iter);
-    else
-      hipLaunchKernelGGL((agx::k_riccati<NV, false>), dim3(o->B), dim3(64), 0, o->stream, o->d_ocp, o->d_dt, qt, o->d_aux,
-                         o->d_Kws, o->d_kws, o->d_dx, o->d_w, o->d_du, o->d_Kout, o->d_state, forward, 0);
+    if constexpr (NV <= 7) {
+      if (pair)
+        hipLaunchKernelGGL((agx::k_riccati_pair<NV>), dim3(2 * o->B), dim3(64), 0, o->stream, o->d_ocp, o->d_dt, o->d_qt, o->d_aux,
+                           o->d_Kws, o->d_kws, o->d_dx, o->d_w, o->d_du, o->d_Kout, o->d_state, iter);
+      else
+        hipLaunchKernelGGL((agx::k_riccati<NV, false>), dim3(o->B), dim3(64), 0, o->stream, o->d_ocp, o->d_dt, qt, o->d_aux,
+                           o->d_Kws, o->d_kws, o->d_dx, o->d_w, o->d_du, o->d_Kout, o->d_state, forward, 0);
+    } else {
+      (void)pair; (void)iter;
+      hipLaunchKernelGGL((agx::k_riccati_big<NV>), dim3(o->B), dim3(256), 0, o->stream, o->d_ocp, o->d_dt, qt, o->d_Kws, o->d_kws, o->d_dx,
+                         o->d_w, o->d_state, forward, 0);
+    }
     HIPCHK(hipGetLastError());
     return 0;
   });
@@ -249,9 +258,14 @@ int launch_step(agx_ocp *o, int iter, int max_iter, int mode, bool with_node_kkt
     constexpr int NV = decltype(NVc)::value;
     constexpr bool CH = decltype(CHc)::value;
     const long long nodes = (long long)o->B * (o->T + 1);
-    if (with_node_kkt)
-      hipLaunchKernelGGL((agx::k_node_kkt<NV>), dim3((int)((nodes * 8 + 255) / 256)), dim3(256), 0, o->stream, o->d_ocp, o->d_qt, o->d_aux,
-                         o->d_dx, o->d_w, o->d_du, o->d_nodestat, o->d_state);
+    if (with_node_kkt) {
+      if constexpr (NV <= 7)
+        hipLaunchKernelGGL((agx::k_node_kkt<NV>), dim3((int)((nodes * 8 + 255) / 256)), dim3(256), 0, o->stream, o->d_ocp, o->d_qt, o->d_aux,
+                           o->d_dx, o->d_w, o->d_du, o->d_nodestat, o->d_state);
+      else
+        hipLaunchKernelGGL((agx::k_node_kkt_big<NV>), dim3((int)((nodes + 63) / 64)), dim3(64), 0, o->stream, o->d_ocp, o->d_qt, o->d_aux,
+                           o->d_dx, o->d_w, o->d_du, o->d_nodestat, o->d_state);
+    }
     if (!with_step) { HIPCHK(hipGetLastError()); return 0; }
     hipLaunchKernelGGL((agx::k_step<NV, CH>), dim3(o->B), dim3(128), 0, o->stream, o->d_model, o->d_ocp, o->d_dt, o->d_xs, o->d_us,
                        o->rv, o->d_qt, o->d_aux, o->d_dx, o->d_nodestat, o->d_du, o->d_state, iter, max_iter, mode, o->d_ndone);
@@ -263,10 +277,23 @@ int launch_step(agx_ocp *o, int iter, int max_iter, int mode, bool with_node_kkt
 // exit path: the sigma (proximal) Riccati sweep that yields the gains the solver reports, one kernel.
 // gmode 0: every instance; 2: only instances whose last direction has no (speculative) sweep yet.
 int launch_gains(agx_ocp *o, int gmode = 0) {
+  if (o->nv > 7 && !o->d_qt2) HIPCHK(hipMalloc((void **)&o->d_qt2, sizeof(double) * (size_t)o->B * (o->T + 1) * o->qt_size));
   return dispatch(o->nv, o->chain, [&](auto NVc, auto CHc) -> int {
     constexpr int NV = decltype(NVc)::value;
-    hipLaunchKernelGGL((agx::k_riccati<NV, true>), dim3(o->B), dim3(64), 0, o->stream, o->d_ocp, o->d_dt, o->d_qt, o->d_aux, o->d_Kws,
-                       o->d_kws, o->d_dx, o->d_w, o->d_du, o->d_Kout, o->d_state, 0, gmode);
+    if constexpr (NV <= 7) {
+      hipLaunchKernelGGL((agx::k_riccati<NV, true>), dim3(o->B), dim3(64), 0, o->stream, o->d_ocp, o->d_dt, o->d_qt, o->d_aux, o->d_Kws,
+                         o->d_kws, o->d_dx, o->d_w, o->d_du, o->d_Kout, o->d_state, 0, gmode);
+    } else {
+      // large models: sigma-augmented tiles, LDS sweep, gains to u-space -- for every instance
+      const long long nodes = (long long)o->B * (o->T + 1);
+      hipLaunchKernelGGL((agx::k_sigma_tile_big<NV>), dim3((int)((nodes * 32 + 255) / 256)), dim3(256), 0, o->stream, o->d_ocp, o->d_qt,
+                         o->d_qt2, o->d_aux);
+      hipLaunchKernelGGL((agx::k_riccati_big<NV>), dim3(o->B), dim3(256), 0, o->stream, o->d_ocp, o->d_dt, o->d_qt2, o->d_Kws, o->d_kws,
+                         o->d_dx, o->d_w, o->d_state, 0, 1);
+      const long long units = (long long)o->B * o->T * 64;
+      hipLaunchKernelGGL((agx::k_gains_to_u_big<NV>), dim3((int)((units + 255) / 256)), dim3(256), 0, o->stream, o->d_ocp, o->d_aux,
+                         o->d_Kws, o->d_Kout);
+    }
     HIPCHK(hipGetLastError());
     return 0;
   });
@@ -345,6 +372,8 @@ int admm_direction(agx_ocp *o) {
   return dispatch(o->nv, o->chain, [&](auto NVc, auto CHc) -> int {
     constexpr int NV = decltype(NVc)::value;
     constexpr bool CH = decltype(CHc)::value;
+    if constexpr (NV > 7) return fail("constraints need nv <= 7");
+    else {
     const long long nodes = (long long)o->B * (o->T + 1);
     const int g8 = (int)((nodes * 8 + 255) / 256), g8b = (int)((nodes * 8 + 127) / 128), g1 = (int)((nodes + 255) / 256);
     if (launch_step(o, 0, 0, 0, true, false)) return -1;  // du of the initial guess (k_node_kkt)
@@ -376,6 +405,7 @@ int admm_direction(agx_ocp *o) {
                        o->d_Kout, o->d_state);
     HIPCHK(hipGetLastError());
     return 0;
+    }
   });
 }
 
@@ -551,8 +581,9 @@ int agx_ocp_create(const agx_model *m, const agx_ocp_desc *d, int batch, int dev
   if (const char *e = getenv("AGX_SPECULATE_GAINS")) o->speculate = (e[0] != '0');
   o->T = d->horizon; o->B = batch; o->device = device;
   o->tile = AGX_TILE_DOUBLES(o->nv);
-  o->qt_size = 6 * o->nv * 8 + 48;   // QT<NV>::SIZE
-  o->aux_size = 4 * o->nv * 8 + 24;  // AUX<NV>::SIZE
+  const int ld = o->nv <= 8 ? 8 : 32;
+  o->qt_size = 6 * o->nv * ld + 5 * ld + 8;  // QT<NV>::SIZE
+  o->aux_size = 4 * o->nv * ld + 3 * ld;     // AUX<NV>::SIZE
   o->stride = agx_ref_stride(d, o->nv);
   o->dt.assign(d->dt, d->dt + d->horizon);
   std::memset(&o->ho, 0, sizeof(o->ho));

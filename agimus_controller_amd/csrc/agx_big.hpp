@@ -1,0 +1,254 @@
+// agimus_controller_amd -- large models (nv > 7, e.g. the 30-DoF humanoid of BASELINE configs[4]).
+//
+// The register-resident kernels map an nv x nv block onto an 8 x 8 lane grid; beyond that the same
+// algebra runs out of LDS: one 256-thread workgroup per instance keeps the 3nv x (3nv + 1) elimination
+// matrix (w | q | v blocks + gradient column) and the value function of node t+1 in LDS
+// (nv = 30: 66 KB + 29 KB) and eliminates the nv acceleration variables with nv Gauss-Jordan pivots,
+// two barriers each.  Same tiles (row stride 32), same acceleration-input QP, same outputs as the
+// nv <= 7 path; correctness first -- the derivative pass for these sizes is the one-lane-per-node
+// kernel with per-lane arrays in scratch (agx_kernels.hpp), the next step is an LDS-tiled / fp64-MFMA
+// version of both.
+//
+// (included at the end of agx_kernels.hpp)
+#pragma once
+
+namespace agx {
+
+// K2 for large nv.  gains_pass: backward sweep only, every instance, on the sigma-augmented tiles
+// (k_sigma_tile_big), gradient ignored.
+template <int NV>
+__global__ void __launch_bounds__(256) k_riccati_big(const DevOcp *__restrict__ op, const double *__restrict__ dts,
+                                                     const double *__restrict__ qts, double *__restrict__ Kws,
+                                                     double *__restrict__ kws, double *__restrict__ dxs,
+                                                     double *__restrict__ wss, const DevState *__restrict__ st, int forward,
+                                                     int gains_pass) {
+  constexpr int NX = 2 * NV, R = 3 * NV, GC = 3 * NV, CS = 3 * NV + 2;
+  typedef QT<NV> Q;
+  __shared__ double Mx[R * CS];
+  __shared__ double V[NX * NX];
+  __shared__ double vx[NX], vp[NX], fl[NX], fac[R], rpv[NV], dxl[NX], wl[NV];
+  const DevOcp &o = *op;
+  const int T = o.T, b = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
+  const DevState &S = st[b];
+  if (!gains_pass && (S.done || S.admm_conv)) return;
+  const double dreg = gains_pass ? (S.solved ? S.dreg : S.gains_dreg) : S.dreg;
+  const double *qb = qts + (long long)b * (T + 1) * Q::SIZE;
+  double *Kw = Kws + (long long)b * T * NV * NX, *kw = kws + (long long)b * T * NV;
+  // value function of the terminal node
+  {
+    const double *tt = qb + (long long)T * Q::SIZE;
+    for (int e = tid; e < NX * NX; e += nt) {
+      const int i = e / NX, j = e % NX;
+      const int ib = i < NV ? i : i - NV, jb = j < NV ? j : j - NV;
+      double v;
+      if (i < NV && j < NV) v = tt[Q::Hqq + ib * Q::LD + jb];
+      else if (i < NV) v = tt[Q::Hqv + ib * Q::LD + jb];
+      else if (j < NV) v = tt[Q::Hqv + jb * Q::LD + ib];
+      else v = tt[Q::Hvv + ib * Q::LD + jb];
+      V[e] = v + ((i == j) ? dreg : 0.0);
+    }
+    for (int i = tid; i < NX; i += nt) vx[i] = gains_pass ? 0.0 : tt[Q::gx + i];
+  }
+  __syncthreads();
+  for (int t = T - 1; t >= 0; --t) {
+    const double *tl = qb + (long long)t * Q::SIZE;
+    const double h = dts[t], h2 = h * h;
+    // vp = vx + V f
+    for (int i = tid; i < NX; i += nt) fl[i] = gains_pass ? 0.0 : tl[Q::f + i];
+    __syncthreads();
+    for (int i = tid; i < NX; i += nt) {
+      double s = vx[i];
+      for (int j = 0; j < NX; ++j) s += V[i * NX + j] * fl[j];
+      vp[i] = s;
+    }
+    __syncthreads();
+    // elimination matrix: rows / columns  w (0..NV) | q | v, gradient in column GC
+    for (int e = tid; e < NV * NV; e += nt) {
+      const int r = e / NV, c = e % NV;
+      const int rc = r * Q::LD + c, cr = c * Q::LD + r;
+      const double Vqq = V[r * NX + c], Vqv = V[r * NX + NV + c], Vvq = V[(NV + r) * NX + c], Vvv = V[(NV + r) * NX + NV + c];
+      const double Yq = h2 * Vqq + h * Vvq, Yv = h2 * Vqv + h * Vvv;
+      const double YqT = h2 * Vqq + h * Vqv, YvT = h2 * Vvq + h * Vvv;
+      Mx[r * CS + c] = tl[Q::Hww + rc] + h2 * Yq + h * Yv;
+      Mx[r * CS + NV + c] = tl[Q::Hqw + cr] + Yq;
+      Mx[r * CS + 2 * NV + c] = tl[Q::Hvw + cr] + h * Yq + Yv;
+      Mx[(NV + r) * CS + c] = tl[Q::Hqw + rc] + YqT;
+      Mx[(2 * NV + r) * CS + c] = tl[Q::Hvw + rc] + h * YqT + YvT;
+      Mx[(NV + r) * CS + NV + c] = tl[Q::Hqq + rc] + Vqq;
+      Mx[(NV + r) * CS + 2 * NV + c] = tl[Q::Hqv + rc] + h * Vqq + Vqv;
+      Mx[(2 * NV + r) * CS + NV + c] = tl[Q::Hqv + cr] + h * Vqq + Vvq;
+      Mx[(2 * NV + r) * CS + 2 * NV + c] = tl[Q::Hvv + rc] + h2 * Vqq + h * (Vqv + Vvq) + Vvv;
+    }
+    for (int r = tid; r < NV; r += nt) {
+      const double vpq = vp[r], vpv = vp[NV + r];
+      Mx[r * CS + GC] = gains_pass ? 0.0 : tl[Q::gw + r] + h2 * vpq + h * vpv;
+      Mx[(NV + r) * CS + GC] = gains_pass ? 0.0 : tl[Q::gx + r] + vpq;
+      Mx[(2 * NV + r) * CS + GC] = gains_pass ? 0.0 : tl[Q::gx + NV + r] + h * vpq + vpv;
+    }
+    __syncthreads();
+    // Gauss-Jordan pivots on the w block; the pivot row itself stays as it is
+    for (int k = 0; k < NV; ++k) {
+      const double rp = 1.0 / Mx[k * CS + k];
+      for (int r = tid; r < R; r += nt) fac[r] = (r == k) ? 0.0 : Mx[r * CS + k] * rp;
+      if (tid == 0) rpv[k] = rp;
+      __syncthreads();
+      const int nc = GC - k;  // columns k+1 .. GC
+      for (int e = tid; e < R * nc; e += nt) {
+        const int r = e / nc, c = k + 1 + e % nc;
+        Mx[r * CS + c] -= fac[r] * Mx[k * CS + c];
+      }
+      __syncthreads();
+    }
+    // gains of this node and the value function of node t
+    for (int e = tid; e < NV * NX; e += nt) {
+      const int r = e / NX, c = e % NX;
+      Kw[(long long)t * NV * NX + e] = Mx[r * CS + NV + c] * rpv[r];
+    }
+    for (int r = tid; r < NV; r += nt) kw[(long long)t * NV + r] = Mx[r * CS + GC] * rpv[r];
+    for (int e = tid; e < NX * NX; e += nt) {
+      const int i = e / NX, j = e % NX;
+      V[e] = 0.5 * (Mx[(NV + i) * CS + NV + j] + Mx[(NV + j) * CS + NV + i]) + ((i == j) ? dreg : 0.0);
+    }
+    for (int i = tid; i < NX; i += nt) vx[i] = Mx[(NV + i) * CS + GC];
+    __syncthreads();
+  }
+  if (gains_pass || !forward) return;
+  // forward pass
+  double *dx = dxs + (long long)b * (T + 1) * NX, *ws = wss + (long long)b * T * NV;
+  for (int i = tid; i < NX; i += nt) { dxl[i] = 0.0; dx[i] = 0.0; }
+  __threadfence_block();
+  __syncthreads();
+  for (int t = 0; t < T; ++t) {
+    const double *tl = qb + (long long)t * Q::SIZE;
+    const double h = dts[t], h2 = h * h;
+    for (int r = tid; r < NV; r += nt) {
+      double s = -kw[(long long)t * NV + r];
+      const double *kr = Kw + ((long long)t * NV + r) * NX;
+      for (int c = 0; c < NX; ++c) s -= kr[c] * dxl[c];
+      wl[r] = s;
+      ws[(long long)t * NV + r] = s;
+    }
+    __syncthreads();
+    double nq = 0.0, nv2 = 0.0;
+    if (tid < NV) {
+      nq = dxl[tid] + h * dxl[NV + tid] + h2 * wl[tid] + tl[Q::f + tid];
+      nv2 = dxl[NV + tid] + h * wl[tid] + tl[Q::f + NV + tid];
+    }
+    __syncthreads();
+    if (tid < NV) {
+      dxl[tid] = nq; dxl[NV + tid] = nv2;
+      dx[(long long)(t + 1) * NX + tid] = nq;
+      dx[(long long)(t + 1) * NX + NV + tid] = nv2;
+    }
+    __syncthreads();
+  }
+}
+
+// K3 for large nv: one lane per node, plain loops (see k_node_kkt for the identities).
+template <int NV>
+__global__ void __launch_bounds__(64) k_node_kkt_big(const DevOcp *__restrict__ op, const double *__restrict__ qts,
+                                                     const double *__restrict__ auxs, const double *__restrict__ dxs,
+                                                     const double *__restrict__ wss, double *__restrict__ dus,
+                                                     double *__restrict__ nodestat, const DevState *__restrict__ st) {
+  constexpr int NX = 2 * NV;
+  typedef QT<NV> Q;
+  typedef AUX<NV> A;
+  const DevOcp &o = *op;
+  const int T = o.T;
+  const long long node = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (node >= (long long)o.B * (T + 1)) return;
+  const int b = (int)(node / (T + 1)), t = (int)(node % (T + 1));
+  const DevState &S = st[b];
+  if (S.done) return;
+  const double preg = S.preg, dreg = S.dreg;
+  const double *qt = qts + node * Q::SIZE;
+  const double *ax = auxs + node * A::SIZE;
+  const double *dx = dxs + node * NX;
+  double kkt = 0.0, gap = 0.0;
+  if (t < T) {
+    const double *w = wss + ((long long)b * T + t) * NV;
+    double *du = dus + ((long long)b * T + t) * NV;
+    for (int i = 0; i < NX; ++i) { kkt = fmax(kkt, fabs(qt[Q::f + i])); gap += fabs(qt[Q::f + i]); }
+    for (int i = 0; i < NV; ++i) {
+      double s = 0.0;
+      for (int l = 0; l < NV; ++l)
+        s += ax[A::M + i * A::LD + l] * w[l] + ax[A::tq + i * A::LD + l] * dx[l] + ax[A::tv + i * A::LD + l] * dx[NV + l];
+      du[i] = s;
+      kkt = fmax(kkt, fabs((ax[A::Luu + i] + preg) * s));
+    }
+  }
+  if (t > 0)
+    for (int i = 0; i < NV; ++i) {
+      double hq = dreg * dx[i];
+      for (int j = 0; j < NV; ++j) hq += ax[A::Lqq + i * A::LD + j] * dx[j];
+      kkt = fmax(kkt, fmax(fabs(hq), fabs((ax[A::Lvv + i] + dreg) * dx[NV + i])));
+    }
+  double *ns = nodestat + node * 4;
+  ns[0] = kkt; ns[1] = qt[Q::cost]; ns[2] = gap; ns[3] = 0.0;
+}
+
+// Exit path for large nv: the Hessian blocks of every node with CSQP's proximal terms,
+//   H + sigma ([taux M]' [taux M] + I_x),  into a second tile; 32 lanes per node, lane j = column j.
+template <int NV>
+__global__ void __launch_bounds__(256) k_sigma_tile_big(const DevOcp *__restrict__ op, const double *__restrict__ qts,
+                                                        double *__restrict__ qt2s, const double *__restrict__ auxs) {
+  typedef QT<NV> Q;
+  typedef AUX<NV> A;
+  const DevOcp &o = *op;
+  const int T = o.T;
+  const long long unit = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long node = unit >> 5;
+  const int j = (int)(unit & 31);
+  if (node >= (long long)o.B * (T + 1) || j >= NV) return;
+  const int t = (int)(node % (T + 1));
+  const double *qt = qts + node * Q::SIZE;
+  double *q2 = qt2s + node * Q::SIZE;
+  const double *ax = auxs + node * A::SIZE;
+  const double sig = kSigma;
+  for (int i = 0; i < NV; ++i) {
+    double hww = 0.0, hqw = 0.0, hvw = 0.0, hqq = 0.0, hqv = 0.0, hvv = 0.0;
+    if (t < T)
+      for (int l = 0; l < NV; ++l) {
+        const double Mli = ax[A::M + l * A::LD + i], tqli = ax[A::tq + l * A::LD + i], tvli = ax[A::tv + l * A::LD + i];
+        const double Mlj = ax[A::M + l * A::LD + j], tqlj = ax[A::tq + l * A::LD + j], tvlj = ax[A::tv + l * A::LD + j];
+        hww += Mli * Mlj; hqw += tqli * Mlj; hvw += tvli * Mlj;
+        hqq += tqli * tqlj; hqv += tqli * tvlj; hvv += tvli * tvlj;
+      }
+    const double d = (i == j) ? sig : 0.0;
+    const int e = i * Q::LD + j;
+    q2[Q::Hqq + e] = qt[Q::Hqq + e] + sig * hqq + d;
+    q2[Q::Hqv + e] = qt[Q::Hqv + e] + sig * hqv;
+    q2[Q::Hvv + e] = qt[Q::Hvv + e] + sig * hvv + d;
+    if (t < T) {
+      q2[Q::Hww + e] = qt[Q::Hww + e] + sig * hww;
+      q2[Q::Hqw + e] = qt[Q::Hqw + e] + sig * hqw;
+      q2[Q::Hvw + e] = qt[Q::Hvw + e] + sig * hvw;
+    }
+  }
+}
+
+// K = M Kw - taux for large nv: 64 lanes per node, lane j < 2 nv = column of K
+template <int NV>
+__global__ void __launch_bounds__(256) k_gains_to_u_big(const DevOcp *__restrict__ op, const double *__restrict__ auxs,
+                                                        const double *__restrict__ Kws, double *__restrict__ Kout) {
+  constexpr int NX = 2 * NV;
+  typedef AUX<NV> A;
+  const DevOcp &o = *op;
+  const int T = o.T;
+  const long long unit = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long node = unit >> 6;
+  const int j = (int)(unit & 63);
+  if (node >= (long long)o.B * T || j >= NX) return;
+  const int b = (int)(node / T), t = (int)(node % T);
+  const double *ax = auxs + ((long long)b * (T + 1) + t) * A::SIZE;
+  const double *Kw = Kws + node * NV * NX;
+  double *K = Kout + node * NV * NX;
+  const double *tx = (j < NV) ? ax + A::tq + j : ax + A::tv + (j - NV);
+  for (int i = 0; i < NV; ++i) {
+    double acc = -tx[i * A::LD];
+    for (int l = 0; l < NV; ++l) acc += ax[A::M + i * A::LD + l] * Kw[l * NX + j];
+    K[i * NX + j] = acc;
+  }
+}
+
+}  // namespace agx

@@ -62,7 +62,9 @@ struct DevOcp {
 };
 
 #define AGX_DEV __device__ __forceinline__
-#define AGX_UNROLL(NV) _Pragma("unroll")
+// loops over the joints: fully unrolled for the register-resident sizes (nv <= 8), rolled for
+// large models (nv = 30: per-lane arrays live in scratch, the code must stay small)
+#define AGX_UNROLL_NV _Pragma("clang loop unroll_count(NV <= 8 ? 64 : 1)")
 
 namespace agx {
 
@@ -204,7 +206,7 @@ AGX_DEV bool is_anc(const DevModel &m, int i, int j) {  // j ancestor-or-self of
 
 template <int NV, bool CHAIN>
 AGX_DEV void kinematics(const DevModel &m, const double *q, Kin<NV> &k) {
-#pragma unroll
+AGX_UNROLL_NV
   for (int i = 0; i < NV; ++i) {
     const double *ax = m.axis[i];
     double s, c;
@@ -280,7 +282,7 @@ struct Dyn {
 template <int NV, bool CHAIN>
 AGX_DEV void bias_and_inertia(const DevModel &m, const Kin<NV> &k, const double *qd, Dyn<NV> &d, double *nle, double (*M)[NV]) {
   double f[NV][6];
-#pragma unroll
+AGX_UNROLL_NV
   for (int i = 0; i < NV; ++i) {
     const int par = parent_of<NV, CHAIN>(m, i);
 #pragma unroll
@@ -303,7 +305,7 @@ AGX_DEV void bias_and_inertia(const DevModel &m, const Kin<NV> &k, const double 
     nle[i] = dot6(k.S[i], f[i]);
     double m6[6];
     iapply(d.Ic[i], k.S[i], m6);
-#pragma unroll
+AGX_UNROLL_NV
     for (int j = 0; j < NV; ++j) {
       if (j <= i || !CHAIN) {
         if (j == i) {
@@ -332,7 +334,7 @@ AGX_DEV void bias_and_inertia(const DevModel &m, const Kin<NV> &k, const double 
 template <int NV>
 AGX_DEV void spd_inverse(double (*A)[NV], double (*Ainv)[NV]) {
   double Li[NV][NV];  // L^-1 (lower)
-#pragma unroll
+AGX_UNROLL_NV
   for (int j = 0; j < NV; ++j) {
     double dd = A[j][j];
 #pragma unroll
@@ -340,7 +342,7 @@ AGX_DEV void spd_inverse(double (*A)[NV], double (*Ainv)[NV]) {
     const double l = sqrt(dd);
     const double il = 1.0 / l;
     A[j][j] = l;
-#pragma unroll
+AGX_UNROLL_NV
     for (int i = j + 1; i < NV; ++i) {
       double s = A[i][j];
 #pragma unroll
@@ -349,10 +351,10 @@ AGX_DEV void spd_inverse(double (*A)[NV], double (*Ainv)[NV]) {
     }
   }
   // invert L: Li[i][j] for j <= i
-#pragma unroll
+AGX_UNROLL_NV
   for (int j = 0; j < NV; ++j) {
     Li[j][j] = 1.0 / A[j][j];
-#pragma unroll
+AGX_UNROLL_NV
     for (int i = j + 1; i < NV; ++i) {
       double s = 0.0;
 #pragma unroll
@@ -360,7 +362,7 @@ AGX_DEV void spd_inverse(double (*A)[NV], double (*Ainv)[NV]) {
       Li[i][j] = s / A[i][i];
     }
   }
-#pragma unroll
+AGX_UNROLL_NV
   for (int i = 0; i < NV; ++i)
 #pragma unroll
     for (int j = 0; j <= i; ++j) {
@@ -385,7 +387,7 @@ template <int NV, bool CHAIN>
 AGX_DEV void rnea_derivatives(const DevModel &m, const Kin<NV> &k, const Dyn<NV> &d, const double *qd, const double *qdd,
                               double (*dq)[NV], double (*dv)[NV]) {
   double a[NV][6], psi[NV][6], fC[NV][6], f0C[NV][3], EC[NV][9];
-#pragma unroll
+AGX_UNROLL_NV
   for (int i = 0; i < NV; ++i) {
     const int par = parent_of<NV, CHAIN>(m, i);
 #pragma unroll
@@ -452,7 +454,7 @@ AGX_DEV void rnea_derivatives(const DevModel &m, const Kin<NV> &k, const Dyn<NV>
       colq[e] = sxf[e] - 2.0 * u2[e] + IcPs[e];
       colq[3 + e] = sxf[3 + e] + e2[e] + IcPs[3 + e];
     }
-#pragma unroll
+AGX_UNROLL_NV
     for (int j = 0; j < NV; ++j) {
       if (j == i) {
         dv[i][i] = 2.0 * dot6(m6, d.Sd[i]) + dot3(Dt, k.S[i] + 3);
@@ -484,7 +486,7 @@ AGX_DEV void rnea_derivatives(const DevModel &m, const Kin<NV> &k, const Dyn<NV>
 template <int NV, bool CHAIN>
 AGX_DEV void rnea(const DevModel &m, const Kin<NV> &k, const double *qd, const double *qdd, double *tau) {
   double v[NV][6], a[NV][6], f[NV][6];
-#pragma unroll
+AGX_UNROLL_NV
   for (int i = 0; i < NV; ++i) {
     const int par = parent_of<NV, CHAIN>(m, i);
     double Sd[6], I[10];
@@ -618,7 +620,7 @@ AGX_DEV void frame_world(const DevModel &m, const Kin<NV> &k, int frame, double 
     for (int e = 0; e < 9; ++e) Rp[e] = 0.0;
 #pragma unroll
     for (int e = 0; e < 3; ++e) pp[e] = 0.0;
-#pragma unroll
+AGX_UNROLL_NV
     for (int i = 0; i < NV; ++i)
       if (i == par) {
 #pragma unroll
@@ -735,7 +737,7 @@ AGX_DEV void node_costs(const DevModel &m, const DevRows &rows, const Kin<NV> &k
                         const double *ref, const int *frames, CostAcc<NV> &c) {
   c.cost = 0.0;
   if (DIFF) {
-#pragma unroll
+AGX_UNROLL_NV
     for (int i = 0; i < NV; ++i) {
       c.Lq[i] = 0.0; c.Lv[i] = 0.0; c.Lu[i] = 0.0; c.Lvv[i] = 0.0; c.Luu[i] = 0.0;
 #pragma unroll
@@ -751,7 +753,7 @@ AGX_DEV void node_costs(const DevModel &m, const DevRows &rows, const Kin<NV> &k
     const int kind = rows.kind[r];
     if (kind == AGX_RES_STATE) {
       double a = 0.0;
-#pragma unroll
+AGX_UNROLL_NV
       for (int i = 0; i < NV; ++i) {
         const double rq = x[i] - rr[i], rv = x[NV + i] - rr[NV + i];
         a += 0.5 * (aw[i] * rq * rq + aw[NV + i] * rv * rv);
@@ -766,7 +768,7 @@ AGX_DEV void node_costs(const DevModel &m, const DevRows &rows, const Kin<NV> &k
     } else if (kind == AGX_RES_CONTROL) {
       if (!TERM) {
         double a = 0.0;
-#pragma unroll
+AGX_UNROLL_NV
         for (int i = 0; i < NV; ++i) {
           const double ru = u[i] - rr[i];
           a += 0.5 * aw[i] * ru * ru;
@@ -793,7 +795,7 @@ AGX_DEV void node_costs(const DevModel &m, const DevRows &rows, const Kin<NV> &k
         mtv3(rr, d, prel);
         log6<DIFF>(Rrel, prel, res, TL, TR);
         if (DIFF) {
-#pragma unroll
+AGX_UNROLL_NV
           for (int j = 0; j < NV; ++j) {
             const bool on = (jf >= 0) && (CHAIN ? (j <= jf) : ((m.anc[jf >= 0 ? jf : 0] >> j) & 1u));
             double lin[3], ang[3], dl[3], t[3];
@@ -816,7 +818,7 @@ AGX_DEV void node_costs(const DevModel &m, const DevRows &rows, const Kin<NV> &k
         res[0] = pF[0] - rr[0]; res[1] = pF[1] - rr[1]; res[2] = pF[2] - rr[2];
         res[3] = res[4] = res[5] = 0.0;
         if (DIFF) {
-#pragma unroll
+AGX_UNROLL_NV
           for (int j = 0; j < NV; ++j) {
             const bool on = (jf >= 0) && (CHAIN ? (j <= jf) : ((m.anc[jf >= 0 ? jf : 0] >> j) & 1u));
             double dl[3], t[3];
@@ -834,7 +836,7 @@ AGX_DEV void node_costs(const DevModel &m, const DevRows &rows, const Kin<NV> &k
         res[3] = res[4] = res[5] = 0.0;
         if (DIFF) {
           jlog3(res, TL);
-#pragma unroll
+AGX_UNROLL_NV
           for (int j = 0; j < NV; ++j) {
             const bool on = (jf >= 0) && (CHAIN ? (j <= jf) : ((m.anc[jf >= 0 ? jf : 0] >> j) & 1u));
             double ang[3];
@@ -858,7 +860,7 @@ AGX_DEV void node_costs(const DevModel &m, const DevRows &rows, const Kin<NV> &k
         for (int e = 0; e < 6; ++e) {
           if (e < nr) {
             const double we = wi * aw[e];
-#pragma unroll
+AGX_UNROLL_NV
             for (int i = 0; i < NV; ++i) {
               c.Lq[i] += we * res[e] * J[e][i];
 #pragma unroll
@@ -877,7 +879,7 @@ AGX_DEV void node_costs(const DevModel &m, const DevRows &rows, const Kin<NV> &k
       c.cost += wi * a;
       if (DIFF) {
         double g[NV];
-#pragma unroll
+AGX_UNROLL_NV
         for (int j = 0; j < NV; ++j) {
           const bool ona = (ja >= 0) && (CHAIN ? (j <= ja) : ((m.anc[ja >= 0 ? ja : 0] >> j) & 1u));
           const bool onb = (jb >= 0) && (CHAIN ? (j <= jb) : ((m.anc[jb >= 0 ? jb : 0] >> j) & 1u));
@@ -888,7 +890,7 @@ AGX_DEV void node_costs(const DevModel &m, const DevRows &rows, const Kin<NV> &k
           cross3(k.S[j] + 3, db, tb);
           g[j] = (ona ? dot3(n, ta) : 0.0) - (onb ? dot3(n, tb) : 0.0);
         }
-#pragma unroll
+AGX_UNROLL_NV
         for (int i = 0; i < NV; ++i) {
           c.Lq[i] += wi * ar * g[i];
 #pragma unroll
@@ -898,7 +900,7 @@ AGX_DEV void node_costs(const DevModel &m, const DevRows &rows, const Kin<NV> &k
     }
   }
   if (DIFF) {
-#pragma unroll
+AGX_UNROLL_NV
     for (int i = 0; i < NV; ++i)
 #pragma unroll
       for (int j = i + 1; j < NV; ++j) c.Lqq[i][j] = c.Lqq[j][i];
@@ -927,7 +929,7 @@ AGX_DEV void constraints_eval(const DevModel &m, const DevCons &c, const double 
       g[off] = collision_distance<NV>(m, k, c.frame[r], c.frame_b[r], ca, cb, n, &ja, &jb);
       if (JAC) {
         double *gj = cj[c.coll_slot[r]];
-#pragma unroll
+AGX_UNROLL_NV
         for (int j = 0; j < NV; ++j) {
           const bool ona = (ja >= 0) && (CHAIN ? (j <= ja) : ((m.anc[ja >= 0 ? ja : 0] >> j) & 1u));
           const bool onb = (jb >= 0) && (CHAIN ? (j <= jb) : ((m.anc[jb >= 0 ? jb : 0] >> j) & 1u));
@@ -973,7 +975,7 @@ AGX_DEV void node_calc_running(const DevModel &m, const DevRows &rows, double dt
   double nle[NV], M[NV][NV], Minv[NV][NV];
   bias_and_inertia<NV, CHAIN>(m, k, x + NV, d, nle, M);
   spd_inverse<NV>(M, Minv);
-#pragma unroll
+AGX_UNROLL_NV
   for (int i = 0; i < NV; ++i) {
     double a = 0.0;
 #pragma unroll

@@ -84,7 +84,7 @@ __global__ void __launch_bounds__(64) k_calc_diff(const DevModel *__restrict__ m
   double nle[NV], M[NV][NV], Minv[NV][NV], qdd[NV];
   bias_and_inertia<NV, CHAIN>(m, k, x + NV, d, nle, M);
   spd_inverse<NV>(M, Minv);
-#pragma unroll
+AGX_UNROLL_NV
   for (int i = 0; i < NV; ++i) {
     double a = 0.0;
 #pragma unroll
@@ -94,7 +94,7 @@ __global__ void __launch_bounds__(64) k_calc_diff(const DevModel *__restrict__ m
   // gap f = xnext - xs[t+1]
   {
     const double *xn = xp + NX;
-#pragma unroll
+AGX_UNROLL_NV
     for (int i = 0; i < NV; ++i) {
       tile[TO::f + i] = x[i] + dt * x[NV + i] + dt * dt * qdd[i] - xn[i];
       tile[TO::f + NV + i] = x[NV + i] + dt * qdd[i] - xn[NV + i];
@@ -105,12 +105,12 @@ __global__ void __launch_bounds__(64) k_calc_diff(const DevModel *__restrict__ m
     rnea_derivatives<NV, CHAIN>(m, k, d, x + NV, qdd, dq, dv);
     // da/dq = -Minv dtau/dq ; da/dv = -Minv dtau/dv ; da/du = Minv
     const double dt2 = dt * dt;
-#pragma unroll
+AGX_UNROLL_NV
     for (int i = 0; i < NV; ++i) {
-#pragma unroll
+AGX_UNROLL_NV
       for (int j = 0; j < NV; ++j) {
         double aq = 0.0, av = 0.0;
-#pragma unroll
+AGX_UNROLL_NV
         for (int l = 0; l < NV; ++l) {
           aq -= Minv[i][l] * dq[l][j];
           av -= Minv[i][l] * dv[l][j];
@@ -128,12 +128,12 @@ __global__ void __launch_bounds__(64) k_calc_diff(const DevModel *__restrict__ m
   CostAcc<NV> c;
   node_costs<NV, CHAIN, false, true>(m, o.rows[0], k, x, u, ref_at(rv, b, t, T), frames_at(rv, b, t, T), c);
   tile[TO::cost] = dt * c.cost;
-#pragma unroll
+AGX_UNROLL_NV
   for (int i = 0; i < NV; ++i) {
     tile[TO::Lx + i] = dt * c.Lq[i];
     tile[TO::Lx + NV + i] = dt * c.Lv[i];
     tile[TO::Lu + i] = dt * c.Lu[i];
-#pragma unroll
+AGX_UNROLL_NV
     for (int j = 0; j < NV; ++j) {
       tile[TO::Lxx + i * NX + j] = dt * c.Lqq[i][j];
       tile[TO::Lxx + i * NX + NV + j] = 0.0;
@@ -169,20 +169,20 @@ __global__ void __launch_bounds__(64) k_calc_diff_term(const DevModel *__restric
   CostAcc<NV> c;
   node_costs<NV, CHAIN, true, true>(m, o.rows[1], k, x, nullptr, ref_at(rv, b, T, T), frames_at(rv, b, T, T), c);
   tile[TO::cost] = c.cost;
-#pragma unroll
+AGX_UNROLL_NV
   for (int i = 0; i < NX; ++i) {
-#pragma unroll
+AGX_UNROLL_NV
     for (int j = 0; j < NX; ++j) tile[TO::Fx + i * NX + j] = (i == j) ? 1.0 : 0.0;
     tile[TO::f + i] = 0.0;
   }
 #pragma unroll
   for (int i = 0; i < NX * NU; ++i) { tile[TO::Fu + i] = 0.0; tile[TO::Lxu + i] = 0.0; }
-#pragma unroll
+AGX_UNROLL_NV
   for (int i = 0; i < NV; ++i) {
     tile[TO::Lx + i] = c.Lq[i];
     tile[TO::Lx + NV + i] = c.Lv[i];
     tile[TO::Lu + i] = 0.0;
-#pragma unroll
+AGX_UNROLL_NV
     for (int j = 0; j < NV; ++j) {
       tile[TO::Lxx + i * NX + j] = c.Lqq[i][j];
       tile[TO::Lxx + i * NX + NV + j] = 0.0;
@@ -215,14 +215,14 @@ __global__ void __launch_bounds__(64) k_calc_diff_term(const DevModel *__restric
 // kernel reads element [r][c] of a block at offset 8 r + c = its own lane id (one 512-byte load).
 template <int NV>
 struct QT {
-  static constexpr int NX = 2 * NV, LD = 8, B2 = NV * LD;
-  static constexpr int Hqq = 0, Hqv = B2, Hvv = 2 * B2, Hqw = 3 * B2, Hvw = 4 * B2, Hww = 5 * B2, gx = 6 * B2, gw = gx + 16,
-                       f = gw + 8, cost = f + 16, SIZE = cost + 8;
+  static constexpr int NX = 2 * NV, LD = (NV <= 8 ? 8 : 32), B2 = NV * LD;  // row stride: one (nv <= 8) or four 64-byte lines
+  static constexpr int Hqq = 0, Hqv = B2, Hvv = 2 * B2, Hqw = 3 * B2, Hvw = 4 * B2, Hww = 5 * B2, gx = 6 * B2, gw = gx + 2 * LD,
+                       f = gw + LD, cost = f + 2 * LD, SIZE = cost + 8;
 };
 template <int NV>
 struct AUX {
-  static constexpr int LD = 8, B2 = NV * LD;
-  static constexpr int M = 0, tq = B2, tv = 2 * B2, Lqq = 3 * B2, Lvv = 4 * B2, Luu = Lvv + 8, Lu = Luu + 8, SIZE = Lu + 8;
+  static constexpr int LD = (NV <= 8 ? 8 : 32), B2 = NV * LD;
+  static constexpr int M = 0, tq = B2, tv = 2 * B2, Lqq = 3 * B2, Lvv = 4 * B2, Luu = Lvv + LD, Lu = Luu + LD, SIZE = Lu + LD;
 };
 
 template <int NV, bool CHAIN>
@@ -257,12 +257,12 @@ __global__ void __launch_bounds__(64) k_calc_qp(const DevModel *__restrict__ mp,
   Dyn<NV> d;
   double nle[NV], M[NV][NV], L[NV][NV], Minv[NV][NV], qdd[NV];
   bias_and_inertia<NV, CHAIN>(m, k, x + NV, d, nle, M);
-#pragma unroll
+AGX_UNROLL_NV
   for (int i = 0; i < NV; ++i)
 #pragma unroll
     for (int j = 0; j < NV; ++j) { L[i][j] = M[i][j]; ax[A::M + i * A::LD + j] = M[i][j]; }
   spd_inverse<NV>(L, Minv);
-#pragma unroll
+AGX_UNROLL_NV
   for (int i = 0; i < NV; ++i) {
     double a = 0.0;
 #pragma unroll
@@ -271,7 +271,7 @@ __global__ void __launch_bounds__(64) k_calc_qp(const DevModel *__restrict__ mp,
   }
   {
     const double *xn = xp + NX;
-#pragma unroll
+AGX_UNROLL_NV
     for (int i = 0; i < NV; ++i) {
       qt[Q::f + i] = x[i] + dt * x[NV + i] + dt * dt * qdd[i] - xn[i];
       qt[Q::f + NV + i] = x[NV + i] + dt * qdd[i] - xn[NV + i];
@@ -283,7 +283,7 @@ __global__ void __launch_bounds__(64) k_calc_qp(const DevModel *__restrict__ mp,
   node_costs<NV, CHAIN, false, true>(m, o.rows[0], k, x, u, ref_at(rv, b, t, T), frames_at(rv, b, t, T), c);
   qt[Q::cost] = dt * c.cost;
   double D[NV], lu[NV];
-#pragma unroll
+AGX_UNROLL_NV
   for (int i = 0; i < NV; ++i) {
     D[i] = dt * c.Luu[i] + preg;
     lu[i] = dt * c.Lu[i];
@@ -292,10 +292,10 @@ __global__ void __launch_bounds__(64) k_calc_qp(const DevModel *__restrict__ mp,
     ax[A::Lu + i] = lu[i];
   }
   // DM = D M (row scaling), then the five transformed blocks
-#pragma unroll
+AGX_UNROLL_NV
   for (int i = 0; i < NV; ++i) {
     double gwi = 0.0, gq = dt * c.Lq[i], gv = dt * c.Lv[i];
-#pragma unroll
+AGX_UNROLL_NV
     for (int l = 0; l < NV; ++l) {
       gwi += M[i][l] * lu[l];
       gq += tq[l][i] * lu[l];
@@ -304,10 +304,10 @@ __global__ void __launch_bounds__(64) k_calc_qp(const DevModel *__restrict__ mp,
     qt[Q::gw + i] = gwi;
     qt[Q::gx + i] = gq;
     qt[Q::gx + NV + i] = gv;
-#pragma unroll
+AGX_UNROLL_NV
     for (int j = 0; j < NV; ++j) {
       double hww = 0.0, hqw = 0.0, hvw = 0.0, hqq = dt * c.Lqq[i][j], hqv = 0.0, hvv = (i == j) ? dt * c.Lvv[i] : 0.0;
-#pragma unroll
+AGX_UNROLL_NV
       for (int l = 0; l < NV; ++l) {
         const double dm = D[l] * M[l][j];
         hww += M[i][l] * dm;
@@ -355,7 +355,7 @@ __global__ void __launch_bounds__(64) k_calc_qp_term(const DevModel *__restrict_
   CostAcc<NV> c;
   node_costs<NV, CHAIN, true, true>(m, o.rows[1], k, x, nullptr, ref_at(rv, b, T, T), frames_at(rv, b, T, T), c);
   qt[Q::cost] = c.cost;
-#pragma unroll
+AGX_UNROLL_NV
   for (int i = 0; i < NV; ++i) {
     qt[Q::gx + i] = c.Lq[i];
     qt[Q::gx + NV + i] = c.Lv[i];
@@ -365,7 +365,7 @@ __global__ void __launch_bounds__(64) k_calc_qp_term(const DevModel *__restrict_
     ax[A::Lvv + i] = c.Lvv[i];
     ax[A::Luu + i] = 0.0;
     ax[A::Lu + i] = 0.0;
-#pragma unroll
+AGX_UNROLL_NV
     for (int j = 0; j < NV; ++j) {
       qt[Q::Hqq + i * Q::LD + j] = c.Lqq[i][j];
       qt[Q::Hqv + i * Q::LD + j] = 0.0;
@@ -528,7 +528,7 @@ __device__ __forceinline__ void riccati_body(const int b, const DevOcp *__restri
       const double *sa = s_aux[GAINS ? (t & 1) : 0];
       // sigma [taux M]' [taux M] at [r][c] (and at [c][r] for the transposed blocks), sigma I on Hxx
       double xww = 0.0, xqw = 0.0, xwq = 0.0, xvw = 0.0, xwv = 0.0, xqq = 0.0, xqv = 0.0, xvq = 0.0, xvv = 0.0;
-#pragma unroll
+AGX_UNROLL_NV
       for (int l = 0; l < NV; ++l) {
         const double aMr = sa[A::M + l * A::LD + rr], aMc = sa[A::M + l * A::LD + cc];
         const double aqr = sa[A::tq + l * A::LD + rr], aqc = sa[A::tq + l * A::LD + cc];
@@ -606,7 +606,7 @@ __device__ __forceinline__ void riccati_body(const int b, const DevOcp *__restri
       // u-space gains  K = M Kw - taux : row r of M against column c of Kw
       const double kq = Mwq * rp_row, kv = Mwv * rp_row;
       double Kq = -tq_rc, Kv = -tv_rc;
-#pragma unroll
+AGX_UNROLL_NV
       for (int l = 0; l < NV; ++l) {
         Kq += Mr_[l] * __shfl(kq, 8 * l + col_lane, 64);
         Kv += Mr_[l] * __shfl(kv, 8 * l + col_lane, 64);
@@ -640,7 +640,7 @@ __device__ __forceinline__ void riccati_body(const int b, const DevOcp *__restri
   const int la = lane < NV ? lane : 0;
   struct Gain { double k[NX], kw, fq, fv; };
   auto load_gain = [&](Gain &g, int t) {
-#pragma unroll
+AGX_UNROLL_NV
     for (int j = 0; j < NX; ++j) g.k[j] = Kw[(long long)t * NV * NX + la * NX + j];
     g.kw = kw[(long long)t * NV + la];
     g.fq = qb[(long long)t * TS + Q::f + la];
@@ -649,7 +649,7 @@ __device__ __forceinline__ void riccati_body(const int b, const DevOcp *__restri
   auto fstep = [&](Gain &g, int t) {
     const double h = dts[t], h2 = h * h;
     double w0 = -g.kw, w1 = 0.0;  // two accumulation chains
-#pragma unroll
+AGX_UNROLL_NV
     for (int j = 0; j < NV; ++j) {
       w0 -= g.k[j] * readlane_f64(dq, j);
       w1 -= g.k[NV + j] * readlane_f64(dv, j);
@@ -757,7 +757,7 @@ __global__ void __launch_bounds__(256) k_node_kkt(const DevOcp *__restrict__ op,
   }
   if (t > 0) {
     double pr[8];
-#pragma unroll
+AGX_UNROLL_NV
     for (int i = 0; i < 8; ++i) pr[i] = (i < NV) ? ax[A::Lqq + i * A::LD + l8] * dq : 0.0;
     const double hq = transpose_reduce8(pr, l8);
     if (jl) kkt = fmax(kkt, fmax(fabs(hq + dreg * dq), fabs((ax[A::Lvv + l8] + dreg) * dv)));
@@ -845,15 +845,15 @@ __global__ void __launch_bounds__(128) k_step(const DevModel *__restrict__ mp, c
       const int t = tid + r * blockDim.x;
       if (t > T) break;
       double x[NX], u[NU];
-#pragma unroll
+AGX_UNROLL_NV
       for (int i = 0; i < NX; ++i) x[i] = X[(long long)t * NX + i] + alpha * DX[(long long)t * NX + i];
       if (t < T) {
-#pragma unroll
+AGX_UNROLL_NV
         for (int i = 0; i < NU; ++i) u[i] = U[(long long)t * NU + i] + alpha * DU[(long long)t * NU + i];
         double xn[NX], c;
         node_calc_running<NV, CHAIN>(m, o.rows[0], dts[t], x, u, ref_at(rv, b, t, T), frames_at(rv, b, t, T), xn, &c);
         double g = 0.0;
-#pragma unroll
+AGX_UNROLL_NV
         for (int i = 0; i < NX; ++i)
           g += fabs(xn[i] - (X[(long long)(t + 1) * NX + i] + alpha * DX[(long long)(t + 1) * NX + i]));
         part += c + o.mu_dyn * g;
@@ -883,10 +883,10 @@ __global__ void __launch_bounds__(128) k_step(const DevModel *__restrict__ mp, c
     for (int r = 0; r < NPT; ++r) {
       const int t = tid + r * blockDim.x;
       if (t > T) break;
-#pragma unroll
+AGX_UNROLL_NV
       for (int i = 0; i < NX; ++i) X[(long long)t * NX + i] += used * DX[(long long)t * NX + i];
       if (t < T) {
-#pragma unroll
+AGX_UNROLL_NV
         for (int i = 0; i < NU; ++i) U[(long long)t * NU + i] += used * DU[(long long)t * NU + i];
       }
     }
@@ -1010,14 +1010,14 @@ __global__ void k_shift(const DevModel *__restrict__ mp, const DevOcp *__restric
   if (valid) {
     double *X = xs + (long long)b * (T + 1) * NX, *U = us + (long long)b * T * NU;
     if (dts[i] == dt0) {
-#pragma unroll
+AGX_UNROLL_NV
       for (int e = 0; e < NX; ++e) xo[e] = X[(long long)(i + 1) * NX + e];
       const int iu = (i < T - 1) ? i + 1 : i;
-#pragma unroll
+AGX_UNROLL_NV
       for (int e = 0; e < NU; ++e) uo[e] = U[(long long)iu * NU + e];
     } else {
       double x[NX], u[NU], c;
-#pragma unroll
+AGX_UNROLL_NV
       for (int e = 0; e < NX; ++e) x[e] = X[(long long)i * NX + e];
 #pragma unroll
       for (int e = 0; e < NU; ++e) { u[e] = U[(long long)i * NU + e]; uo[e] = u[e]; }
@@ -1032,9 +1032,9 @@ __global__ void k_shift(const DevModel *__restrict__ mp, const DevOcp *__restric
   if (valid) {
     double *Xo = xs + (long long)o.B * (T + 1) * NX;  // scratch region appended by the host allocator
     double *Uo = us + (long long)o.B * T * NU;
-#pragma unroll
+AGX_UNROLL_NV
     for (int e = 0; e < NX; ++e) Xo[((long long)b * (T + 1) + i) * NX + e] = xo[e];
-#pragma unroll
+AGX_UNROLL_NV
     for (int e = 0; e < NU; ++e) Uo[((long long)b * T + i) * NU + e] = uo[e];
   }
 }
@@ -1055,14 +1055,14 @@ __global__ void k_integrate(const DevModel *__restrict__ mp, double dt, int n, c
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   double xl[NX], ul[NU], xn[NX], c;
-#pragma unroll
+AGX_UNROLL_NV
   for (int e = 0; e < NX; ++e) xl[e] = x[(long long)i * NX + e];
-#pragma unroll
+AGX_UNROLL_NV
   for (int e = 0; e < NU; ++e) ul[e] = u[(long long)i * NU + e];
   DevRows none;
   none.n = 0;
   node_calc_running<NV, CHAIN>(*mp, none, dt, xl, ul, nullptr, nullptr, xn, &c);
-#pragma unroll
+AGX_UNROLL_NV
   for (int e = 0; e < NX; ++e) xnext[(long long)i * NX + e] = xn[e];
 }
 
@@ -1081,18 +1081,18 @@ __global__ void k_feedback_rollout(const DevModel *__restrict__ mp, const double
   double xr[NX], x[NX], u0[NU], K[NU][NX], tau_d[NU];
 #pragma unroll
   for (int e = 0; e < NX; ++e) { xr[e] = x0[(long long)b * NX + e]; x[e] = xr[e]; }
-#pragma unroll
+AGX_UNROLL_NV
   for (int i = 0; i < NU; ++i) {
     u0[i] = us[(long long)b * T * NU + i];
     tau_d[i] = disturbance ? disturbance[(long long)b * NU + i] : 0.0;
-#pragma unroll
+AGX_UNROLL_NV
     for (int e = 0; e < NX; ++e) K[i][e] = Kout[(long long)b * T * NU * NX + i * NX + e];
   }
   DevRows none;
   none.n = 0;
   for (int s = 0; s < n_sub; ++s) {
     double u[NU], xn[NX], c;
-#pragma unroll
+AGX_UNROLL_NV
     for (int i = 0; i < NU; ++i) {
       double acc = u0[i] + tau_d[i];
 #pragma unroll
@@ -1103,7 +1103,7 @@ __global__ void k_feedback_rollout(const DevModel *__restrict__ mp, const double
 #pragma unroll
     for (int e = 0; e < NX; ++e) x[e] = xn[e];
   }
-#pragma unroll
+AGX_UNROLL_NV
   for (int e = 0; e < NX; ++e) x0[(long long)b * NX + e] = x[e];
 }
 
@@ -1113,12 +1113,12 @@ __global__ void k_rnea(const DevModel *__restrict__ mp, int n, const double *__r
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   double ql[NV], vl[NV], al[NV], tl[NV];
-#pragma unroll
+AGX_UNROLL_NV
   for (int e = 0; e < NV; ++e) { ql[e] = q[(long long)i * NV + e]; vl[e] = v[(long long)i * NV + e]; al[e] = a[(long long)i * NV + e]; }
   Kin<NV> k;
   kinematics<NV, CHAIN>(*mp, ql, k);
   rnea<NV, CHAIN>(*mp, k, vl, al, tl);
-#pragma unroll
+AGX_UNROLL_NV
   for (int e = 0; e < NV; ++e) tau[(long long)i * NV + e] = tl[e];
 }
 
@@ -1127,7 +1127,7 @@ __global__ void k_frame(const DevModel *__restrict__ mp, int n, int frame, const
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   double ql[NV];
-#pragma unroll
+AGX_UNROLL_NV
   for (int e = 0; e < NV; ++e) ql[e] = q[(long long)i * NV + e];
   Kin<NV> k;
   kinematics<NV, CHAIN>(*mp, ql, k);
@@ -1230,10 +1230,10 @@ __global__ void k_sine_fill(const DevModel *__restrict__ mp, const DevOcp *__res
   const double t = sp.t0[b] + kk * sp.dt;
   double q[NV], dq[NV], ddq[NV], u[NV];
   if (sp.gq) {
-#pragma unroll
+AGX_UNROLL_NV
     for (int i = 0; i < NV; ++i) { q[i] = sp.gq[unit * NV + i]; dq[i] = sp.gdq[unit * NV + i]; ddq[i] = sp.gddq[unit * NV + i]; }
   } else
-#pragma unroll
+AGX_UNROLL_NV
   for (int i = 0; i < NV; ++i) {
     const double sd = sp.scale[(long long)b * NV + i], w = sp.puls[(long long)b * NV + i], A = sp.amp[(long long)b * NV + i];
     double p5, v5, a5;
@@ -1258,11 +1258,11 @@ __global__ void k_sine_fill(const DevModel *__restrict__ mp, const DevOcp *__res
   int jf;
   frame_world<NV>(m, k, sp.frame, RF, pF, &jf);
   double *pt = pts + unit * (4 * NV + 12);
-#pragma unroll
+AGX_UNROLL_NV
   for (int i = 0; i < NV; ++i) { pt[i] = q[i]; pt[NV + i] = dq[i]; pt[2 * NV + i] = ddq[i]; pt[3 * NV + i] = u[i]; }
-#pragma unroll
+AGX_UNROLL_NV
   for (int e = 0; e < 9; ++e) pt[4 * NV + e] = RF[e];
-#pragma unroll
+AGX_UNROLL_NV
   for (int e = 0; e < 3; ++e) pt[4 * NV + 9 + e] = pF[e];
   for (int layout = 0; layout < 2; ++layout) {
     const DevRows &rows = o.rows[layout];
@@ -1328,3 +1328,4 @@ __global__ void k_ws_from_ref(double *xs, double *us, double *x0, const double *
 
 #include "agx_k1_lanes.hpp"
 #include "agx_admm.hpp"
+#include "agx_big.hpp"
