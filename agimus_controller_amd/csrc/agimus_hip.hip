@@ -53,6 +53,7 @@ struct agx_ocp {
   // constrained problems (agx_admm.hpp): augmented tiles, constraint values / collision Jacobians,
   // multipliers y (persistent across solves), slack z, prox centre, per-node residual norms
   bool has_con = false;
+  double *d_trial = nullptr;  // [B][T+1] merit shares of a line-search trial (large models)
   double *d_qt2 = nullptr, *d_cg = nullptr, *d_cjac = nullptr, *d_y = nullptr, *d_z = nullptr, *d_cx = nullptr, *d_admmstat = nullptr;
   int qt_size = 0, aux_size = 0;
   bool k1_lanes = true;  // AGX_K1_LANES=0 selects the one-lane-per-node derivative kernel
@@ -254,6 +255,7 @@ int launch_riccati(agx_ocp *o, int forward, bool pair = false, int iter = 0, con
 
 int launch_step(agx_ocp *o, int iter, int max_iter, int mode, bool with_node_kkt = true, bool with_step = true) {
   if (o->T + 1 > 512) return fail("step kernel supports horizons up to 511 nodes");
+  if (o->nv > 7 && !o->d_trial) HIPCHK(hipMalloc((void **)&o->d_trial, sizeof(double) * (size_t)o->B * (o->T + 1)));
   return dispatch(o->nv, o->chain, [&](auto NVc, auto CHc) -> int {
     constexpr int NV = decltype(NVc)::value;
     constexpr bool CH = decltype(CHc)::value;
@@ -267,8 +269,25 @@ int launch_step(agx_ocp *o, int iter, int max_iter, int mode, bool with_node_kkt
                            o->d_dx, o->d_w, o->d_du, o->d_nodestat, o->d_state);
     }
     if (!with_step) { HIPCHK(hipGetLastError()); return 0; }
-    hipLaunchKernelGGL((agx::k_step<NV, CH>), dim3(o->B), dim3(128), 0, o->stream, o->d_model, o->d_ocp, o->d_dt, o->d_xs, o->d_us,
-                       o->rv, o->d_qt, o->d_aux, o->d_dx, o->d_nodestat, o->d_du, o->d_state, iter, max_iter, mode, o->d_ndone);
+    if constexpr (NV <= 7) {
+      hipLaunchKernelGGL((agx::k_step<NV, CH>), dim3(o->B), dim3(128), 0, o->stream, o->d_model, o->d_ocp, o->d_dt, o->d_xs, o->d_us,
+                         o->rv, o->d_qt, o->d_aux, o->d_dx, o->d_nodestat, o->d_du, o->d_state, iter, max_iter, mode, o->d_ndone);
+    } else {
+      // large models: convergence test in k_step, line search node parallel
+      const bool split = (mode & 1) && !(mode & 4);
+      hipLaunchKernelGGL((agx::k_step<NV, CH>), dim3(o->B), dim3(128), 0, o->stream, o->d_model, o->d_ocp, o->d_dt, o->d_xs, o->d_us,
+                         o->rv, o->d_qt, o->d_aux, o->d_dx, o->d_nodestat, o->d_du, o->d_state, iter, max_iter, split ? (mode | 8) : mode,
+                         o->d_ndone);
+      if (split) {
+        double alpha = 1.0;
+        for (int n = 0; n < 10; ++n, alpha *= 0.5) {
+          hipLaunchKernelGGL((agx::k_ls_trial<NV, CH>), dim3((int)((nodes + 63) / 64)), dim3(64), 0, o->stream, o->d_model, o->d_ocp, o->d_dt,
+                             o->d_xs, o->d_us, o->rv, o->d_dx, o->d_du, o->d_trial, o->d_state, alpha);
+          hipLaunchKernelGGL((agx::k_ls_accept<NV>), dim3(o->B), dim3(128), 0, o->stream, o->d_ocp, o->d_xs, o->d_us, o->d_dx, o->d_du,
+                             o->d_trial, o->d_state, alpha, n == 9 ? 1 : 0, iter, max_iter, o->d_ndone);
+        }
+      }
+    }
     HIPCHK(hipGetLastError());
     return 0;
   });
@@ -686,7 +705,7 @@ void agx_ocp_destroy(agx_ocp *o) {
   if (o->stream) (void)hipStreamSynchronize(o->stream);
   void *ptrs[] = {o->d_model, o->d_ocp, o->d_dt, o->d_xs, o->d_us, o->d_x0, o->d_tiles, o->d_Kws, o->d_kws, o->d_Kout, o->d_dx,
                   o->d_du, o->d_ref, o->d_frames, o->d_state, o->d_ndone, o->d_scratch, o->d_traj, o->d_pts, o->d_sine, o->d_qt, o->d_aux, o->d_w, o->d_nodestat,
-                  o->d_qt2, o->d_cg, o->d_cjac, o->d_y, o->d_z, o->d_cx, o->d_admmstat, o->d_hidx};
+                  o->d_qt2, o->d_cg, o->d_cjac, o->d_y, o->d_z, o->d_cx, o->d_admmstat, o->d_hidx, o->d_trial};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
   if (o->h_ndone) (void)hipHostFree(o->h_ndone);

@@ -86,18 +86,23 @@ __global__ void __launch_bounds__(256) k_riccati_big(const DevOcp *__restrict__ 
       Mx[(2 * NV + r) * CS + GC] = gains_pass ? 0.0 : tl[Q::gx + NV + r] + h * vpq + vpv;
     }
     __syncthreads();
-    // Gauss-Jordan pivots on the w block; the pivot row itself stays as it is
-    for (int k = 0; k < NV; ++k) {
-      const double rp = 1.0 / Mx[k * CS + k];
-      for (int r = tid; r < R; r += nt) fac[r] = (r == k) ? 0.0 : Mx[r * CS + k] * rp;
-      if (tid == 0) rpv[k] = rp;
-      __syncthreads();
-      const int nc = GC - k;  // columns k+1 .. GC
-      for (int e = tid; e < R * nc; e += nt) {
-        const int r = e / nc, c = k + 1 + e % nc;
-        Mx[r * CS + c] -= fac[r] * Mx[k * CS + c];
+    // Gauss-Jordan pivots on the w block; the pivot row itself stays as it is.  Thread (g, c) owns
+    // column c of the rows r = g, g + NG, ...: the pivot row element stays in a register, the
+    // factors are LDS broadcasts, no index arithmetic in the inner loop.
+    {
+      constexpr int CG = 128, NG = 256 / CG;
+      const int c = tid & (CG - 1), g = tid / CG;
+      for (int k = 0; k < NV; ++k) {
+        const double rp = 1.0 / Mx[k * CS + k];
+        for (int r = tid; r < R; r += nt) fac[r] = (r == k) ? 0.0 : Mx[r * CS + k] * rp;
+        if (tid == 0) rpv[k] = rp;
+        __syncthreads();
+        if (c > k && c <= GC) {
+          const double rk = Mx[k * CS + c];
+          for (int r = g; r < R; r += NG) Mx[r * CS + c] -= fac[r] * rk;
+        }
+        __syncthreads();
       }
-      __syncthreads();
     }
     // gains of this node and the value function of node t
     for (int e = tid; e < NV * NX; e += nt) {
@@ -223,6 +228,105 @@ __global__ void __launch_bounds__(256) k_sigma_tile_big(const DevOcp *__restrict
       q2[Q::Hww + e] = qt[Q::Hww + e] + sig * hww;
       q2[Q::Hqw + e] = qt[Q::Hqw + e] + sig * hqw;
       q2[Q::Hvw + e] = qt[Q::Hvw + e] + sig * hvw;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Line search for large models, split so that the trial evaluation is node parallel (the per-node
+// calc with per-lane scratch arrays is far too slow inside one workgroup per instance):
+//   k_ls_trial(alpha)   one lane per node: merit share of the node at xs + alpha dx, us + alpha du
+//   k_ls_accept(alpha)  one workgroup per instance: merit_try < merit ? commit the step : keep trying
+// run for alpha = 1, 1/2, ... 2^-9; instances that accepted (or finished) drop out.
+// ---------------------------------------------------------------------------
+template <int NV, bool CHAIN>
+__global__ void __launch_bounds__(64) k_ls_trial(const DevModel *__restrict__ mp, const DevOcp *__restrict__ op,
+                                                 const double *__restrict__ dts, const double *__restrict__ xs,
+                                                 const double *__restrict__ us, RefView rv, const double *__restrict__ dxs,
+                                                 const double *__restrict__ dus, double *__restrict__ trial,
+                                                 const DevState *__restrict__ st, double alpha) {
+  constexpr int NX = 2 * NV, NU = NV;
+  const DevModel &m = *mp;
+  const DevOcp &o = *op;
+  const int T = o.T;
+  const long long node = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (node >= (long long)o.B * (T + 1)) return;
+  const int b = (int)(node / (T + 1)), t = (int)(node % (T + 1));
+  const DevState &S = st[b];
+  if (S.done || S.ls_acc) return;
+  double x[NX], u[NU];
+AGX_UNROLL_NV
+  for (int i = 0; i < NX; ++i) x[i] = xs[node * NX + i] + alpha * dxs[node * NX + i];
+  double part;
+  if (t < T) {
+    const long long un = (long long)b * T + t;
+AGX_UNROLL_NV
+    for (int i = 0; i < NU; ++i) u[i] = us[un * NU + i] + alpha * dus[un * NU + i];
+    double xn[NX], c;
+    node_calc_running<NV, CHAIN>(m, o.rows[0], dts[t], x, u, ref_at(rv, b, t, T), frames_at(rv, b, t, T), xn, &c);
+    double g = 0.0;
+AGX_UNROLL_NV
+    for (int i = 0; i < NX; ++i) g += fabs(xn[i] - (xs[(node + 1) * NX + i] + alpha * dxs[(node + 1) * NX + i]));
+    part = c + o.mu_dyn * g;
+  } else {
+    double c;
+    node_calc_terminal<NV, CHAIN>(m, o.rows[1], x, ref_at(rv, b, T, T), frames_at(rv, b, T, T), &c);
+    part = c;
+  }
+  trial[node] = part;
+}
+
+template <int NV>
+__global__ void __launch_bounds__(128) k_ls_accept(const DevOcp *__restrict__ op, double *__restrict__ xs, double *__restrict__ us,
+                                                   const double *__restrict__ dxs, const double *__restrict__ dus,
+                                                   const double *__restrict__ trial, DevState *__restrict__ st, double alpha,
+                                                   int last, int iter, int max_iter, int *__restrict__ n_done) {
+  constexpr int NX = 2 * NV, NU = NV;
+  __shared__ double red[2];
+  __shared__ int flag;
+  const DevOcp &o = *op;
+  const int T = o.T, b = blockIdx.x, tid = threadIdx.x, nw = blockDim.x >> 6;
+  DevState &S = st[b];
+  if (S.done || S.ls_acc) return;
+  double part = 0.0;
+  for (int t = tid; t <= T; t += blockDim.x) part += trial[(long long)b * (T + 1) + t];
+  part = wave_sum(part);
+  if ((tid & 63) == 0) red[tid >> 6] = part;
+  __syncthreads();
+  if (tid == 0) {
+    double tot = 0.0;
+    for (int w = 0; w < nw; ++w) tot += red[w];
+    flag = (S.merit > tot) ? 1 : 0;
+  }
+  __syncthreads();
+  const bool ok = flag != 0;
+  if (!ok && !last) return;
+  if (ok) {
+    double *X = xs + (long long)b * (T + 1) * NX, *U = us + (long long)b * T * NU;
+    const double *DX = dxs + (long long)b * (T + 1) * NX, *DU = dus + (long long)b * T * NU;
+    for (int e = tid; e < (T + 1) * NX; e += blockDim.x) X[e] += alpha * DX[e];
+    for (int e = tid; e < T * NU; e += blockDim.x) U[e] += alpha * DU[e];
+  }
+  if (tid == 0) {
+    // same epilogue as k_step: regularisation schedule on the step length, iteration bookkeeping
+    if (!ok) S.flags |= 2;
+    double pr = S.preg, dr = S.dreg;
+    S.gains_preg = pr; S.gains_dreg = dr;
+    if (alpha > 0.5) { pr = fmax(pr / 10.0, kRegMin); dr = fmax(dr / 10.0, kRegMin); }
+    bool stop = false;
+    if (alpha <= 0.01) {
+      pr = fmin(pr * 10.0, kRegMax);
+      dr = fmin(dr * 10.0, kRegMax);
+      if (pr == kRegMax) stop = true;
+    }
+    S.preg = pr; S.dreg = dr;
+    S.ls_acc = 1;
+    if (stop) {
+      S.done = 1;
+      S.iter = iter + 1;
+      atomicAdd(n_done, 1);
+    } else if (iter + 1 == max_iter) {
+      S.iter = max_iter;
     }
   }
 }

@@ -28,6 +28,7 @@ struct DevState {
   double rho_sparse;             // persists across solves (SolverCSQP reset_rho = false); 0 = not initialised
   double con;                    // l1 norm of the constraint violation at the last evaluation
   int admm_conv, admm_iter;      // QP converged in this SQP iteration / ADMM iterations done
+  int ls_acc, pad_;              // split line search (large models): step accepted in this SQP iteration
 };
 
 // Addressing of the reference tiles (host tile or a window of the resident trajectory).
@@ -777,6 +778,7 @@ AGX_UNROLL_NV
 //   then the merit line search: alpha = 2^-n, accept the first merit_try < merit.
 // mode bit0: run the line search / state update; without it only the prologue runs (test hook).
 // mode bit2: timing mode (no convergence exit, nothing committed) so that launches are repeatable.
+// mode bit3: convergence test only; the line search is done node-parallel by k_ls_trial / k_ls_accept (large models).
 // ---------------------------------------------------------------------------
 template <int NV, bool CHAIN>
 __global__ void __launch_bounds__(128) k_step(const DevModel *__restrict__ mp, const DevOcp *__restrict__ op,
@@ -824,6 +826,7 @@ __global__ void __launch_bounds__(128) k_step(const DevModel *__restrict__ mp, c
     S.kkt = kk; S.cost = cc; S.gap = gg; S.con = vv; S.merit = cc + o.mu_dyn * gg + o.mu_con * vv;
     S.qp_iters = o.has_con ? S.admm_iter : 1;
     S.admm_conv = 0;  // the next SQP iteration's plain LQR pass runs for this instance again
+    S.ls_acc = 0;
     if (!(mode & 4)) S.dir_iter = iter;
     if (!(kk == kk)) S.flags |= 1;
     const bool conv = (kk <= o.tol) && (mode & 1) && !(mode & 4);
@@ -832,7 +835,7 @@ __global__ void __launch_bounds__(128) k_step(const DevModel *__restrict__ mp, c
     red[6] = S.merit;
   }
   __syncthreads();
-  if (flag || !(mode & 1)) return;
+  if (flag || !(mode & 1) || (mode & 8)) return;  // bit3: the line search runs in k_ls_trial / k_ls_accept
   const double merit = red[6];
   __syncthreads();
   // ---- line search
@@ -926,7 +929,7 @@ __global__ void k_reset_state(DevState *st, int B, int *n_done) {
   if (b == 0) *n_done = 0;
   if (b >= B) return;
   DevState s;
-  s.rho_sparse = st[b].rho_sparse; s.con = 0.0; s.admm_conv = 0; s.admm_iter = 0;
+  s.rho_sparse = st[b].rho_sparse; s.con = 0.0; s.admm_conv = 0; s.admm_iter = 0; s.ls_acc = 0; s.pad_ = 0;
   s.kkt = 0.0; s.cost = 0.0; s.merit = 0.0; s.gap = 0.0;
   s.preg = kRegMin; s.dreg = kRegMin;
   s.iter = 0; s.qp_iters = 0; s.solved = 0; s.flags = 0; s.done = 0; s.gains_iter = -1; s.dir_iter = -1;

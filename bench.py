@@ -24,6 +24,8 @@ import time
 
 import numpy as np
 
+os.environ.setdefault("HSA_NO_SCRATCH_RECLAIM", "1")  # large-model kernels use big per-lane scratch (see backend.py)
+
 ROOT = pathlib.Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
@@ -50,12 +52,31 @@ def parse():
     ap.add_argument("--loop", choices=("prediction", "feedback"), default="prediction",
                     help="how the next measured state is produced: previous xs[1] (the reference's dummy_mpc_test) or the Riccati "
                          "feedback law rolled out on the model at 1 kHz (SURVEY 8(f-3))")
-    ap.add_argument("--workload", choices=("sine", "generic"), default="sine",
-                    help="sine: BASELINE configs[1] (the headline); generic: configs[3] generic_trajectory + pick-and-place costs")
+    ap.add_argument("--workload", choices=("sine", "generic", "humanoid"), default="sine",
+                    help="sine: BASELINE configs[1] (the headline); generic: configs[3] generic_trajectory + pick-and-place costs; "
+                         "humanoid: configs[4] synthetic 30-DoF tree (use --horizon 50 --batch 512)")
     return ap.parse_args()
 
 
+def algo_doubles(nv):
+    """SURVEY 8(d) per-node doubles: its nv = 7 figures as stated there, its formulas for other nv
+    (ndx = 2 nv, nu = nv)."""
+    if nv == 7:
+        return dict(ALGO_DOUBLES)
+    ndx, nu = 2 * nv, nv
+    R = 2 * ndx + 2 * nu + 12 + 6 + 1
+    D = 13 * nv * nv + 5 * nv + 1
+    return {"calc_qp": ndx + nu + R + D, "riccati": (D + nu * ndx + nu) + (nu * ndx + nu + ndx * ndx + ndx * nu + ndx + 2 * ndx + nu),
+            "step": 2 * (ndx + nu) + R + ndx + 1}
+
+
 def make_problem(T, workload="sine"):
+    if workload == "humanoid":
+        table = rt.humanoid30_table()
+        tcp = len(table.frame_names) - 1
+        running, terminal = workloads.goal_reaching_rows(tcp)
+        po = _abi.PackedOcp(30, [0.01] * T, running, terminal, termination_tolerance=1e-3, max_qp_iters=100)
+        return table, tcp, po
     table = rt.panda_table(0.1)
     tcp = table.frame_id("panda_hand_tcp")
     running, terminal = workloads.goal_reaching_rows(tcp) if workload == "sine" else workloads.regulation_rows(terminal_weight=0.0)
@@ -171,10 +192,14 @@ def main():
     hip = backend.HipOcp(table, po, B, device=local_rank)
     n_points = args.warmup + max(args.steps, 200) + T + 2 + 10
     # per-instance seeds follow the GLOBAL instance index so every rank works on different instances
-    q0, amp, puls, scale, t0 = workloads.sine_batch_params(B, seed0=1234 + rank * B, lower=table.lower_position_limit,
-                                                           upper=table.upper_position_limit)
+    nv = table.nv
+    q0, amp, puls, scale, t0 = workloads.sine_batch_params(B, nv=nv, seed0=1234 + rank * B, q0=(None if nv == 7 else np.zeros(nv)),
+                                                           lower=table.lower_position_limit, upper=table.upper_position_limit)
     w = workloads.SINE_WEIGHTS
-    if args.workload == "sine":
+    if args.workload == "humanoid":
+        hip.sine_trajectory(n_points, dt, q0, amp, puls, scale, t0, w["w_q"], w["w_qdot"], w["w_effort"], w["w_pose"], tcp)
+        workload_name = "synthetic 30-DoF humanoid tree (seed 7) sine_wave_configuration_space, goal-reaching costs"
+    elif args.workload == "sine":
         hip.sine_trajectory(n_points, dt, q0, amp, puls, scale, t0, w["w_q"], w["w_qdot"], w["w_effort"], w["w_pose"], tcp)
         workload_name = "Panda 7-DoF sine_wave_configuration_space, ocp_goal_reaching.yaml costs"
     else:
@@ -224,6 +249,7 @@ def main():
     kernels = {}
     if rank == 0:
         nodes = {"calc_qp": B * T, "riccati": B * (T + 1), "step": B * (T + 1)}
+        ALGO = algo_doubles(nv)
         hip.profile(True)
         k0 = args.warmup + args.steps
         for k in range(k0, k0 + min(10, T // 2)):
@@ -232,7 +258,7 @@ def main():
         ms_sum, cnt = hip.profile(False)
         for i, name in enumerate(("calc_qp", "riccati", "step")):
             ms = ms_sum[i] / max(cnt[i], 1)
-            algo = ALGO_DOUBLES[name] * 8 * nodes[name]
+            algo = ALGO[name] * 8 * nodes[name]
             kernels[name] = {"ms": ms, "launches": cnt[i], "algorithmic_bytes": algo, "GBps": algo / (ms * 1e-3) / 1e9,
                              "frac_hbm": algo / (ms * 1e-3) / HBM_PEAK}
 
@@ -286,6 +312,9 @@ def main():
             },
             "kernels": kernels,
         }
+        if args.workload == "humanoid":
+            result["metric"] = f"MPC steps/sec (horizon={T}, 30-DoF humanoid)"
+            result["roofline"]["kernel"] = "k_calc_qp<30> (one lane per node, per-lane arrays in scratch: correctness-first path)"
         if world == 1 and not args.no_batch1 and args.workload == "sine":
             # BASELINE.json configs[1]: the same workload at batch = 1 (latency of one controller)
             h1 = backend.HipOcp(table, po, 1, device=local_rank)
@@ -318,7 +347,7 @@ def main():
                 hip.download()
             msf = (time.perf_counter() - t1) / nfull * 1e3
             result["full_download"] = {"ms_per_step": msf, "value": B / (msf * 1e-3), "unit": "MPC steps/s",
-                                       "bytes_per_step": int(8 * B * ((T + 1) * 14 + T * 7 + T * 98)),
+                                       "bytes_per_step": int(8 * B * ((T + 1) * 2 * nv + T * nv + T * 2 * nv * nv)),
                                        "note": "PCIe-inclusive: xs, us, K of all nodes copied to host every step"}
         if not args.no_cpu_baseline and world == 1 and args.workload == "sine":
             try:
