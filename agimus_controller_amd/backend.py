@@ -16,11 +16,11 @@ import numpy as np
 
 from . import _abi
 
-# The large-model kernels (nv > 8) keep per-lane arrays in scratch (tens of KB per lane).  By default
-# the HSA runtime hands such scratch out per dispatch and reclaims it afterwards (tens of ms each
-# time); keeping it allocated makes those dispatches cost what the kernels cost.  Only effective when
-# set before the HIP runtime initialises, hence at import time; C callers export it themselves.
-os.environ.setdefault("HSA_NO_SCRATCH_RECLAIM", "1")
+# Note for large models (nv > 8): their kernels keep per-lane arrays in scratch (tens of KB per lane).
+# By default the HSA runtime hands such scratch out per dispatch and reclaims it afterwards (tens of ms
+# each time); exporting HSA_NO_SCRATCH_RECLAIM=1 before the process touches the GPU keeps it allocated
+# (bench.py --workload humanoid does).  It is NOT set here: mixing small and large models in one
+# process with it made the runtime abort (seen in the test suite).
 
 _CSRC = pathlib.Path(__file__).resolve().parent / "csrc"
 LIB_PATH = pathlib.Path(os.environ.get("AGX_LIB", _CSRC / "libagimus_hip.so"))  # AGX_LIB: development override

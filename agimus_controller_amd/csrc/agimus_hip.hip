@@ -59,6 +59,7 @@ struct agx_ocp {
   bool k1_lanes = true;  // AGX_K1_LANES=0 selects the one-lane-per-node derivative kernel
   bool lanes_ok = true;  // problem fits the LDS staging of the 8-lanes-per-node kernel
   bool speculate = true;  // AGX_SPECULATE_GAINS=0: gains sweep only on exit
+  bool gains_mfma = true; // AGX_GAINS_MFMA=0: scalar K = M Kw - taux for large models
   double *d_ref = nullptr;  // owned tile [B][T+1][stride]
   int *d_frames = nullptr;  // owned [B][T+1][AGX_MAX_ROWS]
   bool frames_set = false;
@@ -309,6 +310,13 @@ int launch_gains(agx_ocp *o, int gmode = 0) {
                          o->d_qt2, o->d_aux);
       hipLaunchKernelGGL((agx::k_riccati_big<NV>), dim3(o->B), dim3(256), 0, o->stream, o->d_ocp, o->d_dt, o->d_qt2, o->d_Kws, o->d_kws,
                          o->d_dx, o->d_w, o->d_state, 0, 1);
+      if constexpr (NV > 16) {
+        if (o->gains_mfma) {  // the dense feedback-gain GEMM on the matrix cores
+          hipLaunchKernelGGL((agx::k_gains_to_u_mfma<NV>), dim3(o->B * o->T), dim3(64), 0, o->stream, o->d_ocp, o->d_aux, o->d_Kws, o->d_Kout);
+          HIPCHK(hipGetLastError());
+          return 0;
+        }
+      }
       const long long units = (long long)o->B * o->T * 64;
       hipLaunchKernelGGL((agx::k_gains_to_u_big<NV>), dim3((int)((units + 255) / 256)), dim3(256), 0, o->stream, o->d_ocp, o->d_aux,
                          o->d_Kws, o->d_Kout);
@@ -598,6 +606,7 @@ int agx_ocp_create(const agx_model *m, const agx_ocp_desc *d, int batch, int dev
   o->chain = m->h.is_chain != 0;
   if (const char *e = getenv("AGX_K1_LANES")) o->k1_lanes = (e[0] != '0');
   if (const char *e = getenv("AGX_SPECULATE_GAINS")) o->speculate = (e[0] != '0');
+  if (const char *e = getenv("AGX_GAINS_MFMA")) o->gains_mfma = (e[0] != '0');
   o->T = d->horizon; o->B = batch; o->device = device;
   o->tile = AGX_TILE_DOUBLES(o->nv);
   const int ld = o->nv <= 8 ? 8 : 32;

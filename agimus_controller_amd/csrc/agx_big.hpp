@@ -355,4 +355,60 @@ __global__ void __launch_bounds__(256) k_gains_to_u_big(const DevOcp *__restrict
   }
 }
 
+// The dense feedback-gain GEMM of the exit path on the matrix cores:  K = M Kw - taux  per node,
+// (nv x nv) (nv x 2nv) with nv = 30 padded to 32 x 64, as 2 x 4 output tiles of
+// v_mfma_f64_16x16x4_f64 (8 k-steps each); one wave per node.  Operand maps (cdna_hip_programming.md,
+// "f64 MFMA"): A[l & 15][k = l >> 4], B[k = l >> 4][l & 15], C/D col = l & 15, row = (l >> 4) + 4 reg.
+typedef double agx_d4 __attribute__((ext_vector_type(4)));
+template <int NV>
+__global__ void __launch_bounds__(64) k_gains_to_u_mfma(const DevOcp *__restrict__ op, const double *__restrict__ auxs,
+                                                        const double *__restrict__ Kws, double *__restrict__ Kout) {
+  static_assert(NV > 16 && NV <= 32, "tiling below assumes 16 < nv <= 32");
+  constexpr int NX = 2 * NV;
+  typedef AUX<NV> A;
+  const DevOcp &o = *op;
+  const int T = o.T, lane = threadIdx.x;
+  const long long node = blockIdx.x;  // b * T + t
+  const int b = (int)(node / T), t = (int)(node % T);
+  const double *ax = auxs + ((long long)b * (T + 1) + t) * A::SIZE;
+  const double *Kw = Kws + node * NV * NX;
+  double *K = Kout + node * NV * NX;
+  const int l15 = lane & 15, l4 = lane >> 4;
+#pragma unroll
+  for (int ti = 0; ti < 2; ++ti) {
+    const int arow = 16 * ti + l15;
+    // this lane's A operands for the 8 k-steps: M[arow][4 ks + l4]
+    double a[8];
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      const int kk = 4 * ks + l4;
+      a[ks] = (arow < NV && kk < NV) ? ax[A::M + arow * A::LD + kk] : 0.0;
+    }
+#pragma unroll
+    for (int tj = 0; tj < 4; ++tj) {
+      const int col = 16 * tj + l15;
+      // C <- -taux tile: taux = [tq | tv], element [row][col]
+      agx_d4 acc;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = 16 * ti + l4 + 4 * r;
+        double v = 0.0;
+        if (row < NV && col < NX) v = -((col < NV) ? ax[A::tq + row * A::LD + col] : ax[A::tv + row * A::LD + (col - NV)]);
+        acc[r] = v;
+      }
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) {
+        const int kk = 4 * ks + l4;
+        const double bv = (kk < NV && col < NX) ? Kw[kk * NX + col] : 0.0;
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ks], bv, acc, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = 16 * ti + l4 + 4 * r;
+        if (row < NV && col < NX) K[row * NX + col] = acc[r];
+      }
+    }
+  }
+}
+
 }  // namespace agx

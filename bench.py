@@ -24,8 +24,6 @@ import time
 
 import numpy as np
 
-os.environ.setdefault("HSA_NO_SCRATCH_RECLAIM", "1")  # large-model kernels use big per-lane scratch (see backend.py)
-
 ROOT = pathlib.Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
@@ -176,6 +174,10 @@ def cpu_baseline(args, table, tcp, po, n_steps=24):
 
 def main():
     args = parse()
+    if args.workload == "humanoid":
+        # large-model kernels use big per-lane scratch: keep it allocated between dispatches (see backend.py);
+        # must be in the environment before the HIP runtime initialises
+        os.environ.setdefault("HSA_NO_SCRATCH_RECLAIM", "1")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))

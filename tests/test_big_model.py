@@ -79,3 +79,21 @@ def test_full_solve_30dof(hip_backend, humanoid):
     assert rel(K_h, K_o) < 1e-6
     np.testing.assert_allclose(st_h["kkt"], st_o["kkt"], rtol=1e-5, atol=1e-12)
     h.close()
+
+
+def test_gains_gemm_on_matrix_cores_equals_scalar_path(hip_backend, humanoid, monkeypatch):
+    """K = M Kw - taux through v_mfma_f64_16x16x4_f64 (default for nv > 16) against the scalar kernel."""
+    frame = len(humanoid.frame_names) - 1
+    B, T = 2, 5
+    po, ref, x0, xs, us = workloads.random_goal_problem(humanoid, T, 0.01, B, seed=21, frame=frame)
+    xs[:, 0] = x0
+    out = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("AGX_GAINS_MFMA", flag)
+        h = hip_backend.HipOcp(humanoid, po, B)
+        h.set_refs(ref)
+        h.upload_warmstart(xs, us)
+        out[flag] = h.direction()[0]
+        h.close()
+    assert np.abs(out["1"]).max() > 1e-3
+    assert rel(out["1"], out["0"]) < 1e-13
