@@ -41,8 +41,7 @@ EXPORTED_SYMBOLS = [
 
 def build(force: bool = False, verbose: bool = False) -> pathlib.Path:
     """Compile the HIP sources for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
-    srcs = [_CSRC / "agimus_hip.hip", _CSRC / "agx_kernels.hpp", _CSRC / "agx_device.hpp",
-            _CSRC.parent.parent / "include" / "agimus_hip.h"]  # fmt: skip
+    srcs = [_CSRC / "agimus_hip.hip"] + sorted(_CSRC.glob("*.hpp")) + [_CSRC.parent.parent / "include" / "agimus_hip.h"]
     if not force and LIB_PATH.exists() and LIB_PATH.stat().st_mtime >= max(s.stat().st_mtime for s in srcs):
         return LIB_PATH
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")

@@ -162,6 +162,8 @@ int fill_cons(const agx_constraint_row *rows, int n, int nv, const DevModel &m, 
 // ---- dispatch over the compiled (NV, CHAIN) instantiations --------------------
 #ifdef AGX_ONLY_NV7  // development builds: one instantiation, short compile
 #define AGX_FOR_NV(MACRO) MACRO(7)
+#elif defined(AGX_ONLY_NV30)
+#define AGX_FOR_NV(MACRO) MACRO(30)
 #else
 #define AGX_FOR_NV(MACRO) MACRO(1) MACRO(2) MACRO(3) MACRO(4) MACRO(6) MACRO(7) MACRO(30)
 #endif
@@ -220,9 +222,12 @@ int launch_calc_qp(agx_ocp *o, bool running_only = false, bool term_only = false
                            o->d_model, o->d_ocp, o->d_dt, o->d_xs, o->d_us, o->rv, o->d_qt, o->d_aux, o->d_state);
     }
     if (!lanes) {
-      if (!term_only)
-      hipLaunchKernelGGL((agx::k_calc_qp<NV, CH>), dim3((int)((units + 63) / 64)), dim3(64), 0, o->stream, o->d_model, o->d_ocp,
-                         o->d_dt, o->d_xs, o->d_us, o->rv, o->d_qt, o->d_aux, o->d_state);
+      if (!term_only) {
+        hipLaunchKernelGGL((agx::k_calc_qp<NV, CH>), dim3((int)((units + 63) / 64)), dim3(64), 0, o->stream, o->d_model, o->d_ocp,
+                           o->d_dt, o->d_xs, o->d_us, o->rv, o->d_qt, o->d_aux, o->d_state);
+        if constexpr (NV > 8)  // second half for large models: the O(nv^3) transformation, one workgroup per node
+          hipLaunchKernelGGL((agx::k_transform_big<NV>), dim3((int)units), dim3(256), 0, o->stream, o->d_ocp, o->d_qt, o->d_aux, o->d_state);
+      }
       if (!running_only)
         hipLaunchKernelGGL((agx::k_calc_qp_term<NV, CH>), dim3((o->B + 63) / 64), dim3(64), 0, o->stream, o->d_model, o->d_ocp,
                            o->d_xs, o->rv, o->d_qt, o->d_aux, o->d_state);

@@ -14,6 +14,55 @@
 
 namespace agx {
 
+// Second half of the derivative pass for large models: the node's QP blocks in acceleration-input
+// form from the aux tile (M, taux, cost Hessians) -- one 256-thread workgroup per running node,
+// M | tq | tv staged in LDS, thread (i, j) forms element [i][j] of the six blocks:
+//   Hww = M D M, Hxw = taux' D M, Hxx = Lxx + taux' D taux, gw = M Lu, gx = Lx + taux' Lu,  D = Luu + preg.
+template <int NV>
+__global__ void __launch_bounds__(256) k_transform_big(const DevOcp *__restrict__ op, double *__restrict__ qts,
+                                                       const double *__restrict__ auxs, const DevState *__restrict__ st) {
+  typedef QT<NV> Q;
+  typedef AUX<NV> A;
+  __shared__ double sM[NV * NV], sq[NV * NV], sv[NV * NV], sD[NV], slu[NV];
+  const DevOcp &o = *op;
+  const int T = o.T, tid = threadIdx.x, nt = blockDim.x;
+  const long long unit = blockIdx.x;  // b * T + t
+  const int b = (int)(unit / T), t = (int)(unit % T);
+  const DevState &S = st[b];
+  if (S.done) return;
+  double *qt = qts + ((long long)b * (T + 1) + t) * Q::SIZE;
+  const double *ax = auxs + ((long long)b * (T + 1) + t) * A::SIZE;
+  for (int e = tid; e < NV * NV; e += nt) {
+    const int i = e / NV, j = e % NV;
+    sM[e] = ax[A::M + i * A::LD + j]; sq[e] = ax[A::tq + i * A::LD + j]; sv[e] = ax[A::tv + i * A::LD + j];
+  }
+  for (int i = tid; i < NV; i += nt) { sD[i] = ax[A::Luu + i] + S.preg; slu[i] = ax[A::Lu + i]; }
+  __syncthreads();
+  for (int e = tid; e < NV * NV; e += nt) {
+    const int i = e / NV, j = e % NV;
+    double hww = 0.0, hqw = 0.0, hvw = 0.0, hqq = ax[A::Lqq + i * A::LD + j], hqv = 0.0, hvv = (i == j) ? ax[A::Lvv + i] : 0.0;
+    for (int l = 0; l < NV; ++l) {
+      const double d = sD[l];
+      const double dm = d * sM[l * NV + j], dtq = d * sq[l * NV + j], dtv = d * sv[l * NV + j];
+      const double Mil = sM[i * NV + l], tqli = sq[l * NV + i], tvli = sv[l * NV + i];
+      hww += Mil * dm; hqw += tqli * dm; hvw += tvli * dm;
+      hqq += tqli * dtq; hqv += tqli * dtv; hvv += tvli * dtv;
+    }
+    const int o2 = i * Q::LD + j;
+    qt[Q::Hww + o2] = hww; qt[Q::Hqw + o2] = hqw; qt[Q::Hvw + o2] = hvw;
+    qt[Q::Hqq + o2] = hqq; qt[Q::Hqv + o2] = hqv; qt[Q::Hvv + o2] = hvv;
+  }
+  for (int i = tid; i < NV; i += nt) {
+    double gw = 0.0, gq = qt[Q::gx + i], gv = qt[Q::gx + NV + i];
+    for (int l = 0; l < NV; ++l) {
+      gw += sM[i * NV + l] * slu[l];
+      gq += sq[l * NV + i] * slu[l];
+      gv += sv[l * NV + i] * slu[l];
+    }
+    qt[Q::gw + i] = gw; qt[Q::gx + i] = gq; qt[Q::gx + NV + i] = gv;
+  }
+}
+
 // K2 for large nv.  gains_pass: backward sweep only, every instance, on the sigma-augmented tiles
 // (k_sigma_tile_big), gradient ignored.
 template <int NV>
@@ -26,7 +75,8 @@ __global__ void __launch_bounds__(256) k_riccati_big(const DevOcp *__restrict__ 
   typedef QT<NV> Q;
   __shared__ double Mx[R * CS];
   __shared__ double V[NX * NX];
-  __shared__ double vx[NX], vp[NX], fl[NX], fac[R], rpv[NV], dxl[NX], wl[NV];
+  __shared__ double vx[NX], vp[NX], fl[NX], rpv[NV], dxl[NX], wl[NV];
+  __shared__ double rowbuf[2][3 * NV + 8], colbuf[2][3 * NV + 8];
   const DevOcp &o = *op;
   const int T = o.T, b = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
   const DevState &S = st[b];
@@ -86,23 +136,64 @@ __global__ void __launch_bounds__(256) k_riccati_big(const DevOcp *__restrict__ 
       Mx[(2 * NV + r) * CS + GC] = gains_pass ? 0.0 : tl[Q::gx + NV + r] + h * vpq + vpv;
     }
     __syncthreads();
-    // Gauss-Jordan pivots on the w block; the pivot row itself stays as it is.  Thread (g, c) owns
-    // column c of the rows r = g, g + NG, ...: the pivot row element stays in a register, the
-    // factors are LDS broadcasts, no index arithmetic in the inner loop.
+    // Gauss-Jordan pivots on the w block, register blocked: thread (br, bc) keeps the RB x CB block
+    // rows RB*br.., columns CB*bc.. of the elimination matrix in registers for all nv pivots; per pivot
+    // the owners of row k / column k publish them through (double-buffered) LDS vectors, everybody
+    // reads RB + CB values and does RB*CB FMAs.  The pivot row itself stays as it is (factor 0).
     {
-      constexpr int CG = 128, NG = 256 / CG;
-      const int c = tid & (CG - 1), g = tid / CG;
+      constexpr int NBC = 16, CB = (GC + NBC) / NBC, NBR = 256 / NBC - 1, RB = (R + NBR - 1) / NBR;
+      static_assert(CB * NBC > GC && RB * NBR >= R, "block grid must cover the elimination matrix");
+      const int br = tid / NBC, bc = tid % NBC;
+      const bool owner = br < NBR;
+      double m[RB][CB];
+#pragma unroll
+      for (int i = 0; i < RB; ++i)
+#pragma unroll
+        for (int j = 0; j < CB; ++j) {
+          const int r = RB * br + i, c = CB * bc + j;
+          m[i][j] = (owner && r < R && c <= GC) ? Mx[r * CS + c] : 0.0;
+        }
       for (int k = 0; k < NV; ++k) {
-        const double rp = 1.0 / Mx[k * CS + k];
-        for (int r = tid; r < R; r += nt) fac[r] = (r == k) ? 0.0 : Mx[r * CS + k] * rp;
-        if (tid == 0) rpv[k] = rp;
-        __syncthreads();
-        if (c > k && c <= GC) {
-          const double rk = Mx[k * CS + c];
-          for (int r = g; r < R; r += NG) Mx[r * CS + c] -= fac[r] * rk;
+        double *rowk = rowbuf[k & 1], *colk = colbuf[k & 1];
+        if (owner && k / RB == br) {
+#pragma unroll
+          for (int i = 0; i < RB; ++i)
+            if (i == k % RB) {
+#pragma unroll
+              for (int j = 0; j < CB; ++j) rowk[CB * bc + j] = m[i][j];
+            }
+        }
+        if (owner && k / CB == bc) {
+#pragma unroll
+          for (int j = 0; j < CB; ++j)
+            if (j == k % CB) {
+#pragma unroll
+              for (int i = 0; i < RB; ++i) colk[RB * br + i] = m[i][j];
+            }
         }
         __syncthreads();
+        const double rp = 1.0 / rowk[k];
+        if (tid == 0) rpv[k] = rp;
+        double fi[RB], rj[CB];
+#pragma unroll
+        for (int i = 0; i < RB; ++i) fi[i] = (RB * br + i == k) ? 0.0 : colk[RB * br + i] * rp;
+#pragma unroll
+        for (int j = 0; j < CB; ++j) rj[j] = rowk[CB * bc + j];
+#pragma unroll
+        for (int i = 0; i < RB; ++i)
+#pragma unroll
+          for (int j = 0; j < CB; ++j) m[i][j] -= fi[i] * rj[j];
       }
+      __syncthreads();
+      // back to LDS: what the rest of the step reads (x columns and the gradient column of every row)
+#pragma unroll
+      for (int i = 0; i < RB; ++i)
+#pragma unroll
+        for (int j = 0; j < CB; ++j) {
+          const int r = RB * br + i, c = CB * bc + j;
+          if (owner && r < R && c >= NV && c <= GC) Mx[r * CS + c] = m[i][j];
+        }
+      __syncthreads();
     }
     // gains of this node and the value function of node t
     for (int e = tid; e < NV * NX; e += nt) {

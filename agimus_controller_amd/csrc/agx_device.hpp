@@ -331,6 +331,33 @@ AGX_UNROLL_NV
 
 // In-place lower Cholesky of a dense NV x NV SPD matrix (registers), then
 // explicit inverse Minv = L^-T L^-1.
+// x = A^-1 b for a symmetric positive definite A (destroyed): Cholesky + two triangular solves.
+// Used by the large-model derivative pass, where forming the inverse (n^3) is not worth it.
+template <int NV>
+AGX_DEV void spd_solve(double (*A)[NV], double *b) {
+  for (int j = 0; j < NV; ++j) {
+    double dd = A[j][j];
+    for (int kk = 0; kk < j; ++kk) dd -= A[j][kk] * A[j][kk];
+    const double l = sqrt(dd), il = 1.0 / l;
+    A[j][j] = l;
+    for (int i = j + 1; i < NV; ++i) {
+      double s = A[i][j];
+      for (int kk = 0; kk < j; ++kk) s -= A[i][kk] * A[j][kk];
+      A[i][j] = s * il;
+    }
+  }
+  for (int i = 0; i < NV; ++i) {
+    double s = b[i];
+    for (int kk = 0; kk < i; ++kk) s -= A[i][kk] * b[kk];
+    b[i] = s / A[i][i];
+  }
+  for (int i = NV - 1; i >= 0; --i) {
+    double s = b[i];
+    for (int kk = i + 1; kk < NV; ++kk) s -= A[kk][i] * b[kk];
+    b[i] = s / A[i][i];
+  }
+}
+
 template <int NV>
 AGX_DEV void spd_inverse(double (*A)[NV], double (*Ainv)[NV]) {
   double Li[NV][NV];  // L^-1 (lower)

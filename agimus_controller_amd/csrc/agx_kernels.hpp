@@ -262,13 +262,18 @@ AGX_UNROLL_NV
   for (int i = 0; i < NV; ++i)
 #pragma unroll
     for (int j = 0; j < NV; ++j) { L[i][j] = M[i][j]; ax[A::M + i * A::LD + j] = M[i][j]; }
-  spd_inverse<NV>(L, Minv);
+  if constexpr (NV > 8) {
+    for (int i = 0; i < NV; ++i) qdd[i] = u[i] - nle[i];
+    spd_solve<NV>(L, qdd);
+  } else {
+    spd_inverse<NV>(L, Minv);
 AGX_UNROLL_NV
-  for (int i = 0; i < NV; ++i) {
-    double a = 0.0;
+    for (int i = 0; i < NV; ++i) {
+      double a = 0.0;
 #pragma unroll
-    for (int j = 0; j < NV; ++j) a += Minv[i][j] * (u[j] - nle[j]);
-    qdd[i] = a;
+      for (int j = 0; j < NV; ++j) a += Minv[i][j] * (u[j] - nle[j]);
+      qdd[i] = a;
+    }
   }
   {
     const double *xn = xp + NX;
@@ -291,6 +296,21 @@ AGX_UNROLL_NV
     ax[A::Lvv + i] = dt * c.Lvv[i];
     ax[A::Luu + i] = dt * c.Luu[i];
     ax[A::Lu + i] = lu[i];
+  }
+  if constexpr (NV > 8) {
+    // large models: the O(nv^3) transformation into acceleration-input form is done cooperatively by
+    // k_transform_big (agx_big.hpp) from the aux tile; here only the raw pieces are written
+    (void)D;
+    for (int i = 0; i < NV; ++i) {
+      qt[Q::gx + i] = dt * c.Lq[i];
+      qt[Q::gx + NV + i] = dt * c.Lv[i];
+      for (int j = 0; j < NV; ++j) {
+        ax[A::tq + i * A::LD + j] = tq[i][j];
+        ax[A::tv + i * A::LD + j] = tv[i][j];
+        ax[A::Lqq + i * A::LD + j] = dt * c.Lqq[i][j];
+      }
+    }
+    return;
   }
   // DM = D M (row scaling), then the five transformed blocks
 AGX_UNROLL_NV
