@@ -60,6 +60,7 @@ struct agx_ocp {
   bool lanes_ok = true;  // problem fits the LDS staging of the 8-lanes-per-node kernel
   bool speculate = true;  // AGX_SPECULATE_GAINS=0: gains sweep only on exit
   bool gains_mfma = true; // AGX_GAINS_MFMA=0: scalar K = M Kw - taux for large models
+  bool queue_ahead = true;  // AGX_QUEUE_AHEAD=0: next derivative pass only after the host saw the finished count (profiling: no empty launches)
   double *d_ref = nullptr;  // owned tile [B][T+1][stride]
   int *d_frames = nullptr;  // owned [B][T+1][AGX_MAX_ROWS]
   bool frames_set = false;
@@ -451,7 +452,7 @@ int solve_resident(agx_ocp *o, int max_iter, double max_time) {
   // The derivative pass of iteration it+1 is enqueued BEFORE the host waits for iteration it's
   // "everyone finished" word: it skips finished instances, so when the loop ends it was an empty
   // launch, and when it does not the GPU never idles over the host round trip.
-  const bool ahead = !o->prof && max_time <= 0.0;
+  const bool ahead = o->queue_ahead && !o->prof && max_time <= 0.0;
   bool k1_queued = false;
   for (int it = 0; it < max_iter; ++it) {
     if (!k1_queued) {
@@ -612,6 +613,7 @@ int agx_ocp_create(const agx_model *m, const agx_ocp_desc *d, int batch, int dev
   if (const char *e = getenv("AGX_K1_LANES")) o->k1_lanes = (e[0] != '0');
   if (const char *e = getenv("AGX_SPECULATE_GAINS")) o->speculate = (e[0] != '0');
   if (const char *e = getenv("AGX_GAINS_MFMA")) o->gains_mfma = (e[0] != '0');
+  if (const char *e = getenv("AGX_QUEUE_AHEAD")) o->queue_ahead = (e[0] != '0');
   o->T = d->horizon; o->B = batch; o->device = device;
   o->tile = AGX_TILE_DOUBLES(o->nv);
   const int ld = o->nv <= 8 ? 8 : 32;

@@ -17,11 +17,6 @@
 
 namespace agx {
 
-#ifdef AGX_K1_NOSTORE  // experiment: fold every tile store into one checksum store per lane
-#define K1ST(ptr, val) chk += (val)
-#else
-#define K1ST(ptr, val) (ptr) = (val)
-#endif
 
 // Shifts inside the 8-lane group as DPP row shifts (VALU, no LDS traffic): a row is 16 lanes = two
 // groups; values that cross from one group into the next land only in lanes the callers mask out
@@ -142,8 +137,6 @@ __global__ void __launch_bounds__(64, AGX_K1_WAVES) k_calc_qp_lj(const DevModel 
   double *ax = auxs + ((long long)b * (T + 1) + t) * A::SIZE;
   const DevRows &rows = o.rows[TERM ? 1 : 0];
   const bool wr = act && jl;  // this lane stores
-  double chk = 0.0;
-  (void)chk;
 
   // ---- prologue: every global read of the kernel is issued here, back to back, and parked in LDS
   // (one memory round trip instead of one per use; nothing is loaded after the first store)
@@ -374,9 +367,6 @@ __global__ void __launch_bounds__(64, AGX_K1_WAVES) k_calc_qp_lj(const DevModel 
   g_suffix_sum<10>(Ic, l8);
   double m6[6];
   iapply(Ic, S, m6);
-#if defined(AGX_K1_STAGE) && AGX_K1_STAGE == 1
-  { if (wr) qt[l8] = m6[0] + m6[5] + R[0] + p[1]; return; }
-#endif
 
   // ---- TERM nodes carry costs only; running nodes: dynamics
   double v6[6], Sd[6], h6[6], tqc[NV], tvc[NV], Mc[NV], qdd = 0.0, gapq = 0.0, gapv = 0.0;
@@ -464,9 +454,6 @@ __global__ void __launch_bounds__(64, AGX_K1_WAVES) k_calc_qp_lj(const DevModel 
     // gap f = xnext - xs[t+1]  (stored at the end: no load may queue behind a store)
     gapq = qj + dt * vj + dt * dt * qdd - xnq;
     gapv = vj + dt * qdd - xnv;
-#if defined(AGX_K1_STAGE) && AGX_K1_STAGE == 2
-    { if (wr) qt[l8] = gapq + gapv + Mc[0] + Mc[NV - 1]; return; }
-#endif
     // ---- pass B: accelerations with qdd, psi, composite force / momentum / E
     double a6[6];
 #pragma unroll
@@ -559,19 +546,13 @@ __global__ void __launch_bounds__(64, AGX_K1_WAVES) k_calc_qp_lj(const DevModel 
       L.u.d2.tq[i][l8] = tqc[i];
       L.u.d2.tv[i][l8] = tvc[i];
     }
-#if defined(AGX_K1_STAGE) && AGX_K1_STAGE == 3
-  { if (wr) qt[l8] = tqc[0] + tvc[NV - 1] + tqc[NV - 1] + tvc[0] + gapq; return; }
-#endif
   } else {
     wave_lds_sync();
   }
 
   const double sc = TERM ? 1.0 : dt;
-#if defined(AGX_K1_STAGE) && AGX_K1_STAGE == 4
-  { if (wr) qt[l8] = cost + Lq + Lv + Lu + Lqqc[0] + Lqqc[NV - 1] + tqc[0] + tvc[1] + Mc[2] + gapq; return; }
-#endif
   cost = g_sum(cost) * sc;
-  if (act && l8 == 0) K1ST(qt[Q::cost], cost);
+  if (act && l8 == 0) qt[Q::cost] = cost;
   // ---- QP transformation, column l8 of every block
   const double lu = sc * Lu, D = sc * Luu + preg;
   L.vec[1][l8] = jl ? lu : 0.0;
@@ -591,13 +572,9 @@ __global__ void __launch_bounds__(64, AGX_K1_WAVES) k_calc_qp_lj(const DevModel 
   }
   // all 8 lanes store (lanes >= NV write the zero padding): every block row is one whole 64-byte line
   auto store_block = [&](double *blk, const double *col) {
-#ifdef AGX_K1_NOSTORE
-    for (int i = 0; i < NV; ++i) chk += col[i];
-#else
 #pragma unroll
     for (int i = 0; i + 1 < NV; i += 2) store_row_pair(blk, i, l8, jl ? col[i] : 0.0, jl ? col[i + 1] : 0.0);
     if (NV & 1) blk[(NV - 1) * 8 + l8] = jl ? col[NV - 1] : 0.0;
-#endif
   };
   if (act) {
     store_block(ax + A::M, Mc);
@@ -605,14 +582,14 @@ __global__ void __launch_bounds__(64, AGX_K1_WAVES) k_calc_qp_lj(const DevModel 
     store_block(ax + A::tv, tvc);
   }
   if (wr) {
-    K1ST(qt[Q::f + l8], gapq);
-    K1ST(qt[Q::f + NV + l8], gapv);
-    K1ST(qt[Q::gw + l8], TERM ? 0.0 : gw);
-    K1ST(qt[Q::gx + l8], gq);
-    K1ST(qt[Q::gx + NV + l8], gv);
-    K1ST(ax[A::Lvv + l8], sc * Lvv);
-    K1ST(ax[A::Luu + l8], sc * Luu);
-    K1ST(ax[A::Lu + l8], lu);
+    qt[Q::f + l8] = gapq;
+    qt[Q::f + NV + l8] = gapv;
+    qt[Q::gw + l8] = TERM ? 0.0 : gw;
+    qt[Q::gx + l8] = gq;
+    qt[Q::gx + NV + l8] = gv;
+    ax[A::Lvv + l8] = sc * Lvv;
+    ax[A::Luu + l8] = sc * Luu;
+    ax[A::Lu + l8] = lu;
   }
   double cww[NV], cqw[NV], cvw[NV], cqq[NV], cqv[NV], cvv[NV], clq[NV];
 #pragma unroll
@@ -641,9 +618,6 @@ __global__ void __launch_bounds__(64, AGX_K1_WAVES) k_calc_qp_lj(const DevModel 
     store_block(qt + Q::Hvv, cvv);
     store_block(ax + A::Lqq, clq);
   }
-#ifdef AGX_K1_NOSTORE
-  if (wr) qt[l8] = chk;
-#endif
 }
 
 }  // namespace agx

@@ -50,9 +50,10 @@ def parse():
     ap.add_argument("--loop", choices=("prediction", "feedback"), default="prediction",
                     help="how the next measured state is produced: previous xs[1] (the reference's dummy_mpc_test) or the Riccati "
                          "feedback law rolled out on the model at 1 kHz (SURVEY 8(f-3))")
-    ap.add_argument("--workload", choices=("sine", "generic", "humanoid"), default="sine",
+    ap.add_argument("--workload", choices=("sine", "generic", "humanoid", "collision"), default="sine",
                     help="sine: BASELINE configs[1] (the headline); generic: configs[3] generic_trajectory + pick-and-place costs; "
-                         "humanoid: configs[4] synthetic 30-DoF tree (use --horizon 50 --batch 512)")
+                         "humanoid: configs[4] synthetic 30-DoF tree (use --horizon 50 --batch 512); "
+                         "collision: configs[2] shape, collision-avoidance cost + distance constraint (use --horizon 200 --batch 256)")
     return ap.parse_args()
 
 
@@ -74,6 +75,17 @@ def make_problem(T, workload="sine"):
         tcp = len(table.frame_names) - 1
         running, terminal = workloads.goal_reaching_rows(tcp)
         po = _abi.PackedOcp(30, [0.01] * T, running, terminal, termination_tolerance=1e-3, max_qp_iters=100)
+        return table, tcp, po
+    if workload == "collision":
+        # ocp_traj_tracking_collision_avoidance.yaml: QuadExp(alpha 1e-4) cost + distance >= 1 cm on one pair; the sphere
+        # obstacle sits where the link-7 capsule of part of the batch comes close (the reference's test obstacle at
+        # x = 1.535 m is out of the arm's reach and would never be active)
+        table = rt.panda_collision_table(0.1, obstacle_xyz=(0.27, 0.22, 0.70), obstacle_radius=0.06, obstacle_length=0.0)
+        tcp = table.frame_id("panda_hand_tcp")
+        running, terminal = workloads.collision_avoidance_rows(table, tcp, alpha=1e-4)
+        fa, fb = table.frame_id("panda_link7_capsule_0"), table.frame_id("obstacle")
+        con = [_abi.ConstraintSpec(_abi.RES_COLLISION, lower=0.01, upper=np.inf, frame=fa, frame_b=fb, name="collision")]
+        po = _abi.PackedOcp(7, [0.01] * T, running, terminal, termination_tolerance=1e-3, max_qp_iters=100, running_constraints=con)
         return table, tcp, po
     table = rt.panda_table(0.1)
     tcp = table.frame_id("panda_hand_tcp")
@@ -201,6 +213,10 @@ def main():
     if args.workload == "humanoid":
         hip.sine_trajectory(n_points, dt, q0, amp, puls, scale, t0, w["w_q"], w["w_qdot"], w["w_effort"], w["w_pose"], tcp)
         workload_name = "synthetic 30-DoF humanoid tree (seed 7) sine_wave_configuration_space, goal-reaching costs"
+    elif args.workload == "collision":
+        hip.sine_trajectory(n_points, dt, q0, amp, puls, scale, t0, w["w_q"], w["w_qdot"], w["w_effort"], w["w_pose"], tcp)
+        workload_name = ("Panda 7-DoF sine_wave_configuration_space, collision-avoidance costs + distance >= 1 cm constraint "
+                         "(ocp_traj_tracking_collision_avoidance.yaml; ADMM, max_qp_iters 100)")
     elif args.workload == "sine":
         hip.sine_trajectory(n_points, dt, q0, amp, puls, scale, t0, w["w_q"], w["w_qdot"], w["w_effort"], w["w_pose"], tcp)
         workload_name = "Panda 7-DoF sine_wave_configuration_space, ocp_goal_reaching.yaml costs"
@@ -314,6 +330,9 @@ def main():
             },
             "kernels": kernels,
         }
+        if args.workload == "collision":
+            result["metric"] = f"MPC steps/sec (horizon={T}, Panda 7-DoF, collision avoidance)"
+            result["roofline"]["kernel"] = "k_calc_qp<7> (one lane per node: problems with a collision cost row do not use the 8-lane kernel yet)"
         if args.workload == "humanoid":
             result["metric"] = f"MPC steps/sec (horizon={T}, 30-DoF humanoid)"
             result["roofline"]["kernel"] = "k_calc_qp<30> (one lane per node, per-lane arrays in scratch: correctness-first path)"
