@@ -105,22 +105,21 @@ struct LjModel {
 #define AGX_K1_WAVES 2
 #endif
 template <int NV, bool TERM>
-__global__ void __launch_bounds__(64, AGX_K1_WAVES) k_calc_qp_lj(const DevModel *__restrict__ mp, const DevOcp *__restrict__ op,
-                                                    const double *__restrict__ dts, const double *__restrict__ xs,
-                                                    const double *__restrict__ us, RefView rv, double *__restrict__ qts,
-                                                    double *__restrict__ auxs, const DevState *__restrict__ st) {
+__device__ __forceinline__ void calc_qp_lj_body(const long long blk, LjNode *lds, LjModel &lmod, const DevModel *__restrict__ mp,
+                                                const DevOcp *__restrict__ op, const double *__restrict__ dts,
+                                                const double *__restrict__ xs, const double *__restrict__ us, const RefView &rv,
+                                                double *__restrict__ qts, double *__restrict__ auxs,
+                                                const DevState *__restrict__ st) {
   constexpr int NX = 2 * NV;
   typedef QT<NV> Q;
   typedef AUX<NV> A;
-  __shared__ LjNode lds[8];  // one wave per workgroup: 8 nodes
-  __shared__ LjModel lmod;
   const DevModel &m = *mp;
   const DevOcp &o = *op;
   const int T = o.T;
   const int l8 = threadIdx.x & 7;
   LjNode &L = lds[threadIdx.x >> 3];
   const long long n_nodes = TERM ? (long long)o.B : (long long)o.B * T;
-  const long long node = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 3;
+  const long long node = (blk * blockDim.x + threadIdx.x) >> 3;
   const bool node_ok = node < n_nodes;
   const long long nid = node_ok ? node : 0;  // out-of-range groups shadow node 0 and store nothing
   const int b = TERM ? (int)nid : (int)(nid / T), t = TERM ? T : (int)(nid % T);
@@ -618,6 +617,33 @@ __global__ void __launch_bounds__(64, AGX_K1_WAVES) k_calc_qp_lj(const DevModel 
     store_block(qt + Q::Hvv, cvv);
     store_block(ax + A::Lqq, clq);
   }
+}
+
+// Separate launches (timing, terminal-only / running-only callers)
+template <int NV, bool TERM>
+__global__ void __launch_bounds__(64, AGX_K1_WAVES) k_calc_qp_lj(const DevModel *__restrict__ mp, const DevOcp *__restrict__ op,
+                                                    const double *__restrict__ dts, const double *__restrict__ xs,
+                                                    const double *__restrict__ us, RefView rv, double *__restrict__ qts,
+                                                    double *__restrict__ auxs, const DevState *__restrict__ st) {
+  __shared__ LjNode lds[8];  // one wave per workgroup: 8 nodes
+  __shared__ LjModel lmod;
+  calc_qp_lj_body<NV, TERM>(blockIdx.x, lds, lmod, mp, op, dts, xs, us, rv, qts, auxs, st);
+}
+
+// The derivative pass of one SQP iteration in ONE launch: the first n_run workgroups take the running
+// nodes, the rest the terminal nodes (wave-uniform branch, shared LDS declarations): the short
+// terminal launch and its dispatch gap disappear behind the tail of the running nodes.
+template <int NV>
+__global__ void __launch_bounds__(64, AGX_K1_WAVES) k_calc_qp_lj_all(const DevModel *__restrict__ mp, const DevOcp *__restrict__ op,
+                                                        const double *__restrict__ dts, const double *__restrict__ xs,
+                                                        const double *__restrict__ us, RefView rv, double *__restrict__ qts,
+                                                        double *__restrict__ auxs, const DevState *__restrict__ st, int n_run) {
+  __shared__ LjNode lds[8];
+  __shared__ LjModel lmod;
+  if ((int)blockIdx.x < n_run)
+    calc_qp_lj_body<NV, false>(blockIdx.x, lds, lmod, mp, op, dts, xs, us, rv, qts, auxs, st);
+  else
+    calc_qp_lj_body<NV, true>((long long)blockIdx.x - n_run, lds, lmod, mp, op, dts, xs, us, rv, qts, auxs, st);
 }
 
 }  // namespace agx
