@@ -31,7 +31,7 @@ EXPORTED_SYMBOLS = [
     "agx_last_error", "agx_device_count", "agx_row_nref", "agx_row_nr", "agx_ref_stride",
     "agx_model_create", "agx_model_destroy", "agx_ocp_create", "agx_ocp_destroy", "agx_ocp_set_stream",
     "agx_ocp_sync", "agx_ocp_set_refs", "agx_ocp_set_refs_device", "agx_ocp_solve", "agx_ocp_upload_x0",
-    "agx_ocp_upload_warmstart", "agx_ocp_solve_resident", "agx_ocp_download", "agx_ocp_download_first", "agx_ocp_first_packed", "agx_ocp_set_geom_placement", "agx_ocp_reset_duals", "agx_traj_generic_create", "agx_traj_set_horizon_indexes", "agx_ocp_feedback_rollout", "agx_ocp_download_x0",
+    "agx_ocp_upload_warmstart", "agx_ocp_solve_resident", "agx_ocp_download", "agx_ocp_download_first", "agx_ocp_first_packed", "agx_ocp_set_geom_placement", "agx_ocp_reset_duals", "agx_traj_generic_create", "agx_traj_set_horizon_indexes", "agx_ocp_feedback_rollout", "agx_ocp_download_x0", "agx_model_frame_jacobian",
     "agx_ocp_shift_warmstart", "agx_ocp_x0_from_prediction", "agx_ocp_integrate", "agx_model_rnea",
     "agx_model_frame_placement", "agx_ocp_get_residuals", "agx_ocp_calc_diff", "agx_ocp_direction",
     "agx_ocp_time_kernel", "agx_ocp_profile", "agx_traj_sine_create", "agx_traj_set_window",
@@ -240,6 +240,13 @@ class HipOcp:
         out = np.empty((q.shape[0], 12))
         _chk(lib().agx_model_frame_placement(self._h, q.shape[0], int(frame), _p(q), _p(out)))
         return out
+
+    def frame_jacobian(self, frame: int, q, local: bool = False):
+        """pinocchio.getFrameJacobian: [n, 6, nv], rows linear | angular; LOCAL_WORLD_ALIGNED or LOCAL."""
+        q = _f8(q).reshape(-1, self.nv)
+        J = np.empty((q.shape[0], 6, self.nv))
+        _chk(lib().agx_model_frame_jacobian(self._h, q.shape[0], int(frame), 1 if local else 0, _p(q), _p(J)))
+        return J
 
     def residuals(self, row: int):
         nr = _abi.row_nr(self.po.running[row].kind, self.nv)

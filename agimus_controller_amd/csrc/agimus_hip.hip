@@ -1017,6 +1017,27 @@ int agx_model_frame_placement(agx_ocp *o, int n, int frame, const double *q, dou
   return 0;
 }
 
+int agx_model_frame_jacobian(agx_ocp *o, int n, int frame, int local, const double *q, double *J) {
+  if (!o || !q || !J || n < 1) return fail("agx_model_frame_jacobian: bad argument");
+  if (frame < 0 || frame >= o->hm.nframes) return fail("agx_model_frame_jacobian: frame id out of range");
+  if (set_device(o)) return -1;
+  const size_t cnt = (size_t)n * o->nv;
+  if (ensure_scratch(o, sizeof(double) * (cnt + 6 * cnt))) return -1;
+  double *dq = o->d_scratch, *dout = dq + cnt;
+  HIPCHK(hipMemcpyAsync(dq, q, sizeof(double) * cnt, hipMemcpyHostToDevice, o->stream));
+  int rc = dispatch(o->nv, o->chain, [&](auto NVc, auto CHc) -> int {
+    constexpr int NV = decltype(NVc)::value;
+    constexpr bool CH = decltype(CHc)::value;
+    hipLaunchKernelGGL((agx::k_frame_jacobian<NV, CH>), dim3((n + 63) / 64), dim3(64), 0, o->stream, o->d_model, n, frame, local, dq, dout);
+    HIPCHK(hipGetLastError());
+    return 0;
+  });
+  if (rc) return rc;
+  HIPCHK(hipMemcpyAsync(J, dout, sizeof(double) * 6 * cnt, hipMemcpyDeviceToHost, o->stream));
+  HIPCHK(hipStreamSynchronize(o->stream));
+  return 0;
+}
+
 int agx_ocp_get_residuals(agx_ocp *o, int row, double *out) {
   if (!o || !out) return fail("agx_ocp_get_residuals: null argument");
   if (row < 0 || row >= o->ho.rows[0].n) return fail("agx_ocp_get_residuals: row out of range");

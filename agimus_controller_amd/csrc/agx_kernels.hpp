@@ -1163,6 +1163,44 @@ AGX_UNROLL_NV
   for (int e = 0; e < 3; ++e) out[(long long)i * 12 + 9 + e] = p[e];
 }
 
+// Frame Jacobian 6 x nv (pinocchio getFrameJacobian): rows linear | angular, LOCAL_WORLD_ALIGNED
+// (local = 0: axes of the world, origin at the frame) or LOCAL (local = 1: the frame's own axes).
+template <int NV, bool CHAIN>
+__global__ void k_frame_jacobian(const DevModel *__restrict__ mp, int n, int frame, int local, const double *__restrict__ q,
+                                 double *__restrict__ out) {
+  const DevModel &m = *mp;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double ql[NV];
+AGX_UNROLL_NV
+  for (int e = 0; e < NV; ++e) ql[e] = q[(long long)i * NV + e];
+  Kin<NV> k;
+  kinematics<NV, CHAIN>(m, ql, k);
+  double R[9], p[3];
+  int jf;
+  frame_world<NV>(m, k, frame, R, p, &jf);
+  double *J = out + (long long)i * 6 * NV;
+AGX_UNROLL_NV
+  for (int j = 0; j < NV; ++j) {
+    const bool on = (jf >= 0) && (CHAIN ? (j <= jf) : ((m.anc[jf >= 0 ? jf : 0] >> j) & 1u));
+    double d[3], lin[3], ang[3] = {k.S[j][3], k.S[j][4], k.S[j][5]};
+    d[0] = p[0] - k.p[j][0]; d[1] = p[1] - k.p[j][1]; d[2] = p[2] - k.p[j][2];
+    cross3(ang, d, lin);
+    if (local) {
+      double l2[3], a2[3];
+      mtv3(R, lin, l2);
+      mtv3(R, ang, a2);
+      lin[0] = l2[0]; lin[1] = l2[1]; lin[2] = l2[2];
+      ang[0] = a2[0]; ang[1] = a2[1]; ang[2] = a2[2];
+    }
+#pragma unroll
+    for (int e = 0; e < 3; ++e) {
+      J[e * NV + j] = on ? lin[e] : 0.0;
+      J[(3 + e) * NV + j] = on ? ang[e] : 0.0;
+    }
+  }
+}
+
 // residual vector of one running row at the resident solution (debug data,
 // ocp_croco_generic.py:840-853): out [B][T][nr]
 template <int NV, bool CHAIN>

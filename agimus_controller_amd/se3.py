@@ -67,6 +67,10 @@ class SE3:
             return SE3(self.rotation @ np.asarray(other.rotation), self.rotation @ np.asarray(other.translation) + self.translation)
         return self.rotation @ np.asarray(other, dtype=float) + self.translation
 
+    def actInv(self, other):
+        """self^-1 * other (pinocchio SE3.actInv on an SE3)."""
+        return self.inverse() * other
+
     def act(self, other):
         return self * other
 
@@ -113,6 +117,37 @@ class Motion(_Spatial6):
 
 class Force(_Spatial6):
     pass
+
+
+def log3(R) -> np.ndarray:
+    """pinocchio.log3 (axis-angle vector of a rotation), with its branch near theta = pi."""
+    R = np.asarray(R, dtype=float).reshape(3, 3)
+    ct = 0.5 * (min(3.0, max(-1.0, float(np.trace(R)))) - 1.0)
+    theta = np.arccos(ct)
+    if theta >= np.pi - 1e-2:
+        cphi = -ct
+        beta = theta * theta / (1.0 + cphi)
+        v = (np.diag(R) + cphi) * beta
+        sgn = np.array([1.0 if R[2, 1] > R[1, 2] else -1.0, 1.0 if R[0, 2] > R[2, 0] else -1.0, 1.0 if R[1, 0] > R[0, 1] else -1.0])
+        return sgn * np.sqrt(np.maximum(v, 0.0))
+    t = 0.5 * (theta / np.sin(theta) if theta > 1e-8 else 1.0)
+    return t * np.array([R[2, 1] - R[1, 2], R[0, 2] - R[2, 0], R[1, 0] - R[0, 1]])
+
+
+def log6(M: "SE3") -> "Motion":
+    """pinocchio.log6: Motion (linear, angular) with exp6(log6(M)) = M."""
+    w = log3(M.rotation)
+    p = np.asarray(M.translation, dtype=float)
+    t2 = float(w @ w)
+    t = np.sqrt(t2)
+    if t2 < 1e-12:
+        alpha, beta = 1.0 - t2 / 12.0, 1.0 / 12.0 + t2 / 720.0
+    else:
+        st, ct = np.sin(t), np.cos(t)
+        i22 = 1.0 / (2.0 * (1.0 - ct))
+        alpha, beta = t * st * i22, 1.0 / t2 - st / t * i22
+    v = alpha * p - 0.5 * np.cross(w, p) + beta * float(w @ p) * w
+    return Motion(np.concatenate([v, w]))
 
 
 def XYZQUATToSE3(v) -> SE3:

@@ -230,6 +230,9 @@ int agx_model_rnea(agx_ocp *ocp, int n, const double *q, const double *v, const 
 /* Frame placement (pin.framesForwardKinematics,
  * trajectories/trajectory_base.py:38-41): out [n][12].                         */
 int agx_model_frame_placement(agx_ocp *ocp, int n, int frame, const double *q, double *out);
+/* pinocchio.getFrameJacobian: J [n][6][nv], rows linear | angular; local = 0 LOCAL_WORLD_ALIGNED,
+ * 1 LOCAL (the inverse kinematics of trajectories/sine_wave_cartesian_space.py:62-111 uses both). */
+int agx_model_frame_jacobian(agx_ocp *ocp, int n, int frame, int local, const double *q, double *J);
 
 /* Replaces the per-node residual copies of OCPCrocoGeneric.fill_debug_data
  * (ocp_croco_generic.py:840-853): residual of running row `row` at the resident
