@@ -292,3 +292,57 @@ def test_feedback_rollout_is_the_riccati_feedback_law_on_the_model(hip_backend):
     hb.feedback_rollout(1, 0.01, None)
     assert np.abs(hb.download_x0() - xs_s[:, 1]).max() < 2e-3
     hb.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("T,B", [(1, 1), (2, 3), (511, 2)])
+def test_extreme_horizons(hip_backend, panda, T, B):
+    """Shortest horizon (one control), tiny batches, and the longest horizon the step kernel takes
+    (T + 1 = 512 nodes); T + 1 > 512 is refused with a message."""
+    tcp = panda.frame_id("panda_hand_tcp")
+    po, ref, x0, xs, us = workloads.random_goal_problem(panda, T, 0.01, B, seed=31, frame=tcp)
+    h, o = hip_backend.HipOcp(panda, po, B), Oracle(panda, po, B)
+    h.set_refs(ref)
+    iters = 4 if T > 100 else 10
+    xs_h, us_h, K_h, st_h = h.solve(x0, xs, us, iters)
+    xs_o, us_o, K_o, st_o = o.solve(ref, None, x0, xs, us, iters, nthreads=2)
+    np.testing.assert_array_equal(st_h["iter"], st_o["iter"])
+    assert rel(xs_h, xs_o) < 1e-8 and rel(us_h, us_o) < 1e-7 and rel(K_h, K_o) < 1e-6
+    h.close()
+
+
+@pytest.mark.gpu
+def test_horizon_beyond_the_step_kernel_is_refused(hip_backend, panda):
+    tcp = panda.frame_id("panda_hand_tcp")
+    po, ref, x0, xs, us = workloads.random_goal_problem(panda, 512, 0.01, 1, seed=32, frame=tcp)
+    h = hip_backend.HipOcp(panda, po, 1)
+    h.set_refs(ref)
+    with pytest.raises(hip_backend.HipError, match="511"):
+        h.solve(x0, xs, us, 2)
+    h.close()
+
+
+@pytest.mark.gpu
+def test_inactive_and_zero_weight_rows(hip_backend, panda):
+    """CostModelSumItem.active = False and weight 0 rows contribute nothing (ocp_croco_generic.py:578-585, 691)."""
+    tcp = panda.frame_id("panda_hand_tcp")
+    B, T = 3, 8
+    po, ref, x0, xs, us = workloads.random_goal_problem(panda, T, 0.01, B, seed=33, frame=tcp)
+    # same problem with the placement rows switched off two ways
+    run_off = [_abi.RowSpec(r.kind, active=(r.kind != _abi.RES_FRAME_PLACEMENT), frame=r.frame, name=r.name) for r in po.running]
+    term_off = [_abi.RowSpec(r.kind, active=(r.kind != _abi.RES_FRAME_PLACEMENT), frame=r.frame, name=r.name) for r in po.terminal]
+    po_inactive = _abi.PackedOcp(7, [0.01] * T, run_off, term_off)
+    ref_zero = ref.copy()
+    for term, rows in ((False, po.running), (True, po.terminal)):
+        for i, r in enumerate(rows):
+            if r.kind == _abi.RES_FRAME_PLACEMENT:
+                po.row_view(ref_zero, term, i)[0][...] = 0.0
+    h1, h2, o = hip_backend.HipOcp(panda, po_inactive, B), hip_backend.HipOcp(panda, po, B), Oracle(panda, po_inactive, B)
+    h1.set_refs(ref)
+    h2.set_refs(ref_zero)
+    r1 = h1.solve(x0, xs, us, 10)
+    r2 = h2.solve(x0, xs, us, 10)
+    ro = o.solve(ref, None, x0, xs, us, 10)
+    assert rel(r1[0], ro[0]) < 1e-9 and rel(r2[0], ro[0]) < 1e-9
+    np.testing.assert_array_equal(r1[3]["iter"], ro[3]["iter"])
+    h1.close(); h2.close()
