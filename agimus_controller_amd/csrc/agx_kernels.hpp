@@ -462,6 +462,7 @@ __device__ __forceinline__ void riccati_body(const int b, const DevOcp *__restri
                                              double *__restrict__ dxs, double *__restrict__ wss,
                                              double *__restrict__ dus, double *__restrict__ Kout,
                                              DevState *__restrict__ st, int forward, int gmode, int iter) {
+  (void)dus;
   constexpr int gains_pass = GAINS ? 1 : 0;
   typedef AUX<NV> A;
   static_assert(NV <= 7, "the register-resident Riccati kernel maps an NV x NV block plus a gradient column onto an 8 x 8 lane grid");
@@ -489,7 +490,7 @@ __device__ __forceinline__ void riccati_body(const int b, const DevOcp *__restri
   const int rc = in ? r * Q::LD + c : 0, cr = in ? c * Q::LD + r : 0;  // [r][c] and [c][r] of a block
   const int rr = r < NV ? r : 0, cc = c < NV ? c : 0;
   const double diag = (r == c) ? 1.0 : 0.0;
-  const int row_base = lane & 56, col_lane = c;
+  const int col_lane = c;
   // value function of node t+1 (starts as the terminal cost + dreg)
   double Vqq, Vqv, Vvq, Vvv, vxq, vxv;
   {
@@ -809,8 +810,7 @@ __global__ void __launch_bounds__(128) k_step(const DevModel *__restrict__ mp, c
                                               DevState *__restrict__ st, int iter, int max_iter, int mode,
                                               int *__restrict__ n_done) {
   constexpr int NX = 2 * NV, NU = NV;
-  typedef QT<NV> Q;
-  typedef AUX<NV> A;
+  (void)qts; (void)auxs;  // kept in the signature: the step kernel of earlier layouts read them
   __shared__ double red[12];
   __shared__ int flag;
   const DevModel &m = *mp;
