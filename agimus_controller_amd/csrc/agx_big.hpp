@@ -74,7 +74,10 @@ __global__ void __launch_bounds__(256) k_riccati_big(const DevOcp *__restrict__ 
   constexpr int NX = 2 * NV, R = 3 * NV, GC = 3 * NV, CS = 3 * NV + 2;
   typedef QT<NV> Q;
   __shared__ double Mx[R * CS];
-  __shared__ double V[NX * NX];
+  // the value Hessian of node t+1 lives in the x-x block of Mx (rows / columns NV..3NV): the build below
+  // reads exactly the four entries it overwrites, so no second 2nv x 2nv array is needed (69 KB of LDS
+  // in total at nv = 30: two workgroups per CU)
+#define AGX_VV(i, j) Mx[(NV + (i)) * CS + NV + (j)]
   __shared__ double vx[NX], vp[NX], fl[NX], rpv[NV], dxl[NX], wl[NV];
   __shared__ double rowbuf[2][3 * NV + 8], colbuf[2][3 * NV + 8];
   const DevOcp &o = *op;
@@ -95,7 +98,7 @@ __global__ void __launch_bounds__(256) k_riccati_big(const DevOcp *__restrict__ 
       else if (i < NV) v = tt[Q::Hqv + ib * Q::LD + jb];
       else if (j < NV) v = tt[Q::Hqv + jb * Q::LD + ib];
       else v = tt[Q::Hvv + ib * Q::LD + jb];
-      V[e] = v + ((i == j) ? dreg : 0.0);
+      AGX_VV(i, j) = v + ((i == j) ? dreg : 0.0);
     }
     for (int i = tid; i < NX; i += nt) vx[i] = gains_pass ? 0.0 : tt[Q::gx + i];
   }
@@ -108,7 +111,7 @@ __global__ void __launch_bounds__(256) k_riccati_big(const DevOcp *__restrict__ 
     __syncthreads();
     for (int i = tid; i < NX; i += nt) {
       double s = vx[i];
-      for (int j = 0; j < NX; ++j) s += V[i * NX + j] * fl[j];
+      for (int j = 0; j < NX; ++j) s += AGX_VV(i, j) * fl[j];
       vp[i] = s;
     }
     __syncthreads();
@@ -116,7 +119,7 @@ __global__ void __launch_bounds__(256) k_riccati_big(const DevOcp *__restrict__ 
     for (int e = tid; e < NV * NV; e += nt) {
       const int r = e / NV, c = e % NV;
       const int rc = r * Q::LD + c, cr = c * Q::LD + r;
-      const double Vqq = V[r * NX + c], Vqv = V[r * NX + NV + c], Vvq = V[(NV + r) * NX + c], Vvv = V[(NV + r) * NX + NV + c];
+      const double Vqq = AGX_VV(r, c), Vqv = AGX_VV(r, NV + c), Vvq = AGX_VV(NV + r, c), Vvv = AGX_VV(NV + r, NV + c);
       const double Yq = h2 * Vqq + h * Vvq, Yv = h2 * Vqv + h * Vvv;
       const double YqT = h2 * Vqq + h * Vqv, YvT = h2 * Vvq + h * Vvv;
       Mx[r * CS + c] = tl[Q::Hww + rc] + h2 * Yq + h * Yv;
@@ -201,9 +204,12 @@ __global__ void __launch_bounds__(256) k_riccati_big(const DevOcp *__restrict__ 
       Kw[(long long)t * NV * NX + e] = Mx[r * CS + NV + c] * rpv[r];
     }
     for (int r = tid; r < NV; r += nt) kw[(long long)t * NV + r] = Mx[r * CS + GC] * rpv[r];
-    for (int e = tid; e < NX * NX; e += nt) {
+    for (int e = tid; e < NX * NX; e += nt) {  // symmetrise in place: one thread per unordered pair
       const int i = e / NX, j = e % NX;
-      V[e] = 0.5 * (Mx[(NV + i) * CS + NV + j] + Mx[(NV + j) * CS + NV + i]) + ((i == j) ? dreg : 0.0);
+      if (i > j) continue;
+      const double sv = 0.5 * (AGX_VV(i, j) + AGX_VV(j, i)) + ((i == j) ? dreg : 0.0);
+      AGX_VV(i, j) = sv;
+      AGX_VV(j, i) = sv;
     }
     for (int i = tid; i < NX; i += nt) vx[i] = Mx[(NV + i) * CS + GC];
     __syncthreads();
@@ -239,6 +245,8 @@ __global__ void __launch_bounds__(256) k_riccati_big(const DevOcp *__restrict__ 
     __syncthreads();
   }
 }
+
+#undef AGX_VV
 
 // K3 for large nv: one lane per node, plain loops (see k_node_kkt for the identities).
 template <int NV>

@@ -203,8 +203,16 @@ def main():
         import torch
         import torch.distributed as dist
 
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        # AGX_BENCH_REHEARSAL=1: every rank on cuda:0 with the gloo backend -- lets the N > 1 code path (seeding by
+        # global instance index, barriers, MAX of the timed region, rank-0 report) run on a one-GPU box
+        rehearsal = os.environ.get("AGX_BENCH_REHEARSAL", "0") == "1"
+        if rehearsal:
+            local_rank = 0
+            torch.cuda.set_device(0)
+            dist.init_process_group("gloo")
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     B, T, dt = args.batch, args.horizon, 0.01
     table, tcp, po = make_problem(T, args.workload)
