@@ -230,6 +230,15 @@ int launch_calc_qp(agx_ocp *o, bool running_only = false, bool term_only = false
         hipLaunchKernelGGL((agx::k_calc_qp_lj<NV, true>), dim3((int)(((long long)o->B * 8 + 63) / 64)), dim3(64), 0, o->stream,
                            o->d_model, o->d_ocp, o->d_dt, o->d_xs, o->d_us, o->rv, o->d_qt, o->d_aux, o->d_state);
     }
+    if constexpr (NV > 8) if (!lanes && !term_only && !running_only) {
+      // large models: both node types in one launch of the one-lane kernel, then the cooperative transformation
+      const long long all = units + o->B;
+      hipLaunchKernelGGL((agx::k_calc_qp_all<NV, CH>), dim3((int)((all + 63) / 64)), dim3(64), 0, o->stream, o->d_model, o->d_ocp, o->d_dt,
+                         o->d_xs, o->d_us, o->rv, o->d_qt, o->d_aux, o->d_state);
+      hipLaunchKernelGGL((agx::k_transform_big<NV>), dim3((int)units), dim3(256), 0, o->stream, o->d_ocp, o->d_qt, o->d_aux, o->d_state);
+      HIPCHK(hipGetLastError());
+      return 0;
+    }
     if (!lanes) {
       if (!term_only) {
         hipLaunchKernelGGL((agx::k_calc_qp<NV, CH>), dim3((int)((units + 63) / 64)), dim3(64), 0, o->stream, o->d_model, o->d_ocp,
@@ -320,8 +329,7 @@ int launch_gains(agx_ocp *o, int gmode = 0) {
     } else {
       // large models: sigma-augmented tiles, LDS sweep, gains to u-space -- for every instance
       const long long nodes = (long long)o->B * (o->T + 1);
-      hipLaunchKernelGGL((agx::k_sigma_tile_big<NV>), dim3((int)((nodes * 32 + 255) / 256)), dim3(256), 0, o->stream, o->d_ocp, o->d_qt,
-                         o->d_qt2, o->d_aux);
+      hipLaunchKernelGGL((agx::k_sigma_tile_big<NV>), dim3((int)nodes), dim3(256), 0, o->stream, o->d_ocp, o->d_qt, o->d_qt2, o->d_aux);
       hipLaunchKernelGGL((agx::k_riccati_big<NV>), dim3(o->B), dim3(256), 0, o->stream, o->d_ocp, o->d_dt, o->d_qt2, o->d_Kws, o->d_kws,
                          o->d_dx, o->d_w, o->d_state, 0, 1);
       if constexpr (NV > 16) {

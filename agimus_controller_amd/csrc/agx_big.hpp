@@ -292,41 +292,48 @@ __global__ void __launch_bounds__(64) k_node_kkt_big(const DevOcp *__restrict__ 
 }
 
 // Exit path for large nv: the Hessian blocks of every node with CSQP's proximal terms,
-//   H + sigma ([taux M]' [taux M] + I_x),  into a second tile; 32 lanes per node, lane j = column j.
+//   H + sigma ([taux M]' [taux M] + I_x),  into a second tile; one 256-thread workgroup per node,
+// M | tq | tv staged in LDS, thread (i, j) forms element [i][j] of the six blocks.
 template <int NV>
 __global__ void __launch_bounds__(256) k_sigma_tile_big(const DevOcp *__restrict__ op, const double *__restrict__ qts,
                                                         double *__restrict__ qt2s, const double *__restrict__ auxs) {
   typedef QT<NV> Q;
   typedef AUX<NV> A;
+  __shared__ double sM[NV * NV], sq[NV * NV], sv[NV * NV];
   const DevOcp &o = *op;
-  const int T = o.T;
-  const long long unit = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  const long long node = unit >> 5;
-  const int j = (int)(unit & 31);
-  if (node >= (long long)o.B * (T + 1) || j >= NV) return;
+  const int T = o.T, tid = threadIdx.x, nt = blockDim.x;
+  const long long node = blockIdx.x;
   const int t = (int)(node % (T + 1));
   const double *qt = qts + node * Q::SIZE;
   double *q2 = qt2s + node * Q::SIZE;
   const double *ax = auxs + node * A::SIZE;
   const double sig = kSigma;
-  for (int i = 0; i < NV; ++i) {
+  if (t < T) {
+    for (int e = tid; e < NV * NV; e += nt) {
+      const int i = e / NV, j = e % NV;
+      sM[e] = ax[A::M + i * A::LD + j]; sq[e] = ax[A::tq + i * A::LD + j]; sv[e] = ax[A::tv + i * A::LD + j];
+    }
+  }
+  __syncthreads();
+  for (int e = tid; e < NV * NV; e += nt) {
+    const int i = e / NV, j = e % NV;
     double hww = 0.0, hqw = 0.0, hvw = 0.0, hqq = 0.0, hqv = 0.0, hvv = 0.0;
     if (t < T)
       for (int l = 0; l < NV; ++l) {
-        const double Mli = ax[A::M + l * A::LD + i], tqli = ax[A::tq + l * A::LD + i], tvli = ax[A::tv + l * A::LD + i];
-        const double Mlj = ax[A::M + l * A::LD + j], tqlj = ax[A::tq + l * A::LD + j], tvlj = ax[A::tv + l * A::LD + j];
+        const double Mli = sM[l * NV + i], tqli = sq[l * NV + i], tvli = sv[l * NV + i];
+        const double Mlj = sM[l * NV + j], tqlj = sq[l * NV + j], tvlj = sv[l * NV + j];
         hww += Mli * Mlj; hqw += tqli * Mlj; hvw += tvli * Mlj;
         hqq += tqli * tqlj; hqv += tqli * tvlj; hvv += tvli * tvlj;
       }
     const double d = (i == j) ? sig : 0.0;
-    const int e = i * Q::LD + j;
-    q2[Q::Hqq + e] = qt[Q::Hqq + e] + sig * hqq + d;
-    q2[Q::Hqv + e] = qt[Q::Hqv + e] + sig * hqv;
-    q2[Q::Hvv + e] = qt[Q::Hvv + e] + sig * hvv + d;
+    const int o2 = i * Q::LD + j;
+    q2[Q::Hqq + o2] = qt[Q::Hqq + o2] + sig * hqq + d;
+    q2[Q::Hqv + o2] = qt[Q::Hqv + o2] + sig * hqv;
+    q2[Q::Hvv + o2] = qt[Q::Hvv + o2] + sig * hvv + d;
     if (t < T) {
-      q2[Q::Hww + e] = qt[Q::Hww + e] + sig * hww;
-      q2[Q::Hqw + e] = qt[Q::Hqw + e] + sig * hqw;
-      q2[Q::Hvw + e] = qt[Q::Hvw + e] + sig * hvw;
+      q2[Q::Hww + o2] = qt[Q::Hww + o2] + sig * hww;
+      q2[Q::Hqw + o2] = qt[Q::Hqw + o2] + sig * hqw;
+      q2[Q::Hvw + o2] = qt[Q::Hvw + o2] + sig * hvw;
     }
   }
 }

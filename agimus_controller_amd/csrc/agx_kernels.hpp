@@ -227,17 +227,16 @@ struct AUX {
 };
 
 template <int NV, bool CHAIN>
-__global__ void __launch_bounds__(64) k_calc_qp(const DevModel *__restrict__ mp, const DevOcp *__restrict__ op,
-                                                const double *__restrict__ dts, const double *__restrict__ xs,
-                                                const double *__restrict__ us, RefView rv, double *__restrict__ qts,
-                                                double *__restrict__ auxs, const DevState *__restrict__ st) {
+__device__ __forceinline__ void calc_qp_body(const long long unit, const DevModel *__restrict__ mp, const DevOcp *__restrict__ op,
+                                             const double *__restrict__ dts, const double *__restrict__ xs,
+                                             const double *__restrict__ us, const RefView &rv, double *__restrict__ qts,
+                                             double *__restrict__ auxs, const DevState *__restrict__ st) {
   constexpr int NX = 2 * NV, NU = NV;
   typedef QT<NV> Q;
   typedef AUX<NV> A;
   const DevModel &m = *mp;
   const DevOcp &o = *op;
   const int T = o.T;
-  const long long unit = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (unit >= (long long)o.B * T) return;
   const int b = (int)(unit / T), t = (int)(unit % T);
   if (st[b].done) return;
@@ -353,16 +352,23 @@ AGX_UNROLL_NV
 }
 
 template <int NV, bool CHAIN>
-__global__ void __launch_bounds__(64) k_calc_qp_term(const DevModel *__restrict__ mp, const DevOcp *__restrict__ op,
-                                                     const double *__restrict__ xs, RefView rv, double *__restrict__ qts,
-                                                     double *__restrict__ auxs, const DevState *__restrict__ st) {
+__global__ void __launch_bounds__(64) k_calc_qp(const DevModel *__restrict__ mp, const DevOcp *__restrict__ op,
+                                                const double *__restrict__ dts, const double *__restrict__ xs,
+                                                const double *__restrict__ us, RefView rv, double *__restrict__ qts,
+                                                double *__restrict__ auxs, const DevState *__restrict__ st) {
+  calc_qp_body<NV, CHAIN>((long long)blockIdx.x * blockDim.x + threadIdx.x, mp, op, dts, xs, us, rv, qts, auxs, st);
+}
+
+template <int NV, bool CHAIN>
+__device__ __forceinline__ void calc_qp_term_body(const int b, const DevModel *__restrict__ mp, const DevOcp *__restrict__ op,
+                                                  const double *__restrict__ xs, const RefView &rv, double *__restrict__ qts,
+                                                  double *__restrict__ auxs, const DevState *__restrict__ st) {
   constexpr int NX = 2 * NV;
   typedef QT<NV> Q;
   typedef AUX<NV> A;
   const DevModel &m = *mp;
   const DevOcp &o = *op;
   const int T = o.T;
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= o.B) return;
   if (st[b].done) return;
   double x[NX];
@@ -400,6 +406,26 @@ AGX_UNROLL_NV
       ax[A::Lqq + i * A::LD + j] = c.Lqq[i][j];
     }
   }
+}
+
+template <int NV, bool CHAIN>
+__global__ void __launch_bounds__(64) k_calc_qp_term(const DevModel *__restrict__ mp, const DevOcp *__restrict__ op,
+                                                     const double *__restrict__ xs, RefView rv, double *__restrict__ qts,
+                                                     double *__restrict__ auxs, const DevState *__restrict__ st) {
+  calc_qp_term_body<NV, CHAIN>(blockIdx.x * blockDim.x + threadIdx.x, mp, op, xs, rv, qts, auxs, st);
+}
+
+// one-lane derivative pass of both node types in one launch (large models: the terminal nodes would
+// otherwise be a latency-bound launch of B lanes on their own)
+template <int NV, bool CHAIN>
+__global__ void __launch_bounds__(64) k_calc_qp_all(const DevModel *__restrict__ mp, const DevOcp *__restrict__ op,
+                                                    const double *__restrict__ dts, const double *__restrict__ xs,
+                                                    const double *__restrict__ us, RefView rv, double *__restrict__ qts,
+                                                    double *__restrict__ auxs, const DevState *__restrict__ st) {
+  const long long unit = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long n_run = (long long)op->B * op->T;
+  if (unit < n_run) calc_qp_body<NV, CHAIN>(unit, mp, op, dts, xs, us, rv, qts, auxs, st);
+  else calc_qp_term_body<NV, CHAIN>((int)(unit - n_run), mp, op, xs, rv, qts, auxs, st);
 }
 
 __device__ __forceinline__ double wave_max(double v) {
