@@ -335,15 +335,16 @@ AGX_UNROLL_NV
 // Used by the large-model derivative pass, where forming the inverse (n^3) is not worth it.
 template <int NV>
 AGX_DEV void spd_solve(double (*A)[NV], double *b) {
+  // right-looking (outer product) Cholesky: after column j is final, the trailing rows are updated
+  // with independent FMAs (no dot-product chains through scratch memory)
   for (int j = 0; j < NV; ++j) {
-    double dd = A[j][j];
-    for (int kk = 0; kk < j; ++kk) dd -= A[j][kk] * A[j][kk];
-    const double l = sqrt(dd), il = 1.0 / l;
+    const double l = sqrt(A[j][j]), il = 1.0 / l;
     A[j][j] = l;
+    for (int i = j + 1; i < NV; ++i) A[i][j] *= il;
     for (int i = j + 1; i < NV; ++i) {
-      double s = A[i][j];
-      for (int kk = 0; kk < j; ++kk) s -= A[i][kk] * A[j][kk];
-      A[i][j] = s * il;
+      const double lij = A[i][j];
+#pragma unroll 4
+      for (int kk = j + 1; kk <= i; ++kk) A[i][kk] -= lij * A[kk][j];
     }
   }
   for (int i = 0; i < NV; ++i) {
@@ -883,16 +884,23 @@ AGX_UNROLL_NV
         if (e < nr) a += 0.5 * aw[e] * res[e] * res[e];
       c.cost += wi * a;
       if (DIFF) {
+        // J' W r and J' W J with the six residual rows innermost: one update per Hessian element
+        // (large models keep Lqq in scratch: a read-modify-write per row and element serialises)
+        double we[6];
 #pragma unroll
-        for (int e = 0; e < 6; ++e) {
-          if (e < nr) {
-            const double we = wi * aw[e];
+        for (int e = 0; e < 6; ++e) we[e] = (e < nr) ? wi * aw[e] : 0.0;
 AGX_UNROLL_NV
-            for (int i = 0; i < NV; ++i) {
-              c.Lq[i] += we * res[e] * J[e][i];
+        for (int i = 0; i < NV; ++i) {
+          double wj[6], gi = 0.0;
 #pragma unroll
-              for (int j = 0; j <= i; ++j) c.Lqq[i][j] += we * J[e][i] * J[e][j];
-            }
+          for (int e = 0; e < 6; ++e) { wj[e] = we[e] * J[e][i]; gi += wj[e] * res[e]; }
+          c.Lq[i] += gi;
+AGX_UNROLL_NV
+          for (int j = 0; j <= i; ++j) {
+            double acc = 0.0;
+#pragma unroll
+            for (int e = 0; e < 6; ++e) acc += wj[e] * J[e][j];
+            c.Lqq[i][j] += acc;
           }
         }
       }
