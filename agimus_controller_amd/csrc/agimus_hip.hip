@@ -387,9 +387,12 @@ int publish(agx_ocp *o, int slot_value, int slot_seq, const int *d_value, int se
 }
 int wait_stamp(agx_ocp *o, int slot_seq, int seq) {
   volatile int *w = o->h_ndone + slot_seq;
+  const auto t_begin = std::chrono::steady_clock::now();
   for (unsigned long spins = 1;; ++spins) {
     if (__atomic_load_n(w, __ATOMIC_ACQUIRE) == seq) return 0;
-    if ((spins & 0x3FFF) == 0) {  // every so often make sure the stream is still alive
+    if ((spins & 0x3FFF) == 0) {  // every so often make sure the stream is still alive and not stuck
+      if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count() > 120.0)
+        return fail("timed out after 120 s waiting for the device (stamp never published)");
       const hipError_t e = hipStreamQuery(o->stream);
       if (e == hipSuccess) {
         if (__atomic_load_n(w, __ATOMIC_ACQUIRE) == seq) return 0;

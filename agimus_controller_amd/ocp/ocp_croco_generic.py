@@ -460,6 +460,10 @@ class ResidualDistanceCollision(ResidualDistanceCollisionBase):
 @_yaml_class
 @dataclasses.dataclass
 class ResidualDistanceCollision2(ResidualDistanceCollisionBase):
+    """colmpc.ResidualDistanceCollision2: the same signed distance of the pair, with the geometry
+    placements kept in colmpc.StateMultibody upstream.  Here geometry placements always live in the
+    device model (update_geometry_placement), so it lowers to the same row as ResidualDistanceCollision."""
+
     class_: T.ClassVar[str] = "ResidualDistanceCollision2"
 
     @staticmethod
@@ -564,7 +568,7 @@ class DifferentialActionModelFreeFwdDynamics(DifferentialActionModel):
             con = item.constraint
             res = con.residual
             kind = res.kind
-            if kind in (_abi.RES_CONTROL_GRAV, _abi.RES_FRAME_VELOCITY) or isinstance(res, ResidualDistanceCollision2):
+            if kind in (_abi.RES_CONTROL_GRAV, _abi.RES_FRAME_VELOCITY):
                 raise NotImplementedError(f"constraint '{item.name}': {type(res).__name__} is not implemented on the HIP path yet")
             nr = _abi.row_nr(kind, data.nv)
             if isinstance(con, ConstraintModelControlLimit):
@@ -591,7 +595,7 @@ class DifferentialActionModelFreeFwdDynamics(DifferentialActionModel):
         for item in self.costs:
             res, act = item.cost.residual, item.cost.activation
             kind = res.kind
-            if kind in (_abi.RES_CONTROL_GRAV, _abi.RES_FRAME_VELOCITY) or isinstance(res, ResidualDistanceCollision2):
+            if kind in (_abi.RES_CONTROL_GRAV, _abi.RES_FRAME_VELOCITY):
                 raise NotImplementedError(f"cost '{item.name}': {type(res).__name__} is not implemented on the HIP path yet")
             act_kind = _abi.ACT_WEIGHTED_QUAD if act is None else act.kind
             alpha = 1.0 if act is None or act_kind == _abi.ACT_WEIGHTED_QUAD else act.alpha_value

@@ -200,8 +200,19 @@ def test_yaml_unknown_class_and_unsupported_components():
                                  "activation": {"class": "ActivationModelQuadExp", "alpha": 1e-4}}})
     sp = gen.ShootingProblem(**coll)
     assert sp.needs_colmpc_state()
-    with pytest.raises(NotImplementedError, match="ResidualDistanceCollision2"):
+    with pytest.raises(AssertionError, match="no collision geometry"):  # the plain Panda table carries no geometry
         sp.running_model.differential.lower(gen.BuildData(panda_robot_models().robot_model, 7))
+    # with geometry the colmpc.StateMultibody variant lowers to the same distance row
+    from agimus_controller_amd.factory import robot_tables as rt
+    from agimus_controller_amd.factory.robot_model import RobotModelParameters, RobotModels
+
+    table = rt.panda_collision_table(0.1)
+    rm = RobotModels(RobotModelParameters(table=table, armature=table.armature))
+    coll["running_model"]["differential"]["costs"][-1]["cost"]["residual"]["collision_pair"] = ["panda_link5_capsule_0", "obstacle"]
+    sp = gen.ShootingProblem(**coll)
+    rows = sp.running_model.differential.lower(gen.BuildData(rm.robot_model, 7, rm.collision_model))
+    assert rows[-1].kind == _abi.RES_COLLISION and rows[-1].activation == _abi.ACT_QUAD_EXP
+    assert (rows[-1].frame, rows[-1].frame_b) == (table.frame_id("panda_link5_capsule_0"), table.frame_id("obstacle"))
 
 
 def test_add_modules_extends_the_schema():
