@@ -54,6 +54,8 @@ struct agx_ocp {
   // multipliers y (persistent across solves), slack z, prox centre, per-node residual norms
   bool has_con = false;
   double *d_trial = nullptr;  // [B][T+1] merit shares of a line-search trial (large models)
+  bool general = false;       // ControlGrav / FrameVelocity cost rows: one-lane GEN kernels (agx_general.hpp)
+  double *d_auxg = nullptr;   // [B][T+1][3 nv 8]: Lqv | Lvvd | Lqu of every node (general problems)
   double *d_qt2 = nullptr, *d_cg = nullptr, *d_cjac = nullptr, *d_y = nullptr, *d_z = nullptr, *d_cx = nullptr, *d_admmstat = nullptr;
   int qt_size = 0, aux_size = 0;
   bool k1_lanes = true;  // AGX_K1_LANES=0 selects the one-lane-per-node derivative kernel
@@ -126,6 +128,7 @@ void fill_rows(const agx_cost_row *rows, int n, int nv, DevRows &d) {
     d.nr[r] = agx_row_nr(rows[r].kind, nv);
     d.off[r] = off;
     off += 1 + d.nref[r] + d.nr[r];
+    if (rows[r].active && (rows[r].kind == AGX_RES_CONTROL_GRAV || rows[r].kind == AGX_RES_FRAME_VELOCITY)) d.general = 1;
   }
 }
 
@@ -195,6 +198,15 @@ int launch_calc_diff(agx_ocp *o, bool masked, bool running_only = false) {
     constexpr bool CH = decltype(CHc)::value;
     const long long units = (long long)o->B * o->T;
     const int grid = (int)((units + 63) / 64);
+    if constexpr (NV <= 7) if (o->general) {
+      hipLaunchKernelGGL((agx::k_calc_diff<NV, CH, true>), dim3(grid), dim3(64), 0, o->stream, o->d_model, o->d_ocp, o->d_dt, o->d_xs,
+                         o->d_us, o->rv, o->d_tiles, masked ? o->d_state : nullptr);
+      if (running_only) { HIPCHK(hipGetLastError()); return 0; }
+      hipLaunchKernelGGL((agx::k_calc_diff_term<NV, CH, true>), dim3((o->B + 63) / 64), dim3(64), 0, o->stream, o->d_model, o->d_ocp,
+                         o->d_xs, o->rv, o->d_tiles, masked ? o->d_state : nullptr);
+      HIPCHK(hipGetLastError());
+      return 0;
+    }
     hipLaunchKernelGGL((agx::k_calc_diff<NV, CH>), dim3(grid), dim3(64), 0, o->stream, o->d_model, o->d_ocp, o->d_dt, o->d_xs,
                        o->d_us, o->rv, o->d_tiles, masked ? o->d_state : nullptr);
     if (running_only) { HIPCHK(hipGetLastError()); return 0; }
@@ -212,6 +224,16 @@ int launch_calc_qp(agx_ocp *o, bool running_only = false, bool term_only = false
     constexpr int NV = decltype(NVc)::value;
     constexpr bool CH = decltype(CHc)::value;
     const long long units = (long long)o->B * o->T;
+    if constexpr (NV <= 7) if (o->general) {
+      if (!term_only)
+        hipLaunchKernelGGL((agx::k_calc_qp<NV, CH, true>), dim3((int)((units + 63) / 64)), dim3(64), 0, o->stream, o->d_model, o->d_ocp,
+                           o->d_dt, o->d_xs, o->d_us, o->rv, o->d_qt, o->d_aux, o->d_state, o->d_auxg);
+      if (!running_only)
+        hipLaunchKernelGGL((agx::k_calc_qp_term<NV, CH, true>), dim3((o->B + 63) / 64), dim3(64), 0, o->stream, o->d_model, o->d_ocp,
+                           o->d_xs, o->rv, o->d_qt, o->d_aux, o->d_state, o->d_auxg);
+      HIPCHK(hipGetLastError());
+      return 0;
+    }
     bool lanes = false;
     if constexpr (NV <= 7) lanes = CH && o->k1_lanes && o->lanes_ok;
     if constexpr (NV <= 7) if (lanes && !term_only && !running_only) {
@@ -284,6 +306,16 @@ int launch_step(agx_ocp *o, int iter, int max_iter, int mode, bool with_node_kkt
     constexpr int NV = decltype(NVc)::value;
     constexpr bool CH = decltype(CHc)::value;
     const long long nodes = (long long)o->B * (o->T + 1);
+    if constexpr (NV <= 7) if (o->general) {
+      if (with_node_kkt)
+        hipLaunchKernelGGL((agx::k_node_kkt_gen<NV>), dim3((int)((nodes + 63) / 64)), dim3(64), 0, o->stream, o->d_ocp, o->d_qt, o->d_aux,
+                           o->d_auxg, o->d_dx, o->d_w, o->d_du, o->d_nodestat, o->d_state);
+      if (with_step)
+        hipLaunchKernelGGL((agx::k_step<NV, CH, true>), dim3(o->B), dim3(128), 0, o->stream, o->d_model, o->d_ocp, o->d_dt, o->d_xs, o->d_us,
+                           o->rv, o->d_qt, o->d_aux, o->d_dx, o->d_nodestat, o->d_du, o->d_state, iter, max_iter, mode, o->d_ndone);
+      HIPCHK(hipGetLastError());
+      return 0;
+    }
     if (with_node_kkt) {
       if constexpr (NV <= 7)
         hipLaunchKernelGGL((agx::k_node_kkt<NV>), dim3((int)((nodes * 8 + 255) / 256)), dim3(256), 0, o->stream, o->d_ocp, o->d_qt, o->d_aux,
@@ -614,6 +646,11 @@ int agx_ocp_create(const agx_model *m, const agx_ocp_desc *d, int batch, int dev
     switch (row.kind) {
       case AGX_RES_STATE: case AGX_RES_CONTROL: case AGX_RES_FRAME_PLACEMENT: case AGX_RES_FRAME_TRANSLATION: case AGX_RES_FRAME_ROTATION:
       case AGX_RES_COLLISION: break;
+      case AGX_RES_CONTROL_GRAV: case AGX_RES_FRAME_VELOCITY:
+        if (m->h.nv > 7) return fail("agx_ocp_create: ControlGrav / FrameVelocity rows are implemented for nv <= 7");
+        if (row.kind == AGX_RES_FRAME_VELOCITY && (row.frame < 0 || row.frame >= m->h.nframes || row.frame_b < 0 || row.frame_b > 2))
+          return fail("agx_ocp_create: FrameVelocity row needs a valid frame and a reference frame 0 (WORLD), 1 (LOCAL) or 2 (LOCAL_WORLD_ALIGNED)");
+        break;
       default: return fail("agx_ocp_create: residual kind " + std::to_string(row.kind) + " is not implemented on the HIP path yet");
     }
     if (row.activation != AGX_ACT_WEIGHTED_QUAD && row.kind != AGX_RES_COLLISION)
@@ -654,6 +691,8 @@ int agx_ocp_create(const agx_model *m, const agx_ocp_desc *d, int batch, int dev
   if (fill_cons(d->running_constraints, d->n_running_constraints, o->nv, m->h, o->ho.cons[0]) ||
       fill_cons(d->terminal_constraints, d->n_terminal_constraints, o->nv, m->h, o->ho.cons[1])) { delete o; return -1; }
   o->has_con = o->ho.cons[0].nc + o->ho.cons[1].nc > 0;
+  o->general = o->ho.rows[0].general || o->ho.rows[1].general;
+  if (o->general && o->has_con) { delete o; return fail("agx_ocp_create: constraints together with ControlGrav / FrameVelocity cost rows are not implemented"); }
   o->ho.has_con = o->has_con ? 1 : 0;
   o->ho.max_qp = d->max_qp_iters > 0 ? d->max_qp_iters : 1000;
   o->ho.eps_abs = d->eps_abs;
@@ -672,7 +711,7 @@ int agx_ocp_create(const agx_model *m, const agx_ocp_desc *d, int batch, int dev
       return n;
     };
     o->lanes_ok = o->stride <= agx::kLjRef && n_frame_rows(o->ho.rows[0]) <= 2 && n_frame_rows(o->ho.rows[1]) <= 2 &&
-                  n_collision_rows(o->ho.rows[0]) + n_collision_rows(o->ho.rows[1]) == 0;
+                  n_collision_rows(o->ho.rows[0]) + n_collision_rows(o->ho.rows[1]) == 0 && !o->general;
   }
   // probe that a kernel instantiation exists
   if (dispatch(o->nv, o->chain, [](auto, auto) -> int { return 0; })) { delete o; return -1; }
@@ -703,6 +742,7 @@ int agx_ocp_create(const agx_model *m, const agx_ocp_desc *d, int batch, int dev
   ALLOC(o->d_frames, B * (T + 1) * AGX_MAX_ROWS);
   ALLOC(o->d_state, B);
   ALLOC(o->d_ndone, 2);  // [0] finished instances, [1] instances whose ADMM loop has ended
+  if (o->general) ALLOC(o->d_auxg, B * (T + 1) * (size_t)(3 * o->nv * 8));
   if (o->has_con) {
     ALLOC(o->d_qt2, B * (T + 1) * (size_t)o->qt_size);
     ALLOC(o->d_cg, B * (T + 1) * AGX_MAX_NC);
@@ -744,7 +784,7 @@ void agx_ocp_destroy(agx_ocp *o) {
   if (o->stream) (void)hipStreamSynchronize(o->stream);
   void *ptrs[] = {o->d_model, o->d_ocp, o->d_dt, o->d_xs, o->d_us, o->d_x0, o->d_tiles, o->d_Kws, o->d_kws, o->d_Kout, o->d_dx,
                   o->d_du, o->d_ref, o->d_frames, o->d_state, o->d_ndone, o->d_scratch, o->d_traj, o->d_pts, o->d_sine, o->d_qt, o->d_aux, o->d_w, o->d_nodestat,
-                  o->d_qt2, o->d_cg, o->d_cjac, o->d_y, o->d_z, o->d_cx, o->d_admmstat, o->d_hidx, o->d_trial};
+                  o->d_qt2, o->d_cg, o->d_cjac, o->d_y, o->d_z, o->d_cx, o->d_admmstat, o->d_hidx, o->d_trial, o->d_auxg};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
   if (o->h_ndone) (void)hipHostFree(o->h_ndone);

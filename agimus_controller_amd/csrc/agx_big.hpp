@@ -291,6 +291,63 @@ __global__ void __launch_bounds__(64) k_node_kkt_big(const DevOcp *__restrict__ 
   ns[0] = kkt; ns[1] = qt[Q::cost]; ns[2] = gap; ns[3] = 0.0;
 }
 
+// K3 for problems with general cost rows (agx_general.hpp): the optimality identities with every block,
+//   Lu + Fu' lam' = -(Lqu' dq + (Luu + preg) du)
+//   Lx + Fx' lam' - lam = -(Lxx dx + Lxu du + dreg dx),  Lxx = [[Lqq, Lqv], [Lqv', diag(Lvv) + Lvvd]]
+// one lane per node; auxg = Lqv | Lvvd | Lqu of the node.
+template <int NV>
+__global__ void __launch_bounds__(64) k_node_kkt_gen(const DevOcp *__restrict__ op, const double *__restrict__ qts,
+                                                     const double *__restrict__ auxs, const double *__restrict__ auxg,
+                                                     const double *__restrict__ dxs, const double *__restrict__ wss,
+                                                     double *__restrict__ dus, double *__restrict__ nodestat,
+                                                     const DevState *__restrict__ st) {
+  constexpr int NX = 2 * NV;
+  typedef QT<NV> Q;
+  typedef AUX<NV> A;
+  const DevOcp &o = *op;
+  const int T = o.T;
+  const long long node = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (node >= (long long)o.B * (T + 1)) return;
+  const int b = (int)(node / (T + 1)), t = (int)(node % (T + 1));
+  const DevState &S = st[b];
+  if (S.done) return;
+  const double preg = S.preg, dreg = S.dreg;
+  const double *qt = qts + node * Q::SIZE;
+  const double *ax = auxs + node * A::SIZE;
+  const double *ag = auxg + node * (3 * A::B2);
+  const double *Lqv = ag, *Lvvd = ag + A::B2, *Lqu = ag + 2 * A::B2;
+  const double *dx = dxs + node * NX;
+  double kkt = 0.0, gap = 0.0, du[NV];
+  for (int i = 0; i < NV; ++i) du[i] = 0.0;
+  if (t < T) {
+    const double *w = wss + ((long long)b * T + t) * NV;
+    for (int i = 0; i < NX; ++i) { kkt = fmax(kkt, fabs(qt[Q::f + i])); gap += fabs(qt[Q::f + i]); }
+    for (int i = 0; i < NV; ++i) {
+      double s = 0.0;
+      for (int l = 0; l < NV; ++l)
+        s += ax[A::M + i * A::LD + l] * w[l] + ax[A::tq + i * A::LD + l] * dx[l] + ax[A::tv + i * A::LD + l] * dx[NV + l];
+      du[i] = s;
+      dus[((long long)b * T + t) * NV + i] = s;
+    }
+    for (int i = 0; i < NV; ++i) {
+      double s = (ax[A::Luu + i] + preg) * du[i];
+      for (int l = 0; l < NV; ++l) s += Lqu[l * A::LD + i] * dx[l];
+      kkt = fmax(kkt, fabs(s));
+    }
+  }
+  if (t > 0)
+    for (int i = 0; i < NV; ++i) {
+      double hq = dreg * dx[i], hv = (ax[A::Lvv + i] + dreg) * dx[NV + i];
+      for (int j = 0; j < NV; ++j) {
+        hq += ax[A::Lqq + i * A::LD + j] * dx[j] + Lqv[i * A::LD + j] * dx[NV + j] + Lqu[i * A::LD + j] * du[j];
+        hv += Lqv[j * A::LD + i] * dx[j] + Lvvd[i * A::LD + j] * dx[NV + j];
+      }
+      kkt = fmax(kkt, fmax(fabs(hq), fabs(hv)));
+    }
+  double *ns = nodestat + node * 4;
+  ns[0] = kkt; ns[1] = qt[Q::cost]; ns[2] = gap; ns[3] = 0.0;
+}
+
 // Exit path for large nv: the Hessian blocks of every node with CSQP's proximal terms,
 //   H + sigma ([taux M]' [taux M] + I_x),  into a second tile; one 256-thread workgroup per node,
 // M | tq | tv staged in LDS, thread (i, j) forms element [i][j] of the six blocks.

@@ -39,6 +39,7 @@ struct DevRows {
   int kind[AGX_MAX_ROWS], act[AGX_MAX_ROWS], active[AGX_MAX_ROWS], frame[AGX_MAX_ROWS], frame_b[AGX_MAX_ROWS];
   int off[AGX_MAX_ROWS], nref[AGX_MAX_ROWS], nr[AGX_MAX_ROWS];
   double alpha[AGX_MAX_ROWS], weight[AGX_MAX_ROWS];
+  int general, pad_;  // some active row is a ControlGrav / FrameVelocity residual (agx_general.hpp)
 };
 
 // ConstraintListItem rows of one node type:  lb <= g(x, u) <= ub, g stacked over the rows.
@@ -999,9 +1000,13 @@ AGX_DEV double admm_rho(double lb, double ub, double rho_sparse) {
   return rho_sparse;
 }
 
+}  // namespace agx
+#include "agx_general.hpp"
+namespace agx {
+
 // calc of a running node: forward dynamics + semi-implicit Euler + cost
 // (crocoddyl IntegratedActionModelEuler::calc).
-template <int NV, bool CHAIN>
+template <int NV, bool CHAIN, bool GEN = false>
 AGX_DEV void node_calc_running(const DevModel &m, const DevRows &rows, double dt, const double *x, const double *u,
                                const double *ref, const int *frames, double *xnext, double *cost) {
   Kin<NV> k;
@@ -1020,16 +1025,24 @@ AGX_UNROLL_NV
   }
   CostAcc<NV> c;
   node_costs<NV, CHAIN, false, false>(m, rows, k, x, u, ref, frames, c);
+  if constexpr (GEN) {
+    CostGen<NV> g;
+    node_costs_general<NV, CHAIN, false, false>(m, rows, k, x, u, ref, frames, c, g);
+  }
   *cost = dt * c.cost;
 }
 
-template <int NV, bool CHAIN>
+template <int NV, bool CHAIN, bool GEN = false>
 AGX_DEV void node_calc_terminal(const DevModel &m, const DevRows &rows, const double *x, const double *ref,
                                 const int *frames, double *cost) {
   Kin<NV> k;
   kinematics<NV, CHAIN>(m, x, k);
   CostAcc<NV> c;
   node_costs<NV, CHAIN, true, false>(m, rows, k, x, nullptr, ref, frames, c);
+  if constexpr (GEN) {
+    CostGen<NV> g;
+    node_costs_general<NV, CHAIN, true, false>(m, rows, k, x, nullptr, ref, frames, c, g);
+  }
   *cost = c.cost;
 }
 

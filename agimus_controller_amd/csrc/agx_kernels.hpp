@@ -55,7 +55,7 @@ constexpr double kRegMax = 1e9;
 // ---------------------------------------------------------------------------
 // K1: derivative pass over the running nodes.  unit = b*T + t, one lane each.
 // ---------------------------------------------------------------------------
-template <int NV, bool CHAIN>
+template <int NV, bool CHAIN, bool GEN = false>
 __global__ void __launch_bounds__(64) k_calc_diff(const DevModel *__restrict__ mp, const DevOcp *__restrict__ op,
                                                   const double *__restrict__ dts, const double *__restrict__ xs,
                                                   const double *__restrict__ us, RefView rv,
@@ -128,7 +128,11 @@ AGX_UNROLL_NV
   }
   CostAcc<NV> c;
   node_costs<NV, CHAIN, false, true>(m, o.rows[0], k, x, u, ref_at(rv, b, t, T), frames_at(rv, b, t, T), c);
+  CostGen<NV> g;
+  if constexpr (GEN) node_costs_general<NV, CHAIN, false, true>(m, o.rows[0], k, x, u, ref_at(rv, b, t, T), frames_at(rv, b, t, T), c, g);
   tile[TO::cost] = dt * c.cost;
+#pragma unroll
+  for (int i = 0; i < NX * NU; ++i) tile[TO::Lxu + i] = 0.0;
 AGX_UNROLL_NV
   for (int i = 0; i < NV; ++i) {
     tile[TO::Lx + i] = dt * c.Lq[i];
@@ -137,18 +141,17 @@ AGX_UNROLL_NV
 AGX_UNROLL_NV
     for (int j = 0; j < NV; ++j) {
       tile[TO::Lxx + i * NX + j] = dt * c.Lqq[i][j];
-      tile[TO::Lxx + i * NX + NV + j] = 0.0;
-      tile[TO::Lxx + (NV + i) * NX + j] = 0.0;
-      tile[TO::Lxx + (NV + i) * NX + NV + j] = (i == j) ? dt * c.Lvv[i] : 0.0;
+      tile[TO::Lxx + i * NX + NV + j] = GEN ? dt * g.Lqv[i][j] : 0.0;
+      tile[TO::Lxx + (NV + i) * NX + j] = GEN ? dt * g.Lqv[j][i] : 0.0;
+      tile[TO::Lxx + (NV + i) * NX + NV + j] = ((i == j) ? dt * c.Lvv[i] : 0.0) + (GEN ? dt * g.Lvvd[i][j] : 0.0);
       tile[TO::Luu + i * NU + j] = (i == j) ? dt * c.Luu[i] : 0.0;
+      if (GEN) tile[TO::Lxu + i * NU + j] = dt * g.Lqu[i][j];
     }
   }
-#pragma unroll
-  for (int i = 0; i < NX * NU; ++i) tile[TO::Lxu + i] = 0.0;
 }
 
 // terminal nodes: cost only, xnext = x (dt = 0, cost not scaled)
-template <int NV, bool CHAIN>
+template <int NV, bool CHAIN, bool GEN = false>
 __global__ void __launch_bounds__(64) k_calc_diff_term(const DevModel *__restrict__ mp, const DevOcp *__restrict__ op,
                                                        const double *__restrict__ xs, RefView rv,
                                                        double *__restrict__ tiles, const DevState *__restrict__ st) {
@@ -169,6 +172,8 @@ __global__ void __launch_bounds__(64) k_calc_diff_term(const DevModel *__restric
   kinematics<NV, CHAIN>(m, x, k);
   CostAcc<NV> c;
   node_costs<NV, CHAIN, true, true>(m, o.rows[1], k, x, nullptr, ref_at(rv, b, T, T), frames_at(rv, b, T, T), c);
+  CostGen<NV> g;
+  if constexpr (GEN) node_costs_general<NV, CHAIN, true, true>(m, o.rows[1], k, x, nullptr, ref_at(rv, b, T, T), frames_at(rv, b, T, T), c, g);
   tile[TO::cost] = c.cost;
 AGX_UNROLL_NV
   for (int i = 0; i < NX; ++i) {
@@ -186,9 +191,9 @@ AGX_UNROLL_NV
 AGX_UNROLL_NV
     for (int j = 0; j < NV; ++j) {
       tile[TO::Lxx + i * NX + j] = c.Lqq[i][j];
-      tile[TO::Lxx + i * NX + NV + j] = 0.0;
-      tile[TO::Lxx + (NV + i) * NX + j] = 0.0;
-      tile[TO::Lxx + (NV + i) * NX + NV + j] = (i == j) ? c.Lvv[i] : 0.0;
+      tile[TO::Lxx + i * NX + NV + j] = GEN ? g.Lqv[i][j] : 0.0;
+      tile[TO::Lxx + (NV + i) * NX + j] = GEN ? g.Lqv[j][i] : 0.0;
+      tile[TO::Lxx + (NV + i) * NX + NV + j] = ((i == j) ? c.Lvv[i] : 0.0) + (GEN ? g.Lvvd[i][j] : 0.0);
       tile[TO::Luu + i * NU + j] = 0.0;
     }
   }
@@ -226,11 +231,12 @@ struct AUX {
   static constexpr int M = 0, tq = B2, tv = 2 * B2, Lqq = 3 * B2, Lvv = 4 * B2, Luu = Lvv + LD, Lu = Luu + LD, SIZE = Lu + LD;
 };
 
-template <int NV, bool CHAIN>
+template <int NV, bool CHAIN, bool GEN = false>
 __device__ __forceinline__ void calc_qp_body(const long long unit, const DevModel *__restrict__ mp, const DevOcp *__restrict__ op,
                                              const double *__restrict__ dts, const double *__restrict__ xs,
                                              const double *__restrict__ us, const RefView &rv, double *__restrict__ qts,
-                                             double *__restrict__ auxs, const DevState *__restrict__ st) {
+                                             double *__restrict__ auxs, const DevState *__restrict__ st,
+                                             double *__restrict__ auxg = nullptr) {
   constexpr int NX = 2 * NV, NU = NV;
   typedef QT<NV> Q;
   typedef AUX<NV> A;
@@ -286,6 +292,8 @@ AGX_UNROLL_NV
   rnea_derivatives<NV, CHAIN>(m, k, d, x + NV, qdd, tq, tv);
   CostAcc<NV> c;
   node_costs<NV, CHAIN, false, true>(m, o.rows[0], k, x, u, ref_at(rv, b, t, T), frames_at(rv, b, t, T), c);
+  CostGen<NV> g;
+  if constexpr (GEN) node_costs_general<NV, CHAIN, false, true>(m, o.rows[0], k, x, u, ref_at(rv, b, t, T), frames_at(rv, b, t, T), c, g);
   qt[Q::cost] = dt * c.cost;
   double D[NV], lu[NV];
 AGX_UNROLL_NV
@@ -338,6 +346,26 @@ AGX_UNROLL_NV
         hqv += tq[l][i] * dtv;
         hvv += tv[l][i] * dtv;
       }
+      if constexpr (GEN) {
+        // general rows (agx_general.hpp): Lxu = [Lqu; 0], dense Lqv / Lvv:
+        //   Hxx += Lxu taux + taux' Lxu',  Hxw += Lxu M
+        double lt_ij = 0.0, lt_ji = 0.0, ltv = 0.0, lm = 0.0;
+AGX_UNROLL_NV
+        for (int l = 0; l < NV; ++l) {
+          lt_ij += g.Lqu[i][l] * tq[l][j];
+          lt_ji += g.Lqu[j][l] * tq[l][i];
+          ltv += g.Lqu[i][l] * tv[l][j];
+          lm += g.Lqu[i][l] * M[l][j];
+        }
+        hqq += dt * (lt_ij + lt_ji);
+        hqv += dt * (g.Lqv[i][j] + ltv);
+        hvv += dt * g.Lvvd[i][j];
+        hqw += dt * lm;
+        double *ag = auxg + ((long long)b * (T + 1) + t) * (3 * A::B2);
+        ag[i * A::LD + j] = dt * g.Lqv[i][j];
+        ag[A::B2 + i * A::LD + j] = dt * g.Lvvd[i][j];
+        ag[2 * A::B2 + i * A::LD + j] = dt * g.Lqu[i][j];
+      }
       qt[Q::Hww + i * Q::LD + j] = hww;
       qt[Q::Hqw + i * Q::LD + j] = hqw;
       qt[Q::Hvw + i * Q::LD + j] = hvw;
@@ -351,18 +379,20 @@ AGX_UNROLL_NV
   }
 }
 
-template <int NV, bool CHAIN>
+template <int NV, bool CHAIN, bool GEN = false>
 __global__ void __launch_bounds__(64) k_calc_qp(const DevModel *__restrict__ mp, const DevOcp *__restrict__ op,
                                                 const double *__restrict__ dts, const double *__restrict__ xs,
                                                 const double *__restrict__ us, RefView rv, double *__restrict__ qts,
-                                                double *__restrict__ auxs, const DevState *__restrict__ st) {
-  calc_qp_body<NV, CHAIN>((long long)blockIdx.x * blockDim.x + threadIdx.x, mp, op, dts, xs, us, rv, qts, auxs, st);
+                                                double *__restrict__ auxs, const DevState *__restrict__ st,
+                                                double *__restrict__ auxg = nullptr) {
+  calc_qp_body<NV, CHAIN, GEN>((long long)blockIdx.x * blockDim.x + threadIdx.x, mp, op, dts, xs, us, rv, qts, auxs, st, auxg);
 }
 
-template <int NV, bool CHAIN>
+template <int NV, bool CHAIN, bool GEN = false>
 __device__ __forceinline__ void calc_qp_term_body(const int b, const DevModel *__restrict__ mp, const DevOcp *__restrict__ op,
                                                   const double *__restrict__ xs, const RefView &rv, double *__restrict__ qts,
-                                                  double *__restrict__ auxs, const DevState *__restrict__ st) {
+                                                  double *__restrict__ auxs, const DevState *__restrict__ st,
+                                                  double *__restrict__ auxg = nullptr) {
   constexpr int NX = 2 * NV;
   typedef QT<NV> Q;
   typedef AUX<NV> A;
@@ -381,6 +411,8 @@ __device__ __forceinline__ void calc_qp_term_body(const int b, const DevModel *_
   kinematics<NV, CHAIN>(m, x, k);
   CostAcc<NV> c;
   node_costs<NV, CHAIN, true, true>(m, o.rows[1], k, x, nullptr, ref_at(rv, b, T, T), frames_at(rv, b, T, T), c);
+  CostGen<NV> g;
+  if constexpr (GEN) node_costs_general<NV, CHAIN, true, true>(m, o.rows[1], k, x, nullptr, ref_at(rv, b, T, T), frames_at(rv, b, T, T), c, g);
   qt[Q::cost] = c.cost;
 AGX_UNROLL_NV
   for (int i = 0; i < NV; ++i) {
@@ -395,8 +427,14 @@ AGX_UNROLL_NV
 AGX_UNROLL_NV
     for (int j = 0; j < NV; ++j) {
       qt[Q::Hqq + i * Q::LD + j] = c.Lqq[i][j];
-      qt[Q::Hqv + i * Q::LD + j] = 0.0;
-      qt[Q::Hvv + i * Q::LD + j] = (i == j) ? c.Lvv[i] : 0.0;
+      qt[Q::Hqv + i * Q::LD + j] = GEN ? g.Lqv[i][j] : 0.0;
+      qt[Q::Hvv + i * Q::LD + j] = ((i == j) ? c.Lvv[i] : 0.0) + (GEN ? g.Lvvd[i][j] : 0.0);
+      if constexpr (GEN) {
+        double *ag = auxg + ((long long)b * (T + 1) + T) * (3 * A::B2);
+        ag[i * A::LD + j] = g.Lqv[i][j];
+        ag[A::B2 + i * A::LD + j] = g.Lvvd[i][j];
+        ag[2 * A::B2 + i * A::LD + j] = 0.0;
+      }
       qt[Q::Hqw + i * Q::LD + j] = 0.0;
       qt[Q::Hvw + i * Q::LD + j] = 0.0;
       qt[Q::Hww + i * Q::LD + j] = 0.0;
@@ -408,11 +446,12 @@ AGX_UNROLL_NV
   }
 }
 
-template <int NV, bool CHAIN>
+template <int NV, bool CHAIN, bool GEN = false>
 __global__ void __launch_bounds__(64) k_calc_qp_term(const DevModel *__restrict__ mp, const DevOcp *__restrict__ op,
                                                      const double *__restrict__ xs, RefView rv, double *__restrict__ qts,
-                                                     double *__restrict__ auxs, const DevState *__restrict__ st) {
-  calc_qp_term_body<NV, CHAIN>(blockIdx.x * blockDim.x + threadIdx.x, mp, op, xs, rv, qts, auxs, st);
+                                                     double *__restrict__ auxs, const DevState *__restrict__ st,
+                                                     double *__restrict__ auxg = nullptr) {
+  calc_qp_term_body<NV, CHAIN, GEN>(blockIdx.x * blockDim.x + threadIdx.x, mp, op, xs, rv, qts, auxs, st, auxg);
 }
 
 // one-lane derivative pass of both node types in one launch (large models: the terminal nodes would
@@ -827,7 +866,7 @@ AGX_UNROLL_NV
 // mode bit2: timing mode (no convergence exit, nothing committed) so that launches are repeatable.
 // mode bit3: convergence test only; the line search is done node-parallel by k_ls_trial / k_ls_accept (large models).
 // ---------------------------------------------------------------------------
-template <int NV, bool CHAIN>
+template <int NV, bool CHAIN, bool GEN = false>
 __global__ void __launch_bounds__(128) k_step(const DevModel *__restrict__ mp, const DevOcp *__restrict__ op,
                                               const double *__restrict__ dts, double *__restrict__ xs,
                                               double *__restrict__ us, RefView rv, const double *__restrict__ qts,
@@ -900,7 +939,7 @@ AGX_UNROLL_NV
 AGX_UNROLL_NV
         for (int i = 0; i < NU; ++i) u[i] = U[(long long)t * NU + i] + alpha * DU[(long long)t * NU + i];
         double xn[NX], c;
-        node_calc_running<NV, CHAIN>(m, o.rows[0], dts[t], x, u, ref_at(rv, b, t, T), frames_at(rv, b, t, T), xn, &c);
+        node_calc_running<NV, CHAIN, GEN>(m, o.rows[0], dts[t], x, u, ref_at(rv, b, t, T), frames_at(rv, b, t, T), xn, &c);
         double g = 0.0;
 AGX_UNROLL_NV
         for (int i = 0; i < NX; ++i)
@@ -909,7 +948,7 @@ AGX_UNROLL_NV
         if (o.has_con) part += o.mu_con * constraint_violation<NV, CHAIN>(m, o.cons[0], x, u);
       } else {
         double c;
-        node_calc_terminal<NV, CHAIN>(m, o.rows[1], x, ref_at(rv, b, T, T), frames_at(rv, b, T, T), &c);
+        node_calc_terminal<NV, CHAIN, GEN>(m, o.rows[1], x, ref_at(rv, b, T, T), frames_at(rv, b, T, T), &c);
         part += c;
         if (o.has_con) part += o.mu_con * constraint_violation<NV, CHAIN>(m, o.cons[1], x, x);
       }
@@ -1284,6 +1323,26 @@ __global__ void k_residuals(const DevModel *__restrict__ mp, const DevOcp *__res
     double ca[3], cb[3], n[3];
     int ja, jb;
     dst[0] = collision_distance<NV>(m, k, rows.frame[row], rows.frame_b[row], ca, cb, n, &ja, &jb);
+  } else if (kind == AGX_RES_FRAME_VELOCITY) {
+    double xl[NX];
+    for (int e = 0; e < NX; ++e) xl[e] = x[e];
+    Kin<NV> k;
+    kinematics<NV, CHAIN>(m, xl, k);
+    const int *fr = frames_at(rv, b, t, T);
+    int frame = fr ? fr[row] : -1;
+    if (frame < 0) frame = rows.frame[row];
+    double vel[6];
+    frame_velocity<NV, CHAIN, false>(m, k, frame, rows.frame_b[row], xl + NV, vel, nullptr, nullptr);
+    for (int e = 0; e < 6; ++e) dst[e] = vel[e] - rr[e];
+  } else if (kind == AGX_RES_CONTROL_GRAV) {
+    double xl[NX], g0[NV], zero[NV], M0[NV][NV];
+    for (int e = 0; e < NX; ++e) xl[e] = x[e];
+    for (int e = 0; e < NV; ++e) zero[e] = 0.0;
+    Kin<NV> k;
+    kinematics<NV, CHAIN>(m, xl, k);
+    Dyn<NV> d0;
+    bias_and_inertia<NV, CHAIN>(m, k, zero, d0, g0, M0);
+    for (int i = 0; i < NU; ++i) dst[i] = u[i] - g0[i];
   } else {
     for (int i = 0; i < nr; ++i) dst[i] = 0.0;
   }

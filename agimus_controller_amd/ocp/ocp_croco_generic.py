@@ -354,6 +354,10 @@ class ResidualModelFrameVelocity(_FrameResidual):
     def reference(self, data):
         return np.zeros(6) if self.pref is None else np.asarray(self.pref, dtype=float).reshape(6)
 
+    def reference_frame_id(self) -> int:
+        """pinocchio.ReferenceFrame as the row's second index: 0 WORLD, 1 LOCAL, 2 LOCAL_WORLD_ALIGNED."""
+        return _REFERENCE_FRAMES.index(self.reference_frame)
+
     def update(self, data, pt):
         vels = pt.point.end_effector_velocities
         assert len(vels) == 1, f"ResidualModelFrameVelocity requires exactly one end-effector velocity, current is {vels}."
@@ -595,8 +599,6 @@ class DifferentialActionModelFreeFwdDynamics(DifferentialActionModel):
         for item in self.costs:
             res, act = item.cost.residual, item.cost.activation
             kind = res.kind
-            if kind in (_abi.RES_CONTROL_GRAV, _abi.RES_FRAME_VELOCITY):
-                raise NotImplementedError(f"cost '{item.name}': {type(res).__name__} is not implemented on the HIP path yet")
             act_kind = _abi.ACT_WEIGHTED_QUAD if act is None else act.kind
             alpha = 1.0 if act is None or act_kind == _abi.ACT_WEIGHTED_QUAD else act.alpha_value
             if act_kind != _abi.ACT_WEIGHTED_QUAD and kind != _abi.RES_COLLISION:
@@ -606,8 +608,9 @@ class DifferentialActionModelFreeFwdDynamics(DifferentialActionModel):
                 rows.append(_abi.RowSpec(kind=kind, activation=act_kind, active=bool(item.active), frame=fa, frame_b=fb,
                                          alpha=alpha, name=item.name, weight=float(item.weight)))  # fmt: skip
                 continue
-            rows.append(_abi.RowSpec(kind=kind, activation=act_kind, active=bool(item.active),
-                                     frame=res.frame(data), alpha=alpha, name=item.name, weight=float(item.weight)))  # fmt: skip
+            frame_b = res.reference_frame_id() if kind == _abi.RES_FRAME_VELOCITY else 0
+            rows.append(_abi.RowSpec(kind=kind, activation=act_kind, active=bool(item.active), frame=res.frame(data),
+                                     frame_b=frame_b, alpha=alpha, name=item.name, weight=float(item.weight)))  # fmt: skip
         return rows
 
 

@@ -466,6 +466,51 @@ template <int N> void log3_residual(const Dual<N> *R, Dual<N> *r) {
   }
 }
 
+// Velocity of a frame (pinocchio::getFrameVelocity): [linear; angular] in
+//   type 0 WORLD                the spatial velocity seen at the world origin, world axes
+//   type 1 LOCAL                velocity of the frame origin / angular velocity in the frame's own axes
+//   type 2 LOCAL_WORLD_ALIGNED  velocity of the frame origin / angular velocity in world axes
+// by the forward recursion  w_i = w_p + z_i qd_i,  v_i = v_p + w_p x (p_i - p_p)  in world coordinates.
+template <class S> void frame_velocity(const Model &m, int frame, int type, const S *q, const S *qd, S *out6) {
+  static thread_local std::vector<S> Rw, pw, wv, vv;
+  const int nv = m.nv;
+  Rw.resize(9 * nv); pw.resize(3 * nv); wv.resize(3 * nv); vv.resize(3 * nv);
+  joint_placements(m, q, Rw.data(), pw.data());
+  for (int i = 0; i < nv; ++i) {
+    const int par = m.parent[i];
+    S wp[3] = {S(0.0), S(0.0), S(0.0)}, vp[3] = {S(0.0), S(0.0), S(0.0)}, d[3];
+    for (int k = 0; k < 3; ++k) d[k] = pw[3 * i + k];
+    if (par >= 0)
+      for (int k = 0; k < 3; ++k) { wp[k] = wv[3 * par + k]; vp[k] = vv[3 * par + k]; d[k] = pw[3 * i + k] - pw[3 * par + k]; }
+    S c[3];
+    cross(wp, d, c);
+    const double *ax = &m.axis[3 * i];
+    S axs[3] = {S(ax[0]), S(ax[1]), S(ax[2])}, z[3];
+    matvec3(&Rw[9 * i], axs, z);
+    for (int k = 0; k < 3; ++k) { vv[3 * i + k] = vp[k] + c[k]; wv[3 * i + k] = wp[k] + z[k] * qd[i]; }
+  }
+  S R[9], p[3];
+  frame_placement(m, frame, q, R, p);  // (recomputes the joint placements; the checker favours clarity)
+  const int par = m.frame_parent[frame];
+  S w[3] = {S(0.0), S(0.0), S(0.0)}, v[3] = {S(0.0), S(0.0), S(0.0)};
+  if (par >= 0) {
+    S d[3], c[3];
+    for (int k = 0; k < 3; ++k) { w[k] = wv[3 * par + k]; d[k] = p[k] - pw[3 * par + k]; }
+    cross(w, d, c);
+    for (int k = 0; k < 3; ++k) v[k] = vv[3 * par + k] + c[k];
+  }
+  if (type == 0) {
+    S c[3];
+    cross(w, p, c);  // v_O = v_f - w x p_f
+    for (int k = 0; k < 3; ++k) { out6[k] = v[k] - c[k]; out6[3 + k] = w[k]; }
+  } else if (type == 1) {
+    matTvec3(R, v, out6);
+    matTvec3(R, w, out6 + 3);
+  } else {
+    for (int k = 0; k < 3; ++k) { out6[k] = v[k]; out6[3 + k] = w[k]; }
+  }
+}
+
 // ---------------------------------------------------------------------------
 // Closest points of two segments a0 + s (a1 - a0), b0 + t (b1 - b0), s, t in [0, 1]
 // (Ericson, Real-Time Collision Detection 5.1.9 -- the capsule/capsule narrow phase of coal that
@@ -670,6 +715,13 @@ void eval_residual(const Model &m, int kind, int frame, int frame_b, const doubl
         S Rrel[9];
         matmul3(Rt, R, Rrel);
         log3_residual(Rrel, r);
+      } break;
+      case AGX_RES_FRAME_VELOCITY: {
+        // crocoddyl ResidualModelFrameVelocity (ocp_croco_generic.py:360-432): frame velocity in the
+        // chosen reference frame (frame_b: 0 WORLD, 1 LOCAL, 2 LOCAL_WORLD_ALIGNED) minus the reference twist
+        S vf[6];
+        frame_velocity(m, frame, frame_b, q, x + nv, vf);
+        for (int k = 0; k < 6; ++k) r[k] = vf[k] - rref[k];
       } break;
       case AGX_RES_COLLISION:
         // colmpc.ResidualDistanceCollision (ocp_croco_generic.py:524-533): signed distance of the pair

@@ -1,0 +1,139 @@
+"""ResidualModelControlGrav and ResidualModelFrameVelocity (ocp_croco_generic.py:186-194, 360-432): cost rows
+with dense cross Hessians (Lxu, Lqv, dense Lvv) that run on the one-lane GEN kernels (agx_general.hpp).
+No fixture of the reference exercises them: the CPU checker differentiates them automatically and is
+checked here against finite differences and closed forms; the HIP path is checked against the checker."""
+import numpy as np
+import pytest
+
+from agimus_controller_amd import _abi, workloads
+from agimus_controller_amd.factory import robot_tables as rt
+from oracle.oracle import Oracle
+
+
+def general_problem(table, T, B, seed, ref_frame=0, with_grav=True):
+    tcp = table.frame_id("panda_hand_tcp") if "panda_hand_tcp" in table.frame_names else len(table.frame_names) - 1
+    running = [_abi.RowSpec(_abi.RES_CONTROL, name="control_reg"), _abi.RowSpec(_abi.RES_STATE, name="state_reg"),
+               _abi.RowSpec(_abi.RES_FRAME_PLACEMENT, frame=tcp, name="goal_tracking"),
+               _abi.RowSpec(_abi.RES_FRAME_VELOCITY, frame=tcp, frame_b=ref_frame, name="ee_velocity")]
+    if with_grav:
+        running.append(_abi.RowSpec(_abi.RES_CONTROL_GRAV, name="ctrl_grav"))
+    terminal = [_abi.RowSpec(_abi.RES_STATE, name="state_reg"), _abi.RowSpec(_abi.RES_FRAME_VELOCITY, frame=tcp, frame_b=ref_frame, name="ee_velocity")]
+    nv = table.nv
+    po = _abi.PackedOcp(nv, [0.01] * T, running, terminal)
+    rng = np.random.default_rng(seed)
+    ref = po.new_ref_tile(B)
+    qc = rng.uniform(-1.0, 1.0, (B, 1, nv))
+    for term, rows in ((False, running), (True, terminal)):
+        n = 1 if term else T
+        for i, r in enumerate(rows):
+            wi, rr, aw = po.row_view(ref, term, i)
+            wi[...] = rng.uniform(0.5, 2.0, (B, n))
+            aw[...] = rng.uniform(0.1, 2.0, aw.shape)
+            if r.kind == _abi.RES_STATE:
+                rr[..., :nv] = qc + rng.normal(0, 0.05, (B, n, nv))
+                rr[..., nv:] = rng.normal(0, 0.1, (B, n, nv))
+            elif r.kind == _abi.RES_CONTROL:
+                rr[...] = rng.normal(0, 2.0, rr.shape)
+                aw[...] = rng.uniform(1e-3, 1e-2, aw.shape)
+            elif r.kind == _abi.RES_CONTROL_GRAV:
+                aw[...] = rng.uniform(1e-3, 1e-2, aw.shape)
+            elif r.kind == _abi.RES_FRAME_VELOCITY:
+                rr[...] = rng.normal(0, 0.3, rr.shape)
+            elif r.kind == _abi.RES_FRAME_PLACEMENT:
+                for b in range(B):
+                    for t in range(n):
+                        rr[b, t, :9] = rt.rpy(*rng.uniform(-1.0, 1.0, 3)).reshape(9)
+                        rr[b, t, 9:] = rng.uniform(-0.5, 0.5, 3) + np.array([0.3, 0.0, 0.5])
+    x0 = np.concatenate([qc[:, 0, :] + rng.normal(0, 0.02, (B, nv)), rng.normal(0, 0.3, (B, nv))], axis=1)
+    xs = np.repeat(x0[:, None, :], T + 1, axis=1) + rng.normal(0, 0.01, (B, T + 1, 2 * nv))
+    us = rng.normal(0, 1.0, (B, T, nv))
+    return po, ref, x0, xs, us
+
+
+@pytest.mark.parametrize("ref_frame", [0, 1, 2])
+def test_frame_velocity_value_is_the_jacobian_times_the_joint_velocity(ref_frame):
+    """v_frame in LOCAL_WORLD_ALIGNED = d(frame position)/dq * qd for the linear part; WORLD and LOCAL follow from it."""
+    table = rt.panda_table(0.1)
+    tcp = table.frame_id("panda_hand_tcp")
+    rows = [_abi.RowSpec(_abi.RES_FRAME_VELOCITY, frame=tcp, frame_b=ref_frame)]
+    po = _abi.PackedOcp(7, [0.01], rows, rows)
+    o = Oracle(table, po, 1)
+    rng = np.random.default_rng(2)
+    q, qd = rng.uniform(-1, 1, 7), rng.uniform(-1, 1, 7)
+    ref = po.new_ref_tile(1)[0, 0]
+    _, _, res = o.node_calc(True, 0.0, np.concatenate([q, qd]), None, ref)
+    h = 1e-6
+    M0 = o.frame_placement(tcp, q[None])[0]
+    Mp, Mm = o.frame_placement(tcp, (q + h * qd)[None])[0], o.frame_placement(tcp, (q - h * qd)[None])[0]
+    R0, p0 = M0[:9].reshape(3, 3), M0[9:]
+    v_lin = (Mp[9:] - Mm[9:]) / (2 * h)
+    W = ((Mp[:9] - Mm[:9]) / (2 * h)).reshape(3, 3) @ R0.T
+    w = np.array([W[2, 1], W[0, 2], W[1, 0]])
+    want = {0: np.concatenate([v_lin - np.cross(w, p0), w]), 1: np.concatenate([R0.T @ v_lin, R0.T @ w]), 2: np.concatenate([v_lin, w])}[ref_frame]
+    np.testing.assert_allclose(res[:6], want, atol=2e-8)
+
+
+def test_control_grav_residual_is_u_minus_gravity_torque():
+    table = rt.panda_table(0.1)
+    rows = [_abi.RowSpec(_abi.RES_CONTROL_GRAV)]
+    po = _abi.PackedOcp(7, [0.01], rows, [])
+    o = Oracle(table, po, 1)
+    rng = np.random.default_rng(3)
+    q, qd, u = rng.uniform(-1, 1, 7), rng.uniform(-1, 1, 7), rng.uniform(-5, 5, 7)
+    _, cost, res = o.node_calc(False, 0.01, np.concatenate([q, qd]), u, po.new_ref_tile(1)[0, 0])
+    g = o.rnea(q[None], np.zeros((1, 7)), np.zeros((1, 7))).reshape(7)
+    np.testing.assert_allclose(res[:7], u - g, atol=1e-12)
+    assert cost == pytest.approx(0.01 * 0.5 * np.sum((u - g) ** 2), rel=1e-12)
+
+
+def test_checker_gradients_of_general_rows_match_finite_differences():
+    table = rt.panda_table(0.1)
+    po, ref, x0, xs, us = general_problem(table, 3, 2, seed=5, ref_frame=1)
+    o = Oracle(table, po, 2)
+    sl = _abi.tile_slices(7)
+    x, u, r = xs[0, 1], us[0, 1], ref[0, 1]
+    tile, _, _ = o.node_calc_diff(False, 0.01, x, u, r)
+    h = 1e-6
+    for i in range(14):
+        e = np.zeros(14); e[i] = h
+        fd = (o.node_calc(False, 0.01, x + e, u, r)[1] - o.node_calc(False, 0.01, x - e, u, r)[1]) / (2 * h)
+        assert tile[sl["Lx"]][i] == pytest.approx(fd, rel=2e-5, abs=1e-8)
+    for i in range(7):
+        e = np.zeros(7); e[i] = h
+        fd = (o.node_calc(False, 0.01, x, u + e, r)[1] - o.node_calc(False, 0.01, x, u - e, r)[1]) / (2 * h)
+        assert tile[sl["Lu"]][i] == pytest.approx(fd, rel=2e-5, abs=1e-8)
+    assert np.abs(tile[sl["Lxu"]]).max() > 1e-6  # ControlGrav couples q and u
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ref_frame", [0, 1, 2])
+@pytest.mark.parametrize("model", ["panda", "chain4"])
+def test_hip_general_rows_tiles_direction_and_solve(hip_backend, model, ref_frame):
+    table = rt.panda_table(0.1) if model == "panda" else rt.chain_table(4, seed=7)
+    B, T = 4, 10
+    po, ref, x0, xs, us = general_problem(table, T, B, seed=11 + ref_frame, ref_frame=ref_frame)
+    h, o = hip_backend.HipOcp(table, po, B), Oracle(table, po, B)
+    h.set_refs(ref)
+    xs[:, 0] = x0
+    h.upload_x0(x0)
+    h.upload_warmstart(xs, us)
+    got, want = h.calc_diff(), o.calc_diff(ref, None, xs, us)
+    for field, s in _abi.tile_slices(table.nv).items():
+        scale = max(np.abs(want[..., s]).max(), 1e-300)
+        assert np.abs(got[..., s] - want[..., s]).max() <= 1e-10 * scale + 1e-13, field
+    K, k, dx, du, kkt = h.direction()
+    Ko, ko, dxo, duo, kkto = o.direction(want)
+    assert np.abs(dx - dxo).max() <= 1e-8 * np.abs(dxo).max() and np.abs(du - duo).max() <= 1e-8 * np.abs(duo).max()
+    assert np.abs(K - Ko).max() <= 1e-7 * np.abs(Ko).max()
+    np.testing.assert_allclose(kkt, kkto, rtol=1e-6)
+    r_h = h.solve(x0, xs, us, 12)
+    r_o = o.solve(ref, None, x0, xs, us, 12, nthreads=4)
+    np.testing.assert_array_equal(r_h[3]["iter"], r_o[3]["iter"])
+    assert np.abs(r_h[0] - r_o[0]).max() <= 1e-8 * np.abs(r_o[0]).max()
+    assert np.abs(r_h[2] - r_o[2]).max() <= 1e-6 * np.abs(r_o[2]).max()
+    # residual read-back of the velocity row
+    res = h.residuals(3)
+    _, _, rvec = o.node_calc(False, 0.01, r_h[0][0, 2], r_h[1][0, 2], ref[0, 2])
+    off = table.nv + 2 * table.nv + 6
+    np.testing.assert_allclose(res[0, 2], rvec[off:off + 6], atol=1e-10)
+    h.close()
