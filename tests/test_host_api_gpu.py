@@ -379,3 +379,55 @@ def test_resident_window_with_nonuniform_horizon_indexes(hip_backend):
     with pytest.raises(backend.HipError, match="increasing"):
         hb.set_horizon_indexes([0, 2, 1] + list(range(3, T + 1)))
     hb.close()
+
+
+def test_control_grav_and_frame_velocity_rows_from_yaml(hip_backend):
+    """ResidualModelControlGrav + ResidualModelFrameVelocity through the YAML schema and the update chain
+    (ocp_croco_generic.py:186-194, 360-395): the effort weights feed the gravity-compensated control
+    row, the end-effector twist and its weights feed the velocity row; result equals the checker's."""
+    import io
+
+    yaml_text = """
+running_model:
+  class: IntegratedActionModelEuler
+  differential:
+    class: DifferentialActionModelFreeFwdDynamics
+    costs:
+      - {name: ctrl_grav, update: true, weight: 1.0, cost: {class: CostModelResidual, residual: {class: ResidualModelControlGrav},
+         activation: {class: ActivationModelWeightedQuad, weights: 1.0}}}
+      - {name: state_reg, update: true, weight: 1.0, cost: {class: CostModelResidual, residual: {class: ResidualModelState},
+         activation: {class: ActivationModelWeightedQuad, weights: 1.0}}}
+      - {name: ee_vel, update: true, weight: 1.0, cost: {class: CostModelResidual,
+         residual: {class: ResidualModelFrameVelocity, id: panda_hand_tcp, reference_frame: LOCAL_WORLD_ALIGNED},
+         activation: {class: ActivationModelWeightedQuad, weights: 1.0}}}
+terminal_model:
+  class: IntegratedActionModelEuler
+  differential:
+    class: DifferentialActionModelFreeFwdDynamics
+    costs:
+      - {name: state_reg, update: true, weight: 1.0, cost: {class: CostModelResidual, residual: {class: ResidualModelState},
+         activation: {class: ActivationModelWeightedQuad, weights: 1.0}}}
+"""
+    T, dt = 12, 0.01
+    rm = panda_robot_models(0.1)
+    params = OCPParamsBaseCroco(dt=dt, horizon_size=T, dt_factor_n_seq=DTFactorsNSeq(factors=[1], n_steps=[T]), solver_iters=30, callbacks=False)
+    ocp = OCPCrocoGeneric(rm, params, io.StringIO(yaml_text))
+    rows = ocp.problem.running
+    assert [r.kind for r in rows] == [_abi.RES_CONTROL_GRAV, _abi.RES_STATE, _abi.RES_FRAME_VELOCITY] and rows[2].frame_b == 2
+    twist = np.array([0.05, -0.02, 0.03, 0.0, 0.0, 0.1])
+    pt = WeightedTrajectoryPoint(
+        TrajectoryPoint(robot_configuration=PANDA_Q0, robot_velocity=np.zeros(7), robot_effort=np.zeros(7),
+                        end_effector_velocities={"panda_hand_tcp": twist}),
+        TrajectoryPointWeights(w_robot_configuration=1.0 * np.ones(7), w_robot_velocity=0.1 * np.ones(7),
+                               w_robot_effort=1e-3 * np.ones(7), w_end_effector_velocities={"panda_hand_tcp": 5.0 * np.ones(6)}))
+    ocp.set_reference_weighted_trajectory([pt] * (T + 1))
+    x0 = np.concatenate([PANDA_Q0, np.zeros(7)])
+    ocp.solve(x0, [x0] * (T + 1), [np.zeros(7)] * T)
+    o = Oracle(rm.table, ocp.problem, 1)
+    xs_o, us_o, K_o, st_o = o.solve(ocp._ref_tile, ocp._frames, x0[None], np.tile(x0, (1, T + 1, 1)), np.zeros((1, T, 7)), 30)
+    assert ocp.debug_data.nb_iter == st_o["iter"][0]
+    np.testing.assert_allclose(np.array(ocp.ocp_results.states), xs_o[0], rtol=1e-7, atol=1e-9)
+    np.testing.assert_allclose(np.array(ocp.ocp_results.feed_forward_terms), us_o[0], rtol=1e-6, atol=1e-8)
+    # gravity compensation: the solution's torques stay near g(q) and the end effector picks up the twist
+    g = ocp._hip.rnea(PANDA_Q0, np.zeros(7), np.zeros(7))[0]
+    assert np.abs(np.array(ocp.ocp_results.feed_forward_terms)[0] - g).max() < 0.5 * np.abs(g).max()
