@@ -60,6 +60,7 @@ struct DevOcp {
   DevCons cons[2];
   int max_qp, has_con;
   double eps_abs, eps_rel;
+  int use_filter, pad2;  // SolverCSQP.use_filter_line_search (ocp_param_base.py:64)
 };
 
 #define AGX_DEV __device__ __forceinline__

@@ -928,7 +928,7 @@ __global__ void __launch_bounds__(128) k_step(const DevModel *__restrict__ mp, c
   bool ok = false;
   for (int n = 0; n < 10; ++n, alpha *= 0.5) {
     used = alpha;
-    double part = 0.0;
+    double pc = 0.0, pg = 0.0, pv = 0.0;  // cost, gap norm, constraint violation of the trial
     for (int r = 0; r < NPT; ++r) {
       const int t = tid + r * blockDim.x;
       if (t > T) break;
@@ -944,22 +944,36 @@ AGX_UNROLL_NV
 AGX_UNROLL_NV
         for (int i = 0; i < NX; ++i)
           g += fabs(xn[i] - (X[(long long)(t + 1) * NX + i] + alpha * DX[(long long)(t + 1) * NX + i]));
-        part += c + o.mu_dyn * g;
-        if (o.has_con) part += o.mu_con * constraint_violation<NV, CHAIN>(m, o.cons[0], x, u);
+        pc += c; pg += g;
+        if (o.has_con) pv += constraint_violation<NV, CHAIN>(m, o.cons[0], x, u);
       } else {
         double c;
         node_calc_terminal<NV, CHAIN, GEN>(m, o.rows[1], x, ref_at(rv, b, T, T), frames_at(rv, b, T, T), &c);
-        part += c;
-        if (o.has_con) part += o.mu_con * constraint_violation<NV, CHAIN>(m, o.cons[1], x, x);
+        pc += c;
+        if (o.has_con) pv += constraint_violation<NV, CHAIN>(m, o.cons[1], x, x);
       }
     }
-    part = wave_sum(part);
-    if ((tid & 63) == 0) red[tid >> 6] = part;
-    __syncthreads();
-    if (tid == 0) {
-      double tot = 0.0;
-      for (int w = 0; w < nw; ++w) tot += red[w];
-      flag = (merit > tot) ? 1 : 0;
+    if (o.use_filter) {
+      // filter line search with the solver's default filter size 1 (SolverCSQP::solve): the trial is
+      // rejected only if it is no better than the current point in cost AND gaps AND constraints
+      pc = wave_sum(pc); pg = wave_sum(pg); pv = wave_sum(pv);
+      if ((tid & 63) == 0) { red[tid >> 6] = pc; red[2 + (tid >> 6)] = pg; red[4 + (tid >> 6)] = pv; }
+      __syncthreads();
+      if (tid == 0) {
+        double tc = 0.0, tg = 0.0, tv = 0.0;
+        for (int w = 0; w < nw; ++w) { tc += red[w]; tg += red[2 + w]; tv += red[4 + w]; }
+        const bool worse = (S.cost <= tc) && (S.gap <= tg) && (S.con <= tv);
+        flag = worse ? 0 : 1;
+      }
+    } else {
+      double part = wave_sum(pc + o.mu_dyn * pg + o.mu_con * pv);
+      if ((tid & 63) == 0) red[tid >> 6] = part;
+      __syncthreads();
+      if (tid == 0) {
+        double tot = 0.0;
+        for (int w = 0; w < nw; ++w) tot += red[w];
+        flag = (merit > tot) ? 1 : 0;
+      }
     }
     __syncthreads();
     ok = flag != 0;

@@ -50,8 +50,6 @@ class OCPBaseCroco(OCPBase):
             eps_rel=ocp_params.eps_rel,
             use_filter_line_search=bool(ocp_params.use_filter_line_search),
         )
-        if ocp_params.use_filter_line_search:
-            raise NotImplementedError("use_filter_line_search=True: only the merit line search (the reference default) is implemented")
         self._hip = backend.HipOcp(self._table, self._packed, batch=1, device=device)
         self._ref_tile = self._packed.new_ref_tile(1)
         self._frames = self._packed.default_frames(1)

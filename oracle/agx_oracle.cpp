@@ -574,6 +574,7 @@ struct Ocp {
   double tol = 1e-3, mu_dyn = 10.0, mu_con = 10.0;
   int max_qp = 200;
   double eps_abs = 1e-6, eps_rel = 0.0;
+  bool use_filter = false;  // SolverCSQP.use_filter_line_search
   // ConstraintListItem rows (lower <= r(x,u) <= upper), 0 running / 1 terminal
   struct ConRow { int kind, frame, frame_b; std::vector<double> ref, lower, upper; };
   std::vector<ConRow> cons[2];
@@ -636,6 +637,7 @@ void copy_ocp(const agx_ocp_desc *d, int nv, Ocp &o) {
   o.max_qp = d->max_qp_iters;
   o.eps_abs = d->eps_abs;
   o.eps_rel = d->eps_rel;
+  o.use_filter = d->use_filter_line_search != 0;
   for (int s = 0; s < 2; ++s) {
     const int n = s == 0 ? d->n_running_constraints : d->n_terminal_constraints;
     const agx_constraint_row *rows = s == 0 ? d->running_constraints : d->terminal_constraints;
@@ -1309,7 +1311,11 @@ void solve_one(const Model &m, const Ocp &o, const double *ref, const int32_t *f
         if (has_con) con_try += node_constraint_violation(m, o, term, &w.xs_try[(size_t)t * nx], term ? nullptr : &w.us_try[(size_t)t * nu]);
       }
       const double merit_try = cost_try + o.mu_dyn * gap_try + o.mu_con * con_try;
-      if (merit > merit_try) { accepted = true; break; }
+      if (o.use_filter) {
+        // filter of size 1 (the solver's default): rejected only if no better in cost AND gaps AND constraints
+        const bool worse = (cost <= cost_try) && (gap1 <= gap_try) && (con1 <= con_try);
+        if (!worse) { accepted = true; break; }
+      } else if (merit > merit_try) { accepted = true; break; }
     }
     const bool last = (it + 1 == max_iter);
     if (last || !accepted) final_gains();  // gains belong to the point the direction was computed at

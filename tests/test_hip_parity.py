@@ -346,3 +346,22 @@ def test_inactive_and_zero_weight_rows(hip_backend, panda):
     assert rel(r1[0], ro[0]) < 1e-9 and rel(r2[0], ro[0]) < 1e-9
     np.testing.assert_array_equal(r1[3]["iter"], ro[3]["iter"])
     h1.close(); h2.close()
+
+
+@pytest.mark.gpu
+def test_filter_line_search_matches_the_checker(hip_backend, panda):
+    """use_filter_line_search = True (ocp_param_base.py:64, SolverCSQP filter of size 1): accept a step unless
+    it is no better than the current point in cost, gap norm and constraint norm at once."""
+    tcp = panda.frame_id("panda_hand_tcp")
+    B, T = 5, 20
+    po0, ref, x0, xs, us = workloads.random_goal_problem(panda, T, 0.01, B, seed=77, frame=tcp)
+    po = _abi.PackedOcp(7, [0.01] * T, po0.running, po0.terminal, use_filter_line_search=True)
+    h, o = hip_backend.HipOcp(panda, po, B), Oracle(panda, po, B)
+    h.set_refs(ref)
+    r_h = h.solve(x0, xs, us, 15)
+    r_o = o.solve(ref, None, x0, xs, us, 15, nthreads=4)
+    np.testing.assert_array_equal(r_h[3]["iter"], r_o[3]["iter"])
+    assert rel(r_h[0], r_o[0]) < 1e-8 and rel(r_h[2], r_o[2]) < 1e-6
+    # and it is a different algorithm from the merit search on this problem or at least converges
+    assert np.all(r_h[3]["kkt"] < 1e-3) or np.all(r_h[3]["iter"] == 15)
+    h.close()
