@@ -54,6 +54,7 @@ struct agx_ocp {
   // multipliers y (persistent across solves), slack z, prox centre, per-node residual norms
   bool has_con = false;
   double *d_trial = nullptr;  // [B][T+1] merit shares of a line-search trial (large models)
+  double *d_jt = nullptr;     // large models: frame rows parked for the cooperative J'WJ, [B*T][1 + 2 (6 + 6 nv)]
   bool general = false;       // ControlGrav / FrameVelocity cost rows: one-lane GEN kernels (agx_general.hpp)
   double *d_auxg = nullptr;   // [B][T+1][3 nv 8]: Lqv | Lvvd | Lqu of every node (general problems)
   double *d_qt2 = nullptr, *d_cg = nullptr, *d_cjac = nullptr, *d_y = nullptr, *d_z = nullptr, *d_cx = nullptr, *d_admmstat = nullptr;
@@ -62,6 +63,7 @@ struct agx_ocp {
   bool lanes_ok = true;  // problem fits the LDS staging of the 8-lanes-per-node kernel
   bool speculate = true;  // AGX_SPECULATE_GAINS=0: gains sweep only on exit
   bool gains_mfma = true; // AGX_GAINS_MFMA=0: scalar K = M Kw - taux for large models
+  bool k1_fused = true;     // AGX_K1_FUSED=0: running and terminal nodes of the derivative pass as two launches (profiling)
   bool queue_ahead = true;  // AGX_QUEUE_AHEAD=0: next derivative pass only after the host saw the finished count (profiling: no empty launches)
   double *d_ref = nullptr;  // owned tile [B][T+1][stride]
   int *d_frames = nullptr;  // owned [B][T+1][AGX_MAX_ROWS]
@@ -236,7 +238,7 @@ int launch_calc_qp(agx_ocp *o, bool running_only = false, bool term_only = false
     }
     bool lanes = false;
     if constexpr (NV <= 7) lanes = CH && o->k1_lanes && o->lanes_ok;
-    if constexpr (NV <= 7) if (lanes && !term_only && !running_only) {
+    if constexpr (NV <= 7) if (lanes && o->k1_fused && !term_only && !running_only) {
       // both node types in one launch
       const int n_run = (int)((units * 8 + 63) / 64), n_term = (int)(((long long)o->B * 8 + 63) / 64);
       hipLaunchKernelGGL((agx::k_calc_qp_lj_all<NV>), dim3(n_run + n_term), dim3(64), 0, o->stream, o->d_model, o->d_ocp, o->d_dt, o->d_xs,
@@ -256,8 +258,8 @@ int launch_calc_qp(agx_ocp *o, bool running_only = false, bool term_only = false
       // large models: both node types in one launch of the one-lane kernel, then the cooperative transformation
       const long long all = units + o->B;
       hipLaunchKernelGGL((agx::k_calc_qp_all<NV, CH>), dim3((int)((all + 63) / 64)), dim3(64), 0, o->stream, o->d_model, o->d_ocp, o->d_dt,
-                         o->d_xs, o->d_us, o->rv, o->d_qt, o->d_aux, o->d_state);
-      hipLaunchKernelGGL((agx::k_transform_big<NV>), dim3((int)units), dim3(256), 0, o->stream, o->d_ocp, o->d_qt, o->d_aux, o->d_state);
+                         o->d_xs, o->d_us, o->rv, o->d_qt, o->d_aux, o->d_state, o->d_jt);
+      hipLaunchKernelGGL((agx::k_transform_big<NV>), dim3((int)units), dim3(256), 0, o->stream, o->d_ocp, o->d_qt, o->d_aux, o->d_state, o->d_jt);
       HIPCHK(hipGetLastError());
       return 0;
     }
@@ -266,7 +268,7 @@ int launch_calc_qp(agx_ocp *o, bool running_only = false, bool term_only = false
         hipLaunchKernelGGL((agx::k_calc_qp<NV, CH>), dim3((int)((units + 63) / 64)), dim3(64), 0, o->stream, o->d_model, o->d_ocp,
                            o->d_dt, o->d_xs, o->d_us, o->rv, o->d_qt, o->d_aux, o->d_state);
         if constexpr (NV > 8)  // second half for large models: the O(nv^3) transformation, one workgroup per node
-          hipLaunchKernelGGL((agx::k_transform_big<NV>), dim3((int)units), dim3(256), 0, o->stream, o->d_ocp, o->d_qt, o->d_aux, o->d_state);
+          hipLaunchKernelGGL((agx::k_transform_big<NV>), dim3((int)units), dim3(256), 0, o->stream, o->d_ocp, o->d_qt, o->d_aux, o->d_state, (const double *)nullptr);
       }
       if (!running_only)
         hipLaunchKernelGGL((agx::k_calc_qp_term<NV, CH>), dim3((o->B + 63) / 64), dim3(64), 0, o->stream, o->d_model, o->d_ocp,
@@ -674,6 +676,7 @@ int agx_ocp_create(const agx_model *m, const agx_ocp_desc *d, int batch, int dev
   if (const char *e = getenv("AGX_SPECULATE_GAINS")) o->speculate = (e[0] != '0');
   if (const char *e = getenv("AGX_GAINS_MFMA")) o->gains_mfma = (e[0] != '0');
   if (const char *e = getenv("AGX_QUEUE_AHEAD")) o->queue_ahead = (e[0] != '0');
+  if (const char *e = getenv("AGX_K1_FUSED")) o->k1_fused = (e[0] != '0');
   o->T = d->horizon; o->B = batch; o->device = device;
   o->tile = AGX_TILE_DOUBLES(o->nv);
   const int ld = o->nv <= 8 ? 8 : 32;
@@ -744,6 +747,7 @@ int agx_ocp_create(const agx_model *m, const agx_ocp_desc *d, int batch, int dev
   ALLOC(o->d_frames, B * (T + 1) * AGX_MAX_ROWS);
   ALLOC(o->d_state, B);
   ALLOC(o->d_ndone, 2);  // [0] finished instances, [1] instances whose ADMM loop has ended
+  if (o->nv > 8) ALLOC(o->d_jt, B * T * (size_t)(1 + 2 * (6 + 6 * o->nv)));
   if (o->general) ALLOC(o->d_auxg, B * (T + 1) * (size_t)(3 * o->nv * 8));
   if (o->has_con) {
     ALLOC(o->d_qt2, B * (T + 1) * (size_t)o->qt_size);
@@ -786,7 +790,7 @@ void agx_ocp_destroy(agx_ocp *o) {
   if (o->stream) (void)hipStreamSynchronize(o->stream);
   void *ptrs[] = {o->d_model, o->d_ocp, o->d_dt, o->d_xs, o->d_us, o->d_x0, o->d_tiles, o->d_Kws, o->d_kws, o->d_Kout, o->d_dx,
                   o->d_du, o->d_ref, o->d_frames, o->d_state, o->d_ndone, o->d_scratch, o->d_traj, o->d_pts, o->d_sine, o->d_qt, o->d_aux, o->d_w, o->d_nodestat,
-                  o->d_qt2, o->d_cg, o->d_cjac, o->d_y, o->d_z, o->d_cx, o->d_admmstat, o->d_hidx, o->d_trial, o->d_auxg};
+                  o->d_qt2, o->d_cg, o->d_cjac, o->d_y, o->d_z, o->d_cx, o->d_admmstat, o->d_hidx, o->d_trial, o->d_auxg, o->d_jt};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
   if (o->h_ndone) (void)hipHostFree(o->h_ndone);

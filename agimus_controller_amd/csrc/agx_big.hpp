@@ -20,10 +20,13 @@ namespace agx {
 //   Hww = M D M, Hxw = taux' D M, Hxx = Lxx + taux' D taux, gw = M Lu, gx = Lx + taux' Lu,  D = Luu + preg.
 template <int NV>
 __global__ void __launch_bounds__(256) k_transform_big(const DevOcp *__restrict__ op, double *__restrict__ qts,
-                                                       const double *__restrict__ auxs, const DevState *__restrict__ st) {
+                                                       double *__restrict__ auxs, const DevState *__restrict__ st,
+                                                       const double *__restrict__ jtbuf) {
   typedef QT<NV> Q;
   typedef AUX<NV> A;
-  __shared__ double sM[NV * NV], sq[NV * NV], sv[NV * NV], sD[NV], slu[NV];
+  constexpr int JS = 6 + 6 * NV;
+  __shared__ double sM[NV * NV], sq[NV * NV], sv[NV * NV], sD[NV], slu[NV], sJ[2 * JS];
+  __shared__ int s_njt;
   const DevOcp &o = *op;
   const int T = o.T, tid = threadIdx.x, nt = blockDim.x;
   const long long unit = blockIdx.x;  // b * T + t
@@ -31,16 +34,30 @@ __global__ void __launch_bounds__(256) k_transform_big(const DevOcp *__restrict_
   const DevState &S = st[b];
   if (S.done) return;
   double *qt = qts + ((long long)b * (T + 1) + t) * Q::SIZE;
-  const double *ax = auxs + ((long long)b * (T + 1) + t) * A::SIZE;
+  double *ax = auxs + ((long long)b * (T + 1) + t) * A::SIZE;
   for (int e = tid; e < NV * NV; e += nt) {
     const int i = e / NV, j = e % NV;
     sM[e] = ax[A::M + i * A::LD + j]; sq[e] = ax[A::tq + i * A::LD + j]; sv[e] = ax[A::tv + i * A::LD + j];
   }
   for (int i = tid; i < NV; i += nt) { sD[i] = ax[A::Luu + i] + S.preg; slu[i] = ax[A::Lu + i]; }
+  // frame rows parked by the one-lane pass: weights (already scaled by the node's dt) | J
+  const double *jt = jtbuf ? jtbuf + unit * (1 + 2 * JS) : nullptr;
+  if (tid == 0) s_njt = jt ? (int)jt[0] : 0;
+  for (int e = tid; e < 2 * JS; e += nt) sJ[e] = jt ? jt[1 + e] : 0.0;
   __syncthreads();
+  const int njt = s_njt;
   for (int e = tid; e < NV * NV; e += nt) {
     const int i = e / NV, j = e % NV;
-    double hww = 0.0, hqw = 0.0, hvw = 0.0, hqq = ax[A::Lqq + i * A::LD + j], hqv = 0.0, hvv = (i == j) ? ax[A::Lvv + i] : 0.0;
+    double lqq = ax[A::Lqq + i * A::LD + j];
+    for (int s2 = 0; s2 < njt; ++s2) {
+      const double *wv = sJ + s2 * JS, *Jm = wv + 6;
+      double acc = 0.0;
+#pragma unroll
+      for (int r = 0; r < 6; ++r) acc += wv[r] * Jm[r * NV + i] * Jm[r * NV + j];
+      lqq += acc;
+    }
+    if (njt > 0) ax[A::Lqq + i * A::LD + j] = lqq;  // the complete Lqq: K3 reads it for the KKT shares
+    double hww = 0.0, hqw = 0.0, hvw = 0.0, hqq = lqq, hqv = 0.0, hvv = (i == j) ? ax[A::Lvv + i] : 0.0;
     for (int l = 0; l < NV; ++l) {
       const double d = sD[l];
       const double dm = d * sM[l * NV + j], dtq = d * sq[l * NV + j], dtv = d * sv[l * NV + j];

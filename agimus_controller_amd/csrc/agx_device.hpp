@@ -759,6 +759,11 @@ struct CostAcc {
   double Lq[NV], Lv[NV], Lu[NV];
   double Lqq[NV][NV];
   double Lvv[NV], Luu[NV];
+  // Large models only: when set, frame rows do not accumulate J' W J here (an O(6 nv^2) chain of
+  // scratch read-modify-writes on one lane) but park [weights (6) | J (6 x nv)] of up to two rows at
+  // jt + 1 (jt[0] = number of rows); the cooperative k_transform_big adds the products.
+  double *jt = nullptr;
+  int njt = 0;
 };
 
 // Evaluates the cost rows of one node.  DIFF = false: value only (line search).
@@ -766,6 +771,7 @@ template <int NV, bool CHAIN, bool TERM, bool DIFF>
 AGX_DEV void node_costs(const DevModel &m, const DevRows &rows, const Kin<NV> &k, const double *x, const double *u,
                         const double *ref, const int *frames, CostAcc<NV> &c) {
   c.cost = 0.0;
+  c.njt = 0;
   if (DIFF) {
 AGX_UNROLL_NV
     for (int i = 0; i < NV; ++i) {
@@ -897,6 +903,7 @@ AGX_UNROLL_NV
 #pragma unroll
           for (int e = 0; e < 6; ++e) { wj[e] = we[e] * J[e][i]; gi += wj[e] * res[e]; }
           c.Lq[i] += gi;
+          if (NV > 8 && c.jt && c.njt < 2) continue;  // the Hessian part is deferred (see CostAcc::jt)
 AGX_UNROLL_NV
           for (int j = 0; j <= i; ++j) {
             double acc = 0.0;
@@ -904,6 +911,14 @@ AGX_UNROLL_NV
             for (int e = 0; e < 6; ++e) acc += wj[e] * J[e][j];
             c.Lqq[i][j] += acc;
           }
+        }
+        if (NV > 8 && c.jt && c.njt < 2) {
+          double *slot = c.jt + 1 + c.njt * (6 + 6 * NV);
+          for (int e = 0; e < 6; ++e) {
+            slot[e] = we[e];
+            for (int i = 0; i < NV; ++i) slot[6 + e * NV + i] = J[e][i];
+          }
+          c.njt += 1;
         }
       }
     } else if (kind == AGX_RES_COLLISION) {

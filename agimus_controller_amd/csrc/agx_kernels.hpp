@@ -236,7 +236,7 @@ __device__ __forceinline__ void calc_qp_body(const long long unit, const DevMode
                                              const double *__restrict__ dts, const double *__restrict__ xs,
                                              const double *__restrict__ us, const RefView &rv, double *__restrict__ qts,
                                              double *__restrict__ auxs, const DevState *__restrict__ st,
-                                             double *__restrict__ auxg = nullptr) {
+                                             double *__restrict__ auxg = nullptr, double *__restrict__ jtbuf = nullptr) {
   constexpr int NX = 2 * NV, NU = NV;
   typedef QT<NV> Q;
   typedef AUX<NV> A;
@@ -291,7 +291,13 @@ AGX_UNROLL_NV
   double tq[NV][NV], tv[NV][NV];
   rnea_derivatives<NV, CHAIN>(m, k, d, x + NV, qdd, tq, tv);
   CostAcc<NV> c;
+  if constexpr (NV > 8) c.jt = jtbuf ? jtbuf + unit * (1 + 2 * (6 + 6 * NV)) : nullptr;
   node_costs<NV, CHAIN, false, true>(m, o.rows[0], k, x, u, ref_at(rv, b, t, T), frames_at(rv, b, t, T), c);
+  if constexpr (NV > 8) if (c.jt) {
+    c.jt[0] = (double)c.njt;
+    for (int s2 = 0; s2 < c.njt; ++s2)
+      for (int e = 0; e < 6; ++e) c.jt[1 + s2 * (6 + 6 * NV) + e] *= dt;  // running cost = dt * l
+  }
   CostGen<NV> g;
   if constexpr (GEN) node_costs_general<NV, CHAIN, false, true>(m, o.rows[0], k, x, u, ref_at(rv, b, t, T), frames_at(rv, b, t, T), c, g);
   qt[Q::cost] = dt * c.cost;
@@ -460,10 +466,11 @@ template <int NV, bool CHAIN>
 __global__ void __launch_bounds__(64) k_calc_qp_all(const DevModel *__restrict__ mp, const DevOcp *__restrict__ op,
                                                     const double *__restrict__ dts, const double *__restrict__ xs,
                                                     const double *__restrict__ us, RefView rv, double *__restrict__ qts,
-                                                    double *__restrict__ auxs, const DevState *__restrict__ st) {
+                                                    double *__restrict__ auxs, const DevState *__restrict__ st,
+                                                    double *__restrict__ jtbuf) {
   const long long unit = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const long long n_run = (long long)op->B * op->T;
-  if (unit < n_run) calc_qp_body<NV, CHAIN>(unit, mp, op, dts, xs, us, rv, qts, auxs, st);
+  if (unit < n_run) calc_qp_body<NV, CHAIN>(unit, mp, op, dts, xs, us, rv, qts, auxs, st, nullptr, jtbuf);
   else calc_qp_term_body<NV, CHAIN>((int)(unit - n_run), mp, op, xs, rv, qts, auxs, st);
 }
 
