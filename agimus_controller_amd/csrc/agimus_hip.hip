@@ -328,8 +328,12 @@ int launch_step(agx_ocp *o, int iter, int max_iter, int mode, bool with_node_kkt
     }
     if (!with_step) { HIPCHK(hipGetLastError()); return 0; }
     if constexpr (NV <= 7) {
-      hipLaunchKernelGGL((agx::k_step<NV, CH>), dim3(o->B), dim3(128), 0, o->stream, o->d_model, o->d_ocp, o->d_dt, o->d_xs, o->d_us,
-                         o->rv, o->d_qt, o->d_aux, o->d_dx, o->d_nodestat, o->d_du, o->d_state, iter, max_iter, mode, o->d_ndone);
+      if (o->ho.use_filter)
+        hipLaunchKernelGGL((agx::k_step<NV, CH, false, true>), dim3(o->B), dim3(128), 0, o->stream, o->d_model, o->d_ocp, o->d_dt, o->d_xs,
+                           o->d_us, o->rv, o->d_qt, o->d_aux, o->d_dx, o->d_nodestat, o->d_du, o->d_state, iter, max_iter, mode, o->d_ndone);
+      else
+        hipLaunchKernelGGL((agx::k_step<NV, CH>), dim3(o->B), dim3(128), 0, o->stream, o->d_model, o->d_ocp, o->d_dt, o->d_xs, o->d_us,
+                           o->rv, o->d_qt, o->d_aux, o->d_dx, o->d_nodestat, o->d_du, o->d_state, iter, max_iter, mode, o->d_ndone);
     } else {
       // large models: convergence test in k_step, line search node parallel
       const bool split = (mode & 1) && !(mode & 4);
@@ -702,6 +706,7 @@ int agx_ocp_create(const agx_model *m, const agx_ocp_desc *d, int batch, int dev
   o->ho.eps_rel = d->eps_rel;
   o->ho.use_filter = d->use_filter_line_search ? 1 : 0;
   if (o->ho.use_filter && o->nv > 7) { delete o; return fail("agx_ocp_create: the filter line search is implemented for nv <= 7"); }
+  if (o->ho.use_filter && (o->ho.rows[0].general || o->ho.rows[1].general)) { delete o; return fail("agx_ocp_create: the filter line search with ControlGrav / FrameVelocity rows is not implemented"); }
   if (o->has_con && o->nv > 7) { delete o; return fail("agx_ocp_create: constraints need the register Riccati kernel (nv <= 7)"); }
   {
     auto n_frame_rows = [](const DevRows &r) {

@@ -873,7 +873,7 @@ AGX_UNROLL_NV
 // mode bit2: timing mode (no convergence exit, nothing committed) so that launches are repeatable.
 // mode bit3: convergence test only; the line search is done node-parallel by k_ls_trial / k_ls_accept (large models).
 // ---------------------------------------------------------------------------
-template <int NV, bool CHAIN, bool GEN = false>
+template <int NV, bool CHAIN, bool GEN = false, bool FILTER = false>
 __global__ void __launch_bounds__(128) k_step(const DevModel *__restrict__ mp, const DevOcp *__restrict__ op,
                                               const double *__restrict__ dts, double *__restrict__ xs,
                                               double *__restrict__ us, RefView rv, const double *__restrict__ qts,
@@ -935,34 +935,69 @@ __global__ void __launch_bounds__(128) k_step(const DevModel *__restrict__ mp, c
   bool ok = false;
   for (int n = 0; n < 10; ++n, alpha *= 0.5) {
     used = alpha;
-    double pc = 0.0, pg = 0.0, pv = 0.0;  // cost, gap norm, constraint violation of the trial
-    for (int r = 0; r < NPT; ++r) {
-      const int t = tid + r * blockDim.x;
-      if (t > T) break;
-      double x[NX], u[NU];
+    if constexpr (!FILTER) {
+      // merit line search (the reference default): one accumulator, cost + mu_dyn gaps + mu_con violation
+      double part = 0.0;
+      for (int r = 0; r < NPT; ++r) {
+        const int t = tid + r * blockDim.x;
+        if (t > T) break;
+        double x[NX], u[NU];
 AGX_UNROLL_NV
-      for (int i = 0; i < NX; ++i) x[i] = X[(long long)t * NX + i] + alpha * DX[(long long)t * NX + i];
-      if (t < T) {
+        for (int i = 0; i < NX; ++i) x[i] = X[(long long)t * NX + i] + alpha * DX[(long long)t * NX + i];
+        if (t < T) {
 AGX_UNROLL_NV
-        for (int i = 0; i < NU; ++i) u[i] = U[(long long)t * NU + i] + alpha * DU[(long long)t * NU + i];
-        double xn[NX], c;
-        node_calc_running<NV, CHAIN, GEN>(m, o.rows[0], dts[t], x, u, ref_at(rv, b, t, T), frames_at(rv, b, t, T), xn, &c);
-        double g = 0.0;
+          for (int i = 0; i < NU; ++i) u[i] = U[(long long)t * NU + i] + alpha * DU[(long long)t * NU + i];
+          double xn[NX], c;
+          node_calc_running<NV, CHAIN, GEN>(m, o.rows[0], dts[t], x, u, ref_at(rv, b, t, T), frames_at(rv, b, t, T), xn, &c);
+          double g = 0.0;
 AGX_UNROLL_NV
-        for (int i = 0; i < NX; ++i)
-          g += fabs(xn[i] - (X[(long long)(t + 1) * NX + i] + alpha * DX[(long long)(t + 1) * NX + i]));
-        pc += c; pg += g;
-        if (o.has_con) pv += constraint_violation<NV, CHAIN>(m, o.cons[0], x, u);
-      } else {
-        double c;
-        node_calc_terminal<NV, CHAIN, GEN>(m, o.rows[1], x, ref_at(rv, b, T, T), frames_at(rv, b, T, T), &c);
-        pc += c;
-        if (o.has_con) pv += constraint_violation<NV, CHAIN>(m, o.cons[1], x, x);
+          for (int i = 0; i < NX; ++i)
+            g += fabs(xn[i] - (X[(long long)(t + 1) * NX + i] + alpha * DX[(long long)(t + 1) * NX + i]));
+          part += c + o.mu_dyn * g;
+          if (o.has_con) part += o.mu_con * constraint_violation<NV, CHAIN>(m, o.cons[0], x, u);
+        } else {
+          double c;
+          node_calc_terminal<NV, CHAIN, GEN>(m, o.rows[1], x, ref_at(rv, b, T, T), frames_at(rv, b, T, T), &c);
+          part += c;
+          if (o.has_con) part += o.mu_con * constraint_violation<NV, CHAIN>(m, o.cons[1], x, x);
+        }
       }
-    }
-    if (o.use_filter) {
+      part = wave_sum(part);
+      if ((tid & 63) == 0) red[tid >> 6] = part;
+      __syncthreads();
+      if (tid == 0) {
+        double tot = 0.0;
+        for (int w = 0; w < nw; ++w) tot += red[w];
+        flag = (merit > tot) ? 1 : 0;
+      }
+    } else {
       // filter line search with the solver's default filter size 1 (SolverCSQP::solve): the trial is
       // rejected only if it is no better than the current point in cost AND gaps AND constraints
+      double pc = 0.0, pg = 0.0, pv = 0.0;
+      for (int r = 0; r < NPT; ++r) {
+        const int t = tid + r * blockDim.x;
+        if (t > T) break;
+        double x[NX], u[NU];
+AGX_UNROLL_NV
+        for (int i = 0; i < NX; ++i) x[i] = X[(long long)t * NX + i] + alpha * DX[(long long)t * NX + i];
+        if (t < T) {
+AGX_UNROLL_NV
+          for (int i = 0; i < NU; ++i) u[i] = U[(long long)t * NU + i] + alpha * DU[(long long)t * NU + i];
+          double xn[NX], c;
+          node_calc_running<NV, CHAIN, GEN>(m, o.rows[0], dts[t], x, u, ref_at(rv, b, t, T), frames_at(rv, b, t, T), xn, &c);
+          double g = 0.0;
+AGX_UNROLL_NV
+          for (int i = 0; i < NX; ++i)
+            g += fabs(xn[i] - (X[(long long)(t + 1) * NX + i] + alpha * DX[(long long)(t + 1) * NX + i]));
+          pc += c; pg += g;
+          if (o.has_con) pv += constraint_violation<NV, CHAIN>(m, o.cons[0], x, u);
+        } else {
+          double c;
+          node_calc_terminal<NV, CHAIN, GEN>(m, o.rows[1], x, ref_at(rv, b, T, T), frames_at(rv, b, T, T), &c);
+          pc += c;
+          if (o.has_con) pv += constraint_violation<NV, CHAIN>(m, o.cons[1], x, x);
+        }
+      }
       pc = wave_sum(pc); pg = wave_sum(pg); pv = wave_sum(pv);
       if ((tid & 63) == 0) { red[tid >> 6] = pc; red[2 + (tid >> 6)] = pg; red[4 + (tid >> 6)] = pv; }
       __syncthreads();
@@ -971,15 +1006,6 @@ AGX_UNROLL_NV
         for (int w = 0; w < nw; ++w) { tc += red[w]; tg += red[2 + w]; tv += red[4 + w]; }
         const bool worse = (S.cost <= tc) && (S.gap <= tg) && (S.con <= tv);
         flag = worse ? 0 : 1;
-      }
-    } else {
-      double part = wave_sum(pc + o.mu_dyn * pg + o.mu_con * pv);
-      if ((tid & 63) == 0) red[tid >> 6] = part;
-      __syncthreads();
-      if (tid == 0) {
-        double tot = 0.0;
-        for (int w = 0; w < nw; ++w) tot += red[w];
-        flag = (merit > tot) ? 1 : 0;
       }
     }
     __syncthreads();
