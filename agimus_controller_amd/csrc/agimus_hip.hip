@@ -57,7 +57,8 @@ struct agx_ocp {
   double *d_jt = nullptr;     // large models: frame rows parked for the cooperative J'WJ, [B*T][1 + 2 (6 + 6 nv)]
   bool general = false;       // ControlGrav / FrameVelocity cost rows: one-lane GEN kernels (agx_general.hpp)
   double *d_auxg = nullptr;   // [B][T+1][3 nv 8]: Lqv | Lvvd | Lqu of every node (general problems)
-  double *d_qt2 = nullptr, *d_cg = nullptr, *d_cjac = nullptr, *d_y = nullptr, *d_z = nullptr, *d_cx = nullptr, *d_admmstat = nullptr;
+  double *d_qt2 = nullptr, *d_cg = nullptr, *d_cjac = nullptr, *d_y = nullptr, *d_z = nullptr, *d_cx = nullptr, *d_admmstat = nullptr,
+         *d_fac = nullptr;  // Riccati factors of every node for the gradient-only ADMM sweeps [B][T][192]
   int qt_size = 0, aux_size = 0;
   bool k1_lanes = true;  // AGX_K1_LANES=0 selects the one-lane-per-node derivative kernel
   bool lanes_ok = true;  // problem fits the LDS staging of the 8-lanes-per-node kernel
@@ -477,7 +478,8 @@ int admm_direction(agx_ocp *o) {
     for (int iter = 1; iter <= max_qp; ++iter) {
       hipLaunchKernelGGL((agx::k_admm_tile<NV>), dim3(g8b), dim3(128), 0, o->stream, o->d_ocp, o->d_qt, o->d_qt2, o->d_aux, o->d_cx,
                          o->d_du, o->d_cjac, o->d_y, o->d_z, o->d_state);
-      if (launch_riccati(o, 1, false, 0, o->d_qt2)) return -1;
+      hipLaunchKernelGGL((agx::k_riccati_admm<NV>), dim3(o->B), dim3(64), 0, o->stream, o->d_ocp, o->d_dt, o->d_qt2, o->d_aux, o->d_Kws,
+                         o->d_kws, o->d_dx, o->d_w, o->d_du, o->d_Kout, o->d_state, o->d_fac);
       hipLaunchKernelGGL((agx::k_admm_update<NV>), dim3(g8), dim3(256), 0, o->stream, o->d_ocp, o->d_qt, o->d_aux, o->d_dx, o->d_w,
                          o->d_du, o->d_cx, o->d_cg, o->d_cjac, o->d_y, o->d_z, o->d_nodestat, o->d_admmstat, o->d_state);
       hipLaunchKernelGGL(agx::k_admm_reduce, dim3(o->B), dim3(128), 0, o->stream, o->d_ocp, o->d_admmstat, o->d_state, iter,
@@ -762,6 +764,7 @@ int agx_ocp_create(const agx_model *m, const agx_ocp_desc *d, int batch, int dev
     ALLOC(o->d_z, B * (T + 1) * AGX_MAX_NC);
     ALLOC(o->d_cx, B * (T + 1) * nx);
     ALLOC(o->d_admmstat, B * (T + 1) * 4);
+    ALLOC(o->d_fac, B * T * 192);
   }
 #undef ALLOC
   if (hipHostMalloc((void **)&o->h_ndone, 8 * sizeof(int), hipHostMallocMapped) != hipSuccess) { agx_ocp_destroy(o); return fail("hipHostMalloc failed"); }
@@ -795,7 +798,7 @@ void agx_ocp_destroy(agx_ocp *o) {
   if (o->stream) (void)hipStreamSynchronize(o->stream);
   void *ptrs[] = {o->d_model, o->d_ocp, o->d_dt, o->d_xs, o->d_us, o->d_x0, o->d_tiles, o->d_Kws, o->d_kws, o->d_Kout, o->d_dx,
                   o->d_du, o->d_ref, o->d_frames, o->d_state, o->d_ndone, o->d_scratch, o->d_traj, o->d_pts, o->d_sine, o->d_qt, o->d_aux, o->d_w, o->d_nodestat,
-                  o->d_qt2, o->d_cg, o->d_cjac, o->d_y, o->d_z, o->d_cx, o->d_admmstat, o->d_hidx, o->d_trial, o->d_auxg, o->d_jt};
+                  o->d_qt2, o->d_cg, o->d_cjac, o->d_y, o->d_z, o->d_cx, o->d_admmstat, o->d_fac, o->d_hidx, o->d_trial, o->d_auxg, o->d_jt};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
   if (o->h_ndone) (void)hipHostFree(o->h_ndone);

@@ -71,6 +71,7 @@ __global__ void __launch_bounds__(256) k_admm_init(const DevOcp *__restrict__ op
   for (int k = 0; k < AGX_MAX_NC; ++k) zs[node * AGX_MAX_NC + k] = 0.0;
   if (t == 0) {
     S.admm_conv = 0;
+    S.admm_refactor = 1;
     S.admm_iter = o.max_qp;
     if (!(S.rho_sparse > 0.0)) S.rho_sparse = 1e-1;  // rho_sparse_base of a fresh solver
   }
@@ -112,8 +113,10 @@ __global__ void __launch_bounds__(128) k_admm_tile(const DevOcp *__restrict__ op
   double *sh = lds[grp];
   for (int e = l8; e < 3 * B2; e += 8) sh[e] = ax[A::M + e];
   __syncthreads();
-  // copy the base tile
-  if (live)
+  // Hessian part only when it changed (first ADMM iteration of the SQP iteration, or new rho); the
+  // gradient part below is rewritten at every iteration from the base tile
+  const bool full = S.admm_refactor != 0;
+  if (live && full)
     for (int e = l8; e < Q::SIZE; e += 8) q2[e] = qt[e];
   __syncthreads();
   // per-row weights on u (control rows) and the state / collision terms
@@ -137,7 +140,7 @@ __global__ void __launch_bounds__(128) k_admm_tile(const DevOcp *__restrict__ op
       gv += y[off + NV + j] - rv * z[off + NV + j];
     }
   }
-  if (wr) {
+  if (wr && full) {
     q2[Q::Hqq + j * Q::LD + j] += add_qq_diag;
     q2[Q::Hvv + j * Q::LD + j] += add_vv_diag;
   }
@@ -149,7 +152,7 @@ __global__ void __launch_bounds__(128) k_admm_tile(const DevOcp *__restrict__ op
     const double rho = admm_rho(c.lb[off], c.ub[off], rs);
     const double h = y[off] - rho * z[off];
     gq += h * gj[j];
-    if (wr)
+    if (wr && full)
       for (int i = 0; i < NV; ++i) q2[Q::Hqq + i * Q::LD + j] += rho * gj[i] * gj[j];
   }
   double gwv = 0.0;
@@ -163,6 +166,7 @@ __global__ void __launch_bounds__(128) k_admm_tile(const DevOcp *__restrict__ op
       const double e = hu[l] - sig * du[l];
       gwv += Mc[l] * e; gq += tqc[l] * e; gv += tvc[l] * e;
     }
+    if (full)
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       double hww = 0.0, hqw = 0.0, hvw = 0.0, hqq = 0.0, hqv = 0.0, hvv = 0.0;
@@ -183,10 +187,91 @@ __global__ void __launch_bounds__(128) k_admm_tile(const DevOcp *__restrict__ op
     }
   }
   if (wr) {
-    if (t < T) q2[Q::gw + j] += gwv;
-    q2[Q::gx + j] += gq;
-    q2[Q::gx + NV + j] += gv;
+    if (t < T) q2[Q::gw + j] = qt[Q::gw + j] + gwv;
+    q2[Q::gx + j] = qt[Q::gx + j] + gq;
+    q2[Q::gx + NV + j] = qt[Q::gx + NV + j] + gv;
   }
+}
+
+// ---------------------------------------------------------------------------
+// Riccati sweep of one ADMM iteration.  When the Hessian part of the instance's augmented tiles
+// changed (S.admm_refactor) the full Gauss-Jordan sweep runs and leaves its factors behind
+// (FT: multipliers of the 7 pivots, pivot reciprocals, V' f of every node); otherwise only the
+// gradient recursion is redone with those factors -- the reference makes the same distinction
+// (backwardPass / backwardPass_without_rho_update).  Every lane of grid row r carries the row's
+// three gradient entries redundantly; a pivot is one v_readlane and three FMAs.
+// ---------------------------------------------------------------------------
+template <int NV>
+__device__ __forceinline__ void riccati_vec_body(const int b, const DevOcp *__restrict__ op, const double *__restrict__ dts,
+                                                 const double *__restrict__ qts, const double *__restrict__ Kws,
+                                                 double *__restrict__ kws, double *__restrict__ dxs, double *__restrict__ wss,
+                                                 const double *__restrict__ facs) {
+  constexpr int NX = 2 * NV, TS = QT<NV>::SIZE;
+  typedef QT<NV> Q;
+  typedef FT<NV> F;
+  const DevOcp &o = *op;
+  const int T = o.T, lane = threadIdx.x;
+  const int r = lane >> 3, c = lane & 7;
+  const int rr = r < NV ? r : 0;
+  const double *qb = qts + (long long)b * (T + 1) * TS;
+  const double *Kw = Kws + (long long)b * T * NV * NX;
+  double *kw = kws + (long long)b * T * NV;
+  const double *fb = facs + (long long)b * T * F::SIZE;
+  double vxq, vxv;
+  {
+    const double *tt = qb + (long long)T * TS;
+    vxq = tt[Q::gx + rr]; vxv = tt[Q::gx + NV + rr];
+  }
+  struct Node { double gw, gq, gv, rp, pq, pv, fw[NV], fq[NV], fv[NV]; };
+  auto load_node = [&](Node &z, int t) {
+    const double *tl = qb + (long long)t * TS;
+    const double *ft = fb + (long long)t * F::SIZE;
+    z.gw = tl[Q::gw + rr]; z.gq = tl[Q::gx + rr]; z.gv = tl[Q::gx + NV + rr];
+    z.rp = ft[F::RP + rr]; z.pq = ft[F::PQ + rr]; z.pv = ft[F::PV + rr];
+#pragma unroll
+    for (int k = 0; k < NV; ++k) { z.fw[k] = ft[F::FW + k * 8 + rr]; z.fq[k] = ft[F::FQ + k * 8 + rr]; z.fv[k] = ft[F::FV + k * 8 + rr]; }
+  };
+  auto step = [&](Node &z, int t) {
+    const double h = dts[t], h2 = h * h;
+    const double vpq = vxq + z.pq, vpv = vxv + z.pv;
+    double gW = z.gw + h2 * vpq + h * vpv, gQ = z.gq + vpq, gV = z.gv + h * vpq + vpv;
+    const double rp = z.rp;
+    double fw[NV], fq[NV], fv[NV];
+#pragma unroll
+    for (int k = 0; k < NV; ++k) { fw[k] = z.fw[k]; fq[k] = z.fq[k]; fv[k] = z.fv[k]; }
+    if (t >= 2) load_node(z, t - 2);
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      const double gk = readlane_f64(gW, 8 * k);  // row k's entry (its own factor fw[k] is 0 there)
+      gW -= fw[k] * gk; gQ -= fq[k] * gk; gV -= fv[k] * gk;
+    }
+    if (c == 0 && r < NV) kw[(long long)t * NV + r] = gW * rp;
+    vxq = gQ; vxv = gV;
+  };
+  Node na, nb;
+  load_node(na, T - 1);
+  if (T >= 2) load_node(nb, T - 2);
+  for (int t = T - 1; t >= 0; t -= 2) {
+    step(na, t);
+    if (t >= 1) step(nb, t - 1);
+  }
+  riccati_forward<NV>(b, T, dts, qb, Kw, kw, dxs, wss);
+}
+
+template <int NV>
+__global__ void __launch_bounds__(64) k_riccati_admm(const DevOcp *__restrict__ op, const double *__restrict__ dts,
+                                                     const double *__restrict__ qts, const double *__restrict__ auxs,
+                                                     double *__restrict__ Kws, double *__restrict__ kws,
+                                                     double *__restrict__ dxs, double *__restrict__ wss,
+                                                     double *__restrict__ dus, double *__restrict__ Kout,
+                                                     DevState *__restrict__ st, double *__restrict__ facs) {
+  const int b = blockIdx.x;
+  const DevState &S = st[b];
+  if (S.done || S.admm_conv) return;
+  if (S.admm_refactor)
+    riccati_body<NV, false, true>(b, op, dts, qts, auxs, Kws, kws, dxs, wss, dus, Kout, st, 1, 0, 0, facs);
+  else
+    riccati_vec_body<NV>(b, op, dts, qts, Kws, kws, dxs, wss, facs);
 }
 
 // After the Riccati sweep on the augmented tiles: du, the multiplier update and the node's shares of
@@ -343,8 +428,10 @@ __global__ void __launch_bounds__(128) k_admm_reduce(const DevOcp *__restrict__ 
   double est = scale * S.rho_sparse;
   est = (est < kRhoMin) ? kRhoMin : est;
   est = (kRhoMax < est) ? kRhoMax : est;
+  int refactor = 0;
   if (iter % kRhoInterval == 0 && iter > 1)
-    if (est > S.rho_sparse * kAdaptiveRhoTol || est < S.rho_sparse / kAdaptiveRhoTol) S.rho_sparse = est;
+    if (est > S.rho_sparse * kAdaptiveRhoTol || est < S.rho_sparse / kAdaptiveRhoTol) { S.rho_sparse = est; refactor = 1; }
+  S.admm_refactor = refactor;  // unchanged rho: the next sweep only redoes the gradient recursion
   const bool conv = (np_ <= o.eps_abs + o.eps_rel * npr) && (nd <= o.eps_abs + o.eps_rel * ndr);
   if (conv || iter == o.max_qp) {
     S.admm_conv = 1;

@@ -28,7 +28,8 @@ struct DevState {
   double rho_sparse;             // persists across solves (SolverCSQP reset_rho = false); 0 = not initialised
   double con;                    // l1 norm of the constraint violation at the last evaluation
   int admm_conv, admm_iter;      // QP converged in this SQP iteration / ADMM iterations done
-  int ls_acc, pad_;              // split line search (large models): step accepted in this SQP iteration
+  int ls_acc;                    // split line search (large models): step accepted in this SQP iteration
+  int admm_refactor;             // ADMM: the Hessian part of the augmented tiles changed (first iteration / new rho)
 };
 
 // Addressing of the reference tiles (host tile or a window of the resident trajectory).
@@ -527,13 +528,76 @@ __device__ __forceinline__ double fast_rcp(double x) {
 // on Hxx; the corrections  sigma [taux M]' [taux M]  are formed on the fly from the aux tile, the
 // gradient recursion is skipped (it does not influence the gains) and the gains are mapped to
 // u-space in registers:  K = M Kw - taux  -> Kout.  No forward pass.
-template <int NV, bool GAINS>
+// Linear forward pass of one instance with the gains (Kw, kw) of the backward sweep.
+template <int NV>
+__device__ __forceinline__ void riccati_forward(const int b, const int T, const double *__restrict__ dts, const double *__restrict__ qb,
+                                                const double *__restrict__ Kw, const double *__restrict__ kw,
+                                                double *__restrict__ dxs, double *__restrict__ wss) {
+  constexpr int NX = 2 * NV, TS = QT<NV>::SIZE;
+  typedef QT<NV> Q;
+  const int lane = threadIdx.x;
+  // ---- forward pass: lane a < NV owns joint a (dx_q[a], dx_v[a], w[a]); the only cross-lane traffic
+  // is the broadcast of dx to every lane (v_readlane), the state update is lane-local.
+  double *dx = dxs + (long long)b * (T + 1) * NX, *ws = wss + (long long)b * T * NV;
+  double dq = 0.0, dv = 0.0;
+  if (lane < NV) { dx[lane] = 0.0; dx[NV + lane] = 0.0; }
+  __threadfence_block();  // the gains written above are read back by other lanes below
+  const int la = lane < NV ? lane : 0;
+  struct Gain { double k[NX], kw, fq, fv; };
+  auto load_gain = [&](Gain &g, int t) {
+AGX_UNROLL_NV
+    for (int j = 0; j < NX; ++j) g.k[j] = Kw[(long long)t * NV * NX + la * NX + j];
+    g.kw = kw[(long long)t * NV + la];
+    g.fq = qb[(long long)t * TS + Q::f + la];
+    g.fv = qb[(long long)t * TS + Q::f + NV + la];
+  };
+  auto fstep = [&](Gain &g, int t) {
+    const double h = dts[t], h2 = h * h;
+    double w0 = -g.kw, w1 = 0.0;  // two accumulation chains
+AGX_UNROLL_NV
+    for (int j = 0; j < NV; ++j) {
+      w0 -= g.k[j] * readlane_f64(dq, j);
+      w1 -= g.k[NV + j] * readlane_f64(dv, j);
+    }
+    const double wv = w0 + w1, fqc = g.fq, fvc = g.fv;
+    if (t + 4 < T) load_gain(g, t + 4);  // refill this register set four nodes ahead
+    const double nq = dq + h * dv + h2 * wv + fqc;
+    const double nv2 = dv + h * wv + fvc;
+    dq = nq; dv = nv2;
+    if (lane < NV) {
+      ws[(long long)t * NV + lane] = wv;
+      dx[(long long)(t + 1) * NX + lane] = dq;
+      dx[(long long)(t + 1) * NX + NV + lane] = dv;
+    }
+  };
+  Gain g0, g1, g2, g3;
+  load_gain(g0, 0);
+  if (T > 1) load_gain(g1, 1);
+  if (T > 2) load_gain(g2, 2);
+  if (T > 3) load_gain(g3, 3);
+  for (int t = 0; t < T; t += 4) {
+    fstep(g0, t);
+    if (t + 1 < T) fstep(g1, t + 1);
+    if (t + 2 < T) fstep(g2, t + 2);
+    if (t + 3 < T) fstep(g3, t + 3);
+  }
+}
+
+// Factors of one node kept for gradient-only sweeps (ADMM iterations that do not change rho,
+// agx_admm.hpp): the elimination multipliers of the 7 pivots, the pivot reciprocals and V' f.
+template <int NV>
+struct FT {
+  static constexpr int FW = 0, FQ = 56, FV = 112, RP = 168, PQ = 176, PV = 184, SIZE = 192;
+};
+
+template <int NV, bool GAINS, bool STORE = false>
 __device__ __forceinline__ void riccati_body(const int b, const DevOcp *__restrict__ op, const double *__restrict__ dts,
                                              const double *__restrict__ qts, const double *__restrict__ auxs,
                                              double *__restrict__ Kws, double *__restrict__ kws,
                                              double *__restrict__ dxs, double *__restrict__ wss,
                                              double *__restrict__ dus, double *__restrict__ Kout,
-                                             DevState *__restrict__ st, int forward, int gmode, int iter) {
+                                             DevState *__restrict__ st, int forward, int gmode, int iter,
+                                             double *__restrict__ facs = nullptr) {
   (void)dus;
   constexpr int gains_pass = GAINS ? 1 : 0;
   typedef AUX<NV> A;
@@ -651,6 +715,10 @@ AGX_UNROLL_NV
       pq += dpp_xor2(pq); pv += dpp_xor2(pv);
       pq += dpp_xor4(pq); pv += dpp_xor4(pv);
       vpq = vxq + pq; vpv = vxv + pv;
+      if constexpr (STORE) {
+        double *ft = facs + ((long long)b * T + t) * FT<NV>::SIZE;
+        if (c == 0) { ft[FT<NV>::PQ + r] = pq; ft[FT<NV>::PV + r] = pv; }
+      }
     }
     // Y = G' V  (rows indexed by the acceleration variable):  Yq = h^2 Vqq + h Vvq, Yv = h^2 Vqv + h Vvv
     const double Yq = h2 * Vqq + h * Vvq, Yv = h2 * Vqv + h * Vvv;
@@ -681,6 +749,10 @@ AGX_UNROLL_NV
       const double rp = fast_rcp(piv);
       const double fw = (r == k) ? 0.0 : cw * rp;  // the pivot row itself is left untouched
       const double fqx = cq * rp, fvx = cv * rp;
+      if constexpr (STORE) {
+        double *ft = facs + ((long long)b * T + t) * FT<NV>::SIZE;
+        if (c == 0) { ft[FT<NV>::FW + k * 8 + r] = fw; ft[FT<NV>::FQ + k * 8 + r] = fqx; ft[FT<NV>::FV + k * 8 + r] = fvx; }
+      }
       Mww -= fw * rw; Mwq -= fw * rq; Mwv -= fw * rv2;
       Mqw -= fqx * rw; Mqq -= fqx * rq; Mqv -= fqx * rv2;
       Mvw -= fvx * rw; Mvq -= fvx * rq; Mvv -= fvx * rv2;
@@ -689,6 +761,10 @@ AGX_UNROLL_NV
     pivot(std::integral_constant<int, 0>()); pivot(std::integral_constant<int, 1>()); pivot(std::integral_constant<int, 2>());
     pivot(std::integral_constant<int, 3>()); pivot(std::integral_constant<int, 4>()); pivot(std::integral_constant<int, 5>());
     pivot(std::integral_constant<int, 6>());
+    if constexpr (STORE) {
+      double *ft = facs + ((long long)b * T + t) * FT<NV>::SIZE;
+      if (c == 0) ft[FT<NV>::RP + r] = rp_row;
+    }
     // gains of this node: Kw = D^-1 [Mwq Mwv], kw = D^-1 qw
     if (!GAINS) {
       if (in) {
@@ -725,51 +801,7 @@ AGX_UNROLL_NV
     if (t >= 1) step(tb, t - 1);
   }
   if (GAINS || !forward) return;
-  // ---- forward pass: lane a < NV owns joint a (dx_q[a], dx_v[a], w[a]); the only cross-lane traffic
-  // is the broadcast of dx to every lane (v_readlane), the state update is lane-local.
-  double *dx = dxs + (long long)b * (T + 1) * NX, *ws = wss + (long long)b * T * NV;
-  double dq = 0.0, dv = 0.0;
-  if (lane < NV) { dx[lane] = 0.0; dx[NV + lane] = 0.0; }
-  __threadfence_block();  // the gains written above are read back by other lanes below
-  const int la = lane < NV ? lane : 0;
-  struct Gain { double k[NX], kw, fq, fv; };
-  auto load_gain = [&](Gain &g, int t) {
-AGX_UNROLL_NV
-    for (int j = 0; j < NX; ++j) g.k[j] = Kw[(long long)t * NV * NX + la * NX + j];
-    g.kw = kw[(long long)t * NV + la];
-    g.fq = qb[(long long)t * TS + Q::f + la];
-    g.fv = qb[(long long)t * TS + Q::f + NV + la];
-  };
-  auto fstep = [&](Gain &g, int t) {
-    const double h = dts[t], h2 = h * h;
-    double w0 = -g.kw, w1 = 0.0;  // two accumulation chains
-AGX_UNROLL_NV
-    for (int j = 0; j < NV; ++j) {
-      w0 -= g.k[j] * readlane_f64(dq, j);
-      w1 -= g.k[NV + j] * readlane_f64(dv, j);
-    }
-    const double wv = w0 + w1, fqc = g.fq, fvc = g.fv;
-    if (t + 4 < T) load_gain(g, t + 4);  // refill this register set four nodes ahead
-    const double nq = dq + h * dv + h2 * wv + fqc;
-    const double nv2 = dv + h * wv + fvc;
-    dq = nq; dv = nv2;
-    if (lane < NV) {
-      ws[(long long)t * NV + lane] = wv;
-      dx[(long long)(t + 1) * NX + lane] = dq;
-      dx[(long long)(t + 1) * NX + NV + lane] = dv;
-    }
-  };
-  Gain g0, g1, g2, g3;
-  load_gain(g0, 0);
-  if (T > 1) load_gain(g1, 1);
-  if (T > 2) load_gain(g2, 2);
-  if (T > 3) load_gain(g3, 3);
-  for (int t = 0; t < T; t += 4) {
-    fstep(g0, t);
-    if (t + 1 < T) fstep(g1, t + 1);
-    if (t + 2 < T) fstep(g2, t + 2);
-    if (t + 3 < T) fstep(g3, t + 3);
-  }
+  riccati_forward<NV>(b, T, dts, qb, Kw, kw, dxs, wss);
 }
 
 template <int NV, bool GAINS>
@@ -1061,7 +1093,7 @@ __global__ void k_reset_state(DevState *st, int B, int *n_done) {
   if (b == 0) *n_done = 0;
   if (b >= B) return;
   DevState s;
-  s.rho_sparse = st[b].rho_sparse; s.con = 0.0; s.admm_conv = 0; s.admm_iter = 0; s.ls_acc = 0; s.pad_ = 0;
+  s.rho_sparse = st[b].rho_sparse; s.con = 0.0; s.admm_conv = 0; s.admm_iter = 0; s.ls_acc = 0; s.admm_refactor = 1;
   s.kkt = 0.0; s.cost = 0.0; s.merit = 0.0; s.gap = 0.0;
   s.preg = kRegMin; s.dreg = kRegMin;
   s.iter = 0; s.qp_iters = 0; s.solved = 0; s.flags = 0; s.done = 0; s.gains_iter = -1; s.dir_iter = -1;
