@@ -180,8 +180,8 @@ int dispatch(int nv, bool chain, F &&f) {
   switch (nv) {
 #define AGX_CASE(N)                                                  \
   case N:                                                            \
-    if (chain) return f(std::integral_constant<int, N>(), std::true_type()); \
-    return f(std::integral_constant<int, N>(), std::false_type());
+    if constexpr (N <= 8) { if (chain) return f(std::integral_constant<int, N>(), std::true_type()); } \
+    return f(std::integral_constant<int, N>(), std::false_type());  /* large models: the tree code path serves chains too */
     AGX_FOR_NV(AGX_CASE)
 #undef AGX_CASE
   }
