@@ -31,7 +31,8 @@ extern "C" {
 #endif
 
 #define AGX_MAX_ROWS 8   /* cost rows per node type (running / terminal)        */
-#define AGX_MAX_NV 32    /* joints supported by the templated kernels            */
+#define AGX_MAX_NV 32    /* joints a model table may have; kernels are compiled for nv in {1,2,3,4,6,7} (register-resident
+                            path) and 30 (LDS path for large models); other sizes are refused by agx_ocp_create */
 
 /* Residual kinds: class names of the YAML schema,
  * agimus_controller/agimus_controller/ocp/ocp_croco_generic.py:147-550.        */
@@ -251,7 +252,8 @@ int agx_ocp_direction(agx_ocp *ocp, double *K, double *k, double *dx, double *du
  * measured with hipEvents on the problem's stream.
  * which: 0 = derivative pass (running + terminal launches), 1 = Riccati backward + forward,
  * 2 = step kernel (du, KKT, line search; nothing committed), 3 = derivative pass over the running
- * nodes only (one launch), 4 = canonical-tile derivative pass (running nodes).            */
+ * nodes only (one launch), 4 = canonical-tile derivative pass (running nodes), 5 = Riccati backward
+ * only, 6 = exit (gains) sweep alone, 7 = direction + speculative gains sweep in one launch.        */
 int agx_ocp_time_kernel(agx_ocp *ocp, int which, int reps, double *avg_ms);
 
 /* In-situ kernel timing: while enabled, every solve brackets the launches of its SQP loop with
