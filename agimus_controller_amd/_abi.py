@@ -76,6 +76,7 @@ class ModelDesc(C.Structure):
         ("frame_placement", c_double_p),
         ("frame_radius", c_double_p),
         ("frame_halflen", c_double_p),
+        ("frame_box", c_double_p),
     ]
 
 
@@ -259,6 +260,8 @@ class PackedModel:
         hl = getattr(table, "frame_halflen", None)
         self.frame_radius = f8(np.zeros(self.nframes) if rad is None else rad, (self.nframes,))
         self.frame_halflen = f8(np.zeros(self.nframes) if hl is None else hl, (self.nframes,))
+        bx = getattr(table, "frame_box", None)
+        self.frame_box = f8(np.zeros((self.nframes, 3)) if bx is None else bx, (self.nframes, 3))
         d = ModelDesc()
         d.nv = nv
         d.nframes = self.nframes
@@ -275,6 +278,7 @@ class PackedModel:
         d.frame_placement = _dptr(self.frame_placement)
         d.frame_radius = _dptr(self.frame_radius)
         d.frame_halflen = _dptr(self.frame_halflen)
+        d.frame_box = _dptr(self.frame_box)
         self.desc = d
 
 

@@ -155,9 +155,11 @@ int fill_cons(const agx_constraint_row *rows, int n, int nv, const DevModel &m, 
       if (!(c.lower[k] <= c.upper[k])) return fail("agx_ocp_create: constraint with lower > upper");
     }
     if (c.kind == AGX_RES_COLLISION) {
-      if (c.frame < 0 || c.frame >= m.nframes || c.frame_b < 0 || c.frame_b >= m.nframes || !(m.frame_radius[c.frame] > 0.0) ||
-          !(m.frame_radius[c.frame_b] > 0.0))
+      if (c.frame < 0 || c.frame >= m.nframes || c.frame_b < 0 || c.frame_b >= m.nframes || !agx::frame_has_geometry(m, c.frame) ||
+          !agx::frame_has_geometry(m, c.frame_b))
         return fail("agx_ocp_create: collision constraint refers to a frame without geometry");
+      if (agx::frame_is_box(m, c.frame) && agx::frame_is_box(m, c.frame_b))
+        return fail("agx_ocp_create: box / box collision pairs are not supported");
       d.coll_slot[i] = d.ncoll++;
     }
     off += nr;
@@ -476,12 +478,15 @@ int admm_direction(agx_ocp *o) {
     HIPCHK(hipGetLastError());
     const int max_qp = o->ho.max_qp;
     for (int iter = 1; iter <= max_qp; ++iter) {
-      hipLaunchKernelGGL((agx::k_admm_tile<NV>), dim3(g8b), dim3(128), 0, o->stream, o->d_ocp, o->d_qt, o->d_qt2, o->d_aux, o->d_cx,
-                         o->d_du, o->d_cjac, o->d_y, o->d_z, o->d_state);
+      // augmented Hessians change at the first iteration and after a rho update (k_admm_reduce decides at
+      // multiples of kRhoInterval); in between k_admm_update leaves the next gradient behind
+      if (iter == 1 || (iter > 2 && (iter - 1) % agx::kRhoInterval == 0))
+        hipLaunchKernelGGL((agx::k_admm_tile<NV>), dim3(g8b), dim3(128), 0, o->stream, o->d_ocp, o->d_qt, o->d_qt2, o->d_aux, o->d_cx,
+                           o->d_du, o->d_cjac, o->d_y, o->d_z, o->d_state);
       hipLaunchKernelGGL((agx::k_riccati_admm<NV>), dim3(o->B), dim3(64), 0, o->stream, o->d_ocp, o->d_dt, o->d_qt2, o->d_aux, o->d_Kws,
                          o->d_kws, o->d_dx, o->d_w, o->d_du, o->d_Kout, o->d_state, o->d_fac);
       hipLaunchKernelGGL((agx::k_admm_update<NV>), dim3(g8), dim3(256), 0, o->stream, o->d_ocp, o->d_qt, o->d_aux, o->d_dx, o->d_w,
-                         o->d_du, o->d_cx, o->d_cg, o->d_cjac, o->d_y, o->d_z, o->d_nodestat, o->d_admmstat, o->d_state);
+                         o->d_du, o->d_cx, o->d_cg, o->d_cjac, o->d_y, o->d_z, o->d_nodestat, o->d_admmstat, o->d_qt2, o->d_state);
       hipLaunchKernelGGL(agx::k_admm_reduce, dim3(o->B), dim3(128), 0, o->stream, o->d_ocp, o->d_admmstat, o->d_state, iter,
                          o->d_ndone + 1);
       HIPCHK(hipGetLastError());
@@ -635,6 +640,11 @@ int agx_model_create(const agx_model_desc *d, agx_model **out) {
     std::memcpy(h.frame_placement[f], d->frame_placement + 12 * f, sizeof(double) * 12);
     h.frame_radius[f] = d->frame_radius ? d->frame_radius[f] : 0.0;
     h.frame_halflen[f] = d->frame_halflen ? d->frame_halflen[f] : 0.0;
+    for (int e = 0; e < 3; ++e) h.frame_box[f][e] = d->frame_box ? d->frame_box[3 * f + e] : 0.0;
+    if (h.frame_box[f][0] > 0.0 && !(h.frame_box[f][1] > 0.0 && h.frame_box[f][2] > 0.0)) {
+      delete m;
+      return fail("agx_model_create: box half extents must all be positive");
+    }
   }
   *out = m;
   return 0;
@@ -670,8 +680,10 @@ int agx_ocp_create(const agx_model *m, const agx_ocp_desc *d, int batch, int dev
     if (row.kind == AGX_RES_COLLISION) {
       if (row.frame < 0 || row.frame >= m->h.nframes || row.frame_b < 0 || row.frame_b >= m->h.nframes)
         return fail("agx_ocp_create: collision pair refers to a geometry frame out of range");
-      if (!(m->h.frame_radius[row.frame] > 0.0) || !(m->h.frame_radius[row.frame_b] > 0.0))
-        return fail("agx_ocp_create: collision pair refers to a frame without geometry (radius 0)");
+      if (!agx::frame_has_geometry(m->h, row.frame) || !agx::frame_has_geometry(m->h, row.frame_b))
+        return fail("agx_ocp_create: collision pair refers to a frame without geometry (radius 0, no box)");
+      if (agx::frame_is_box(m->h, row.frame) && agx::frame_is_box(m->h, row.frame_b))
+        return fail("agx_ocp_create: box / box collision pairs are not supported");
     }
   }
   agx_ocp *o = new agx_ocp();

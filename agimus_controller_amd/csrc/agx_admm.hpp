@@ -109,13 +109,14 @@ __global__ void __launch_bounds__(128) k_admm_tile(const DevOcp *__restrict__ op
   const double sig = kSigma, rs = S.rho_sparse;
   const bool jl = l8 < NV, wr = live && jl;
   const int j = jl ? l8 : 0;
+  // runs only where the Hessian part changed (first ADMM iteration of the SQP iteration, or new rho);
+  // otherwise k_admm_update has already written the gradient
+  const bool full = S.admm_refactor != 0;
+  if (!__syncthreads_or(live && full)) return;
   // stage M | tq | tv (contiguous in the aux tile)
   double *sh = lds[grp];
   for (int e = l8; e < 3 * B2; e += 8) sh[e] = ax[A::M + e];
   __syncthreads();
-  // Hessian part only when it changed (first ADMM iteration of the SQP iteration, or new rho); the
-  // gradient part below is rewritten at every iteration from the base tile
-  const bool full = S.admm_refactor != 0;
   if (live && full)
     for (int e = l8; e < Q::SIZE; e += 8) q2[e] = qt[e];
   __syncthreads();
@@ -186,7 +187,7 @@ __global__ void __launch_bounds__(128) k_admm_tile(const DevOcp *__restrict__ op
       }
     }
   }
-  if (wr) {
+  if (wr && full) {
     if (t < T) q2[Q::gw + j] = qt[Q::gw + j] + gwv;
     q2[Q::gx + j] = qt[Q::gx + j] + gq;
     q2[Q::gx + NV + j] = qt[Q::gx + NV + j] + gv;
@@ -198,8 +199,7 @@ __global__ void __launch_bounds__(128) k_admm_tile(const DevOcp *__restrict__ op
 // changed (S.admm_refactor) the full Gauss-Jordan sweep runs and leaves its factors behind
 // (FT: multipliers of the 7 pivots, pivot reciprocals, V' f of every node); otherwise only the
 // gradient recursion is redone with those factors -- the reference makes the same distinction
-// (backwardPass / backwardPass_without_rho_update).  Every lane of grid row r carries the row's
-// three gradient entries redundantly; a pivot is one v_readlane and three FMAs.
+// (backwardPass / backwardPass_without_rho_update).
 // ---------------------------------------------------------------------------
 template <int NV>
 __device__ __forceinline__ void riccati_vec_body(const int b, const DevOcp *__restrict__ op, const double *__restrict__ dts,
@@ -217,43 +217,54 @@ __device__ __forceinline__ void riccati_vec_body(const int b, const DevOcp *__re
   const double *Kw = Kws + (long long)b * T * NV * NX;
   double *kw = kws + (long long)b * T * NV;
   const double *fb = facs + (long long)b * T * F::SIZE;
-  double vxq, vxv;
-  {
-    const double *tt = qb + (long long)T * TS;
-    vxq = tt[Q::gx + rr]; vxv = tt[Q::gx + NV + rr];
-  }
-  struct Node { double gw, gq, gv, rp, pq, pv, fw[NV], fq[NV], fv[NV]; };
+  // Lanes c = 0, 1, 2 of grid row r carry entry r of the three gradient blocks (w | q | v); each has
+  // its own factor column, so a pivot is one v_readlane pair and ONE FMA per lane.
+  const int sel = c < 3 ? c : 0;
+  const int goff = sel == 0 ? Q::gw : (sel == 1 ? Q::gx : Q::gx + NV);
+  const int foff = sel == 0 ? F::FW : (sel == 1 ? F::FQ : F::FV);
+  const int poff = sel == 2 ? F::PV : F::PQ;
+  double v = qb[(long long)T * TS + (sel == 2 ? Q::gx + NV : Q::gx) + rr];  // value-function gradient (c = 1: q, c = 2: v)
+  struct Node { double g, rp, p, h, f[NV]; };
+  int vzero;  // dts through the vector memory path, see riccati_forward
+  asm volatile("v_mov_b32 %0, 0" : "=v"(vzero));
   auto load_node = [&](Node &z, int t) {
     const double *tl = qb + (long long)t * TS;
     const double *ft = fb + (long long)t * F::SIZE;
-    z.gw = tl[Q::gw + rr]; z.gq = tl[Q::gx + rr]; z.gv = tl[Q::gx + NV + rr];
-    z.rp = ft[F::RP + rr]; z.pq = ft[F::PQ + rr]; z.pv = ft[F::PV + rr];
+    z.g = tl[goff + rr];
+    z.rp = ft[F::RP + rr]; z.p = ft[poff + rr];
+    z.h = dts[t + vzero];
 #pragma unroll
-    for (int k = 0; k < NV; ++k) { z.fw[k] = ft[F::FW + k * 8 + rr]; z.fq[k] = ft[F::FQ + k * 8 + rr]; z.fv[k] = ft[F::FV + k * 8 + rr]; }
+    for (int k = 0; k < NV; ++k) z.f[k] = ft[foff + k * 8 + rr];
   };
   auto step = [&](Node &z, int t) {
-    const double h = dts[t], h2 = h * h;
-    const double vpq = vxq + z.pq, vpv = vxv + z.pv;
-    double gW = z.gw + h2 * vpq + h * vpv, gQ = z.gq + vpq, gV = z.gv + h * vpq + vpv;
+    const double h = z.h, h2 = h * h;
+    const double vp = v + z.p;
+    const double vpq = dpp_mov<0x55>(vp), vpv = dpp_mov<0xAA>(vp);  // quad broadcast of lanes c = 1 / c = 2
+    const double ca = sel == 0 ? h2 : (sel == 1 ? 1.0 : h), cb = sel == 0 ? h : (sel == 1 ? 0.0 : 1.0);
+    double g = z.g + ca * vpq + cb * vpv;  // gw + h2 vpq + h vpv | gq + vpq | gv + h vpq + vpv
     const double rp = z.rp;
-    double fw[NV], fq[NV], fv[NV];
+    double f[NV];
 #pragma unroll
-    for (int k = 0; k < NV; ++k) { fw[k] = z.fw[k]; fq[k] = z.fq[k]; fv[k] = z.fv[k]; }
-    if (t >= 2) load_node(z, t - 2);
+    for (int k = 0; k < NV; ++k) f[k] = z.f[k];
+    if (t >= 4) load_node(z, t - 4);
 #pragma unroll
     for (int k = 0; k < NV; ++k) {
-      const double gk = readlane_f64(gW, 8 * k);  // row k's entry (its own factor fw[k] is 0 there)
-      gW -= fw[k] * gk; gQ -= fq[k] * gk; gV -= fv[k] * gk;
+      const double gk = readlane_f64(g, 8 * k);  // gW of row k (its own factor fw[k] is 0 there)
+      g -= f[k] * gk;
     }
-    if (c == 0 && r < NV) kw[(long long)t * NV + r] = gW * rp;
-    vxq = gQ; vxv = gV;
+    if (c == 0 && r < NV) kw[(long long)t * NV + r] = g * rp;
+    v = g;
   };
-  Node na, nb;
-  load_node(na, T - 1);
-  if (T >= 2) load_node(nb, T - 2);
-  for (int t = T - 1; t >= 0; t -= 2) {
-    step(na, t);
-    if (t >= 1) step(nb, t - 1);
+  Node n0, n1, n2, n3;
+  load_node(n0, T - 1);
+  if (T >= 2) load_node(n1, T - 2);
+  if (T >= 3) load_node(n2, T - 3);
+  if (T >= 4) load_node(n3, T - 4);
+  for (int t = T - 1; t >= 0; t -= 4) {
+    step(n0, t);
+    if (t >= 1) step(n1, t - 1);
+    if (t >= 2) step(n2, t - 2);
+    if (t >= 3) step(n3, t - 3);
   }
   riccati_forward<NV>(b, T, dts, qb, Kw, kw, dxs, wss);
 }
@@ -287,7 +298,8 @@ __global__ void __launch_bounds__(256) k_admm_update(const DevOcp *__restrict__ 
                                                      double *__restrict__ cxs, const double *__restrict__ cg,
                                                      const double *__restrict__ cjac, double *__restrict__ ys,
                                                      double *__restrict__ zs, double *__restrict__ nodestat,
-                                                     double *__restrict__ admmstat, const DevState *__restrict__ st) {
+                                                     double *__restrict__ admmstat, double *__restrict__ qt2s,
+                                                     const DevState *__restrict__ st) {
   constexpr int NX = 2 * NV;
   typedef QT<NV> Q;
   typedef AUX<NV> A;
@@ -315,6 +327,7 @@ __global__ void __launch_bounds__(256) k_admm_update(const DevOcp *__restrict__ 
   const double dq = jl ? dx[jj] : 0.0, dv = jl ? dx[NV + jj] : 0.0;
   const double cq = jl ? cx[jj] : 0.0, cv = jl ? cx[NV + jj] : 0.0;
   double du = 0.0, duc = 0.0, kkt = 0.0, gap = 0.0;
+  double Mr[8], tqr[8], tvr[8];  // M[i][l8], taux[i][l8]: operands of du here and of the next gradient below
   if (t < T) {
     const double wj = jl ? wss[((long long)b * T + t) * NV + jj] : 0.0;
     const double fq = jl ? qt[Q::f + jj] : 0.0, fv = jl ? qt[Q::f + NV + jj] : 0.0;
@@ -322,8 +335,12 @@ __global__ void __launch_bounds__(256) k_admm_update(const DevOcp *__restrict__ 
     gap = fabs(fq) + fabs(fv);
     double pr[8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
-      pr[i] = (i < NV) ? ax[A::M + i * A::LD + l8] * wj + ax[A::tq + i * A::LD + l8] * dq + ax[A::tv + i * A::LD + l8] * dv : 0.0;
+    for (int i = 0; i < 8; ++i) {
+      Mr[i] = (i < NV) ? ax[A::M + i * A::LD + l8] : 0.0;
+      tqr[i] = (i < NV) ? ax[A::tq + i * A::LD + l8] : 0.0;
+      tvr[i] = (i < NV) ? ax[A::tv + i * A::LD + l8] : 0.0;
+      pr[i] = Mr[i] * wj + tqr[i] * dq + tvr[i] * dv;
+    }
     du = transpose_reduce8(pr, l8);
     duc = jl ? dus[((long long)b * T + t) * NV + jj] : 0.0;
   }
@@ -331,6 +348,7 @@ __global__ void __launch_bounds__(256) k_admm_update(const DevOcp *__restrict__ 
   double primal = 0.0, primal_rel = 0.0;
   double dual_q = 0.0, dual_v = 0.0, dual_u = 0.0, drel_q = 0.0, drel_v = 0.0, drel_u = 0.0;  // (G' rho dz)_j, (G' y)_j
   double e_q = 0.0, e_v = 0.0, e_u = 0.0;                                                   // (G' (rho C d + h - y))_j
+  double hn_q = 0.0, hn_v = 0.0, hn_u = 0.0;  // (G' (y - rho z))_j with the updated y, z: the next iteration's gradient terms
   auto comp = [&](int k, double Cd, double &dual, double &drel, double &e, double jac) {
     const double rho = admm_rho(c.lb[k], c.ub[k], rs);
     const double z0 = z[k], y0 = y[k];
@@ -350,12 +368,15 @@ __global__ void __launch_bounds__(256) k_admm_update(const DevOcp *__restrict__ 
     if (c.kind[r] == AGX_RES_CONTROL) {
       if (jl && t < T) {
         const double2 zy = comp(off + jj, du, dual_u, drel_u, e_u, 1.0);
+        hn_u += zy.y - admm_rho(c.lb[off + jj], c.ub[off + jj], rs) * zy.x;
         if (act) { z[off + jj] = zy.x; y[off + jj] = zy.y; }
       }
     } else if (c.kind[r] == AGX_RES_STATE) {
       if (jl) {
         const double2 a = comp(off + jj, dq, dual_q, drel_q, e_q, 1.0);
         const double2 bq = comp(off + NV + jj, dv, dual_v, drel_v, e_v, 1.0);
+        hn_q += a.y - admm_rho(c.lb[off + jj], c.ub[off + jj], rs) * a.x;
+        hn_v += bq.y - admm_rho(c.lb[off + NV + jj], c.ub[off + NV + jj], rs) * bq.x;
         if (act) { z[off + jj] = a.x; y[off + jj] = a.y; z[off + NV + jj] = bq.x; y[off + NV + jj] = bq.y; }
       }
     } else if (c.kind[r] == AGX_RES_COLLISION) {
@@ -363,6 +384,7 @@ __global__ void __launch_bounds__(256) k_admm_update(const DevOcp *__restrict__ 
       double Cd = gj * dq;
       Cd += dpp_xor4(Cd); Cd += dpp_xor2(Cd); Cd += dpp_xor1(Cd);
       const double2 zy = comp(off, Cd, dual_q, drel_q, e_q, gj);  // identical on every lane of the group
+      hn_q += (zy.y - admm_rho(c.lb[off], c.ub[off], rs) * zy.x) * gj;
       if (act && l8 == 0) { z[off] = zy.x; y[off] = zy.y; }
     }
   }
@@ -387,8 +409,24 @@ __global__ void __launch_bounds__(256) k_admm_update(const DevOcp *__restrict__ 
   primal_rel = fmax(primal_rel, dpp_xor4(primal_rel)); primal_rel = fmax(primal_rel, dpp_xor2(primal_rel)); primal_rel = fmax(primal_rel, dpp_xor1(primal_rel));
   dual = fmax(dual, dpp_xor4(dual)); dual = fmax(dual, dpp_xor2(dual)); dual = fmax(dual, dpp_xor1(dual));
   drel = fmax(drel, dpp_xor4(drel)); drel = fmax(drel, dpp_xor2(drel)); drel = fmax(drel, dpp_xor1(drel));
+  // Gradient of the next ADMM iteration's augmented tile (what k_admm_tile computes from y, z, cx, du),
+  // valid while rho stays: after a rho update k_admm_tile rebuilds Hessian and gradient.
+  //   g = g0 + [taux M]' (h_u - sigma du) - sigma dx + h_x
+  double gwn = 0.0, gqn = hn_q - sig * dq, gvn = hn_v - sig * dv;
+  if (t < T) {
+    const double e_own = hn_u - sig * du;
+#pragma unroll
+    for (int l = 0; l < NV; ++l) {
+      const double e = __shfl(e_own, l, 8);
+      gwn += Mr[l] * e; gqn += tqr[l] * e; gvn += tvr[l] * e;
+    }
+  }
   if (act) {
     if (jl) {
+      double *q2 = qt2s + nid * Q::SIZE;
+      if (t < T) q2[Q::gw + l8] = qt[Q::gw + l8] + gwn;
+      q2[Q::gx + l8] = qt[Q::gx + l8] + gqn;
+      q2[Q::gx + NV + l8] = qt[Q::gx + NV + l8] + gvn;
       if (t < T) dus[((long long)b * T + t) * NV + l8] = du;
       cx[l8] = dq; cx[NV + l8] = dv;  // prox centre of the next iteration
     }

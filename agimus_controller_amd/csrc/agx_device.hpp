@@ -32,6 +32,7 @@ struct DevModel {
   int frame_parent[AGX_MAX_FRAMES];
   double frame_placement[AGX_MAX_FRAMES][12];
   double frame_radius[AGX_MAX_FRAMES], frame_halflen[AGX_MAX_FRAMES];  // collision geometry carried by frames
+  double frame_box[AGX_MAX_FRAMES][3];                                 // box half extents (all 0: capsule / sphere)
 };
 
 struct DevRows {
@@ -64,6 +65,7 @@ struct DevOcp {
 };
 
 #define AGX_DEV __device__ __forceinline__
+#define AGX_HD __host__ __device__ __forceinline__
 // loops over the joints: fully unrolled for the register-resident sizes (nv <= 8), rolled for
 // large models (nv = 30: per-lane arrays live in scratch, the code must stay small)
 #define AGX_UNROLL_NV _Pragma("clang loop unroll_count(NV <= 8 ? 64 : 1)")
@@ -722,8 +724,36 @@ AGX_DEV void closest_seg_seg(const double *a0, const double *a1, const double *b
   else if (t > 1.0) { t = 1.0; s = clamp01((b - c) / a); }
 }
 
-// Signed distance of two capsule / sphere geometry frames and the witness points on the segments:
-//   d = |ca - cb| - ra - rb,  n = (ca - cb) / |ca - cb|;  d'(q) = n' (Ja(ca) - Jb(cb)).
+// Parameter s in [-h, h] of the point of the segment c + s d closest to the box |x_i| <= b_i (all in
+// the box frame).  f(s) = dist^2 is convex and piecewise quadratic, f' monotone: bisection on f'.
+AGX_HD double seg_box_param(const double *c, const double *d, double h, const double *b) {
+  auto fp = [&](double s) {
+    double g = 0.0;
+    for (int i = 0; i < 3; ++i) {
+      const double x = c[i] + s * d[i], e = fabs(x) - b[i];
+      if (e > 0.0) g += (x > 0.0 ? e : -e) * d[i];
+    }
+    return g;
+  };
+  if (!(h > 0.0)) return 0.0;
+  double lo = -h, hi = h;
+  if (fp(lo) >= 0.0) return lo;
+  if (fp(hi) <= 0.0) return hi;
+  for (int it = 0; it < 60; ++it) {
+    const double mid = 0.5 * (lo + hi);
+    if (fp(mid) < 0.0) lo = mid; else hi = mid;
+  }
+  return 0.5 * (lo + hi);
+}
+
+AGX_HD bool frame_is_box(const DevModel &m, int f) { return m.frame_box[f][0] > 0.0; }
+AGX_HD bool frame_has_geometry(const DevModel &m, int f) { return m.frame_radius[f] > 0.0 || frame_is_box(m, f); }
+
+// Signed distance of two geometry frames and the witness points (on the capsule segments / on the
+// box):  d = sgn |ca - cb| - ra - rb,  n = sgn (ca - cb) / |ca - cb|;  d'(q) = n' (Ja(ca) - Jb(cb)).
+// Capsule / sphere pairs: segment-segment closest points.  Box against capsule / sphere: closest
+// point of the segment to the box; when that point lies inside the box (sgn = -1) the box witness is
+// its projection on the nearest face (a simple penetration model, not coal's EPA depth).
 template <int NV>
 AGX_DEV double collision_distance(const DevModel &m, const Kin<NV> &k, int fa, int fb, double *ca, double *cb, double *n,
                                   int *ja, int *jb) {
@@ -731,26 +761,65 @@ AGX_DEV double collision_distance(const DevModel &m, const Kin<NV> &k, int fa, i
   frame_world<NV>(m, k, fa, Ra, pa, ja);
   frame_world<NV>(m, k, fb, Rb, pb, jb);
   const double ha = m.frame_halflen[fa], hb = m.frame_halflen[fb];
-  double a0[3], a1[3], b0[3], b1[3];
+  double sgn = 1.0;
+  if (frame_is_box(m, fa) || frame_is_box(m, fb)) {
+    const bool bb = frame_is_box(m, fb);  // which of the two is the box
+    const double *Rx = bb ? Rb : Ra, *px = bb ? pb : pa, *Rc = bb ? Ra : Rb, *pc = bb ? pa : pb;
+    const double *half = m.frame_box[bb ? fb : fa];
+    const double hc = bb ? ha : hb;
+    double rel[3], cl[3], dl[3], zc[3] = {Rc[2], Rc[5], Rc[8]};
 #pragma unroll
-  for (int e = 0; e < 3; ++e) {
-    a0[e] = pa[e] - ha * Ra[3 * e + 2]; a1[e] = pa[e] + ha * Ra[3 * e + 2];
-    b0[e] = pb[e] - hb * Rb[3 * e + 2]; b1[e] = pb[e] + hb * Rb[3 * e + 2];
+    for (int e = 0; e < 3; ++e) rel[e] = pc[e] - px[e];
+    mtv3(Rx, rel, cl);
+    mtv3(Rx, zc, dl);
+    const double s = seg_box_param(cl, dl, hc, half);
+    double x[3], y[3];
+    bool inside = true;
+#pragma unroll
+    for (int e = 0; e < 3; ++e) {
+      x[e] = cl[e] + s * dl[e];
+      y[e] = x[e] < -half[e] ? -half[e] : (x[e] > half[e] ? half[e] : x[e]);
+      inside = inside && (y[e] == x[e]);
+    }
+    if (inside) {
+      int best = 0;
+      double depth = half[0] - fabs(x[0]);
+#pragma unroll
+      for (int e = 1; e < 3; ++e)
+        if (half[e] - fabs(x[e]) < depth) { depth = half[e] - fabs(x[e]); best = e; }
+      y[best] = x[best] < 0.0 ? -half[best] : half[best];
+      sgn = -1.0;
+    }
+    double wy[3];
+    mv3(Rx, y, wy);
+    double *cc = bb ? ca : cb, *cx = bb ? cb : ca;
+#pragma unroll
+    for (int e = 0; e < 3; ++e) { cc[e] = pc[e] + s * zc[e]; cx[e] = px[e] + wy[e]; }
+  } else {
+    double a0[3], a1[3], b0[3], b1[3];
+#pragma unroll
+    for (int e = 0; e < 3; ++e) {
+      a0[e] = pa[e] - ha * Ra[3 * e + 2]; a1[e] = pa[e] + ha * Ra[3 * e + 2];
+      b0[e] = pb[e] - hb * Rb[3 * e + 2]; b1[e] = pb[e] + hb * Rb[3 * e + 2];
+    }
+    double sa, sb;
+    closest_seg_seg(a0, a1, b0, b1, sa, sb);
+#pragma unroll
+    for (int e = 0; e < 3; ++e) {
+      ca[e] = pa[e] + ((2.0 * sa - 1.0) * ha) * Ra[3 * e + 2];
+      cb[e] = pb[e] + ((2.0 * sb - 1.0) * hb) * Rb[3 * e + 2];
+    }
   }
-  double sa, sb;
-  closest_seg_seg(a0, a1, b0, b1, sa, sb);
   double d2 = 0.0;
 #pragma unroll
   for (int e = 0; e < 3; ++e) {
-    ca[e] = pa[e] + ((2.0 * sa - 1.0) * ha) * Ra[3 * e + 2];
-    cb[e] = pb[e] + ((2.0 * sb - 1.0) * hb) * Rb[3 * e + 2];
     n[e] = ca[e] - cb[e];
     d2 += n[e] * n[e];
   }
-  const double dn = sqrt(d2), inv = dn > 0.0 ? 1.0 / dn : 0.0;
+  const double dn = sqrt(d2), inv = dn > 0.0 ? sgn / dn : 0.0;
 #pragma unroll
   for (int e = 0; e < 3; ++e) n[e] *= inv;
-  return dn - (m.frame_radius[fa] + m.frame_radius[fb]);
+  return sgn * dn - (m.frame_radius[fa] + m.frame_radius[fb]);
 }
 
 template <int NV>

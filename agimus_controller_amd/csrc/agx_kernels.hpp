@@ -528,7 +528,11 @@ __device__ __forceinline__ double fast_rcp(double x) {
 // on Hxx; the corrections  sigma [taux M]' [taux M]  are formed on the fly from the aux tile, the
 // gradient recursion is skipped (it does not influence the gains) and the gains are mapped to
 // u-space in registers:  K = M Kw - taux  -> Kout.  No forward pass.
-// Linear forward pass of one instance with the gains (Kw, kw) of the backward sweep.
+// Linear forward pass of one instance with the gains (Kw, kw) of the backward sweep, on the same
+// 8 x 8 lane grid as the backward sweep: lane (r, c) holds Kw[r][c] (q and v halves), the state lives
+// twice -- indexed by the lane's column (operand of the products) and by its row (the update).
+// Per node: two FMAs, a DPP row reduction (w = -kw - Kw dx), the lane-local state update and one
+// transposing broadcast of the new state (row r's value to every lane of column r).
 template <int NV>
 __device__ __forceinline__ void riccati_forward(const int b, const int T, const double *__restrict__ dts, const double *__restrict__ qb,
                                                 const double *__restrict__ Kw, const double *__restrict__ kw,
@@ -536,50 +540,57 @@ __device__ __forceinline__ void riccati_forward(const int b, const int T, const 
   constexpr int NX = 2 * NV, TS = QT<NV>::SIZE;
   typedef QT<NV> Q;
   const int lane = threadIdx.x;
-  // ---- forward pass: lane a < NV owns joint a (dx_q[a], dx_v[a], w[a]); the only cross-lane traffic
-  // is the broadcast of dx to every lane (v_readlane), the state update is lane-local.
+  const int r = lane >> 3, c = lane & 7;
+  const bool in = (r < NV) && (c < NV);
+  const int rr = r < NV ? r : 0, cc = c < NV ? c : 0;
   double *dx = dxs + (long long)b * (T + 1) * NX, *ws = wss + (long long)b * T * NV;
-  double dq = 0.0, dv = 0.0;
   if (lane < NV) { dx[lane] = 0.0; dx[NV + lane] = 0.0; }
-  __threadfence_block();  // the gains written above are read back by other lanes below
-  const int la = lane < NV ? lane : 0;
-  struct Gain { double k[NX], kw, fq, fv; };
+  __threadfence_block();  // the gains written by the backward sweep are read back by other lanes below
+  double dq_r = 0.0, dv_r = 0.0, dq_c = 0.0, dv_c = 0.0;
+  struct Gain { double kq, kv, kw, fq, fv, h; };
+  // dts through the vector memory path (index laundered through a VGPR): a scalar load would put an
+  // s_waitcnt lgkmcnt(0) -- which also drains the ds_bpermutes -- on every node of the chain
+  int vzero;
+  asm volatile("v_mov_b32 %0, 0" : "=v"(vzero));
+#ifndef AGX_FWD_DEPTH
+#define AGX_FWD_DEPTH 8
+#endif
+  constexpr int FWD_DEPTH = AGX_FWD_DEPTH;  // nodes of gains in flight: covers the HBM latency of the read-back
   auto load_gain = [&](Gain &g, int t) {
-AGX_UNROLL_NV
-    for (int j = 0; j < NX; ++j) g.k[j] = Kw[(long long)t * NV * NX + la * NX + j];
-    g.kw = kw[(long long)t * NV + la];
-    g.fq = qb[(long long)t * TS + Q::f + la];
-    g.fv = qb[(long long)t * TS + Q::f + NV + la];
+    const double *kr = Kw + ((long long)t * NV + rr) * NX;
+    g.kq = in ? kr[cc] : 0.0;
+    g.kv = in ? kr[NV + cc] : 0.0;
+    g.kw = kw[(long long)t * NV + rr];
+    g.fq = qb[(long long)t * TS + Q::f + rr];
+    g.fv = qb[(long long)t * TS + Q::f + NV + rr];
+    g.h = dts[t + vzero];
   };
   auto fstep = [&](Gain &g, int t) {
-    const double h = dts[t], h2 = h * h;
-    double w0 = -g.kw, w1 = 0.0;  // two accumulation chains
-AGX_UNROLL_NV
-    for (int j = 0; j < NV; ++j) {
-      w0 -= g.k[j] * readlane_f64(dq, j);
-      w1 -= g.k[NV + j] * readlane_f64(dv, j);
-    }
-    const double wv = w0 + w1, fqc = g.fq, fvc = g.fv;
-    if (t + 4 < T) load_gain(g, t + 4);  // refill this register set four nodes ahead
-    const double nq = dq + h * dv + h2 * wv + fqc;
-    const double nv2 = dv + h * wv + fvc;
-    dq = nq; dv = nv2;
-    if (lane < NV) {
-      ws[(long long)t * NV + lane] = wv;
-      dx[(long long)(t + 1) * NX + lane] = dq;
-      dx[(long long)(t + 1) * NX + NV + lane] = dv;
+    const double h = g.h, h2 = h * h;
+    double p = g.kq * dq_c + g.kv * dv_c;
+    const double kwv = g.kw, fqc = g.fq, fvc = g.fv;
+    if (t + FWD_DEPTH < T) load_gain(g, t + FWD_DEPTH);  // refill this register set FWD_DEPTH nodes ahead
+    p += dpp_xor1(p); p += dpp_xor2(p); p += dpp_xor4(p);  // row sum, on every lane of the row
+    const double wv = -(kwv + p);
+    const double nq = dq_r + h * dv_r + h2 * wv + fqc;
+    const double nv2 = dv_r + h * wv + fvc;
+    dq_r = nq; dv_r = nv2;
+    dq_c = __shfl(nq, 8 * cc, 64);   // row cc's value (lane (cc, 0)) to every lane of column cc
+    dv_c = __shfl(nv2, 8 * cc, 64);
+    if (c == 0 && r < NV) {
+      ws[(long long)t * NV + r] = wv;
+      dx[(long long)(t + 1) * NX + r] = nq;
+      dx[(long long)(t + 1) * NX + NV + r] = nv2;
     }
   };
-  Gain g0, g1, g2, g3;
-  load_gain(g0, 0);
-  if (T > 1) load_gain(g1, 1);
-  if (T > 2) load_gain(g2, 2);
-  if (T > 3) load_gain(g3, 3);
-  for (int t = 0; t < T; t += 4) {
-    fstep(g0, t);
-    if (t + 1 < T) fstep(g1, t + 1);
-    if (t + 2 < T) fstep(g2, t + 2);
-    if (t + 3 < T) fstep(g3, t + 3);
+  Gain g[FWD_DEPTH];
+#pragma unroll
+  for (int i = 0; i < FWD_DEPTH; ++i)
+    if (i < T) load_gain(g[i], i);
+  for (int t = 0; t < T; t += FWD_DEPTH) {
+#pragma unroll
+    for (int i = 0; i < FWD_DEPTH; ++i)
+      if (t + i < T) fstep(g[i], t + i);
   }
 }
 

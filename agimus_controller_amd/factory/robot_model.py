@@ -43,7 +43,7 @@ class TableModel:
 
 class TableGeometryModel:
     """pinocchio.GeometryModel look-alike over the geometry frames of a RobotTable (capsules /
-    spheres; what factory/robot_model.py:261-302 of the reference leaves in the collision model)."""
+    spheres / boxes; what factory/robot_model.py:261-302 of the reference leaves in the collision model)."""
 
     def __init__(self, table: robot_tables.RobotTable, collision_pairs=()):
         self.table = table
@@ -54,7 +54,9 @@ class TableGeometryModel:
     def existGeometryName(self, name: str) -> bool:
         if name not in self.table.frame_names or self.table.frame_radius is None:
             return False
-        return float(self.table.frame_radius[self.table.frame_names.index(name)]) > 0.0
+        i = self.table.frame_names.index(name)
+        is_box = self.table.frame_box is not None and float(np.asarray(self.table.frame_box).reshape(-1, 3)[i, 0]) > 0.0
+        return float(self.table.frame_radius[i]) > 0.0 or is_box
 
     def getGeometryId(self, name: str) -> int:
         assert self.existGeometryName(name), f"Geometry object '{name}' not found."
@@ -109,7 +111,8 @@ class RobotModels:
         self._table = param.table.with_armature(param.armature)
         self._robot_model = TableModel(self._table)
         self._q0 = param.q0
-        has_geom = self._table.frame_radius is not None and np.any(np.asarray(self._table.frame_radius) > 0.0)
+        has_geom = (self._table.frame_radius is not None and np.any(np.asarray(self._table.frame_radius) > 0.0)) or (
+            self._table.frame_box is not None and np.any(np.asarray(self._table.frame_box) > 0.0))
         self._collision_model = TableGeometryModel(self._table, param.collision_pairs) if has_geom else None
 
     @property

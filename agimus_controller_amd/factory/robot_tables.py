@@ -86,6 +86,7 @@ class RobotTable:
     # (capsule segment along the frame's z axis; 0 = sphere).  None = no frame carries geometry.
     frame_radius: np.ndarray | None = None
     frame_halflen: np.ndarray | None = None
+    frame_box: np.ndarray | None = None  # [nframes,3] half extents of box geometry (coal.Box), zeros = not a box
 
     @property
     def nv(self) -> int:
@@ -102,14 +103,19 @@ class RobotTable:
         assert name in self.frame_names, f"Frame '{name}' does not exist!"
         return self.frame_names.index(name)
 
-    def with_geometry(self, name, parent, placement12, radius, halflen=0.0) -> "RobotTable":
+    def with_geometry(self, name, parent, placement12, radius=0.0, halflen=0.0, box=None) -> "RobotTable":
         """Copy with one more geometry frame: capsule (coal.Capsule(radius, halfLength), the shape
-        factory/robot_model.py:261-302 converts cylinders to) or sphere, attached to joint `parent`
-        (-1 = world, e.g. an obstacle of the environment)."""
+        factory/robot_model.py:261-302 converts cylinders to), sphere, or box (`box` = the three half
+        extents; coal.Box, which the reference keeps as is), attached to joint `parent` (-1 = world,
+        e.g. an obstacle of the environment)."""
         assert name not in self.frame_names, f"frame '{name}' exists"
+        assert (box is None) != (float(radius) <= 0.0), "a geometry is either a box or has a radius"
         n = len(self.frame_names)
         rad = np.zeros(n) if self.frame_radius is None else np.asarray(self.frame_radius, dtype=float)
         hl = np.zeros(n) if self.frame_halflen is None else np.asarray(self.frame_halflen, dtype=float)
+        bx = np.zeros((n, 3)) if self.frame_box is None else np.asarray(self.frame_box, dtype=float).reshape(n, 3)
+        half = np.zeros(3) if box is None else np.asarray(box, dtype=float).reshape(3)
+        assert box is None or np.all(half > 0.0), "box half extents must be positive"
         return dataclasses.replace(
             self,
             frame_names=list(self.frame_names) + [name],
@@ -118,6 +124,7 @@ class RobotTable:
                                        np.asarray(placement12, dtype=float).reshape(1, 12)]),
             frame_radius=np.append(rad, float(radius)),
             frame_halflen=np.append(hl, float(halflen)),
+            frame_box=np.vstack([bx, half.reshape(1, 3)]),
         )
 
     def with_armature(self, armature) -> "RobotTable":
@@ -216,12 +223,16 @@ PANDA_CAPSULES = {
 }
 
 
-def panda_collision_table(armature=0.1, obstacle_xyz=(1.535, 0.0, 0.43), obstacle_radius=0.1, obstacle_length=0.4) -> RobotTable:
+def panda_collision_table(armature=0.1, obstacle_xyz=(1.535, 0.0, 0.43), obstacle_radius=0.1, obstacle_length=0.4,
+                          obstacle_box=None) -> RobotTable:
     """panda_table plus link capsules and the capsule obstacle `obstacle` of the reference's
-    tests/resources/environment.xacro:23-24 (xyz 1.535 0 0.43, direction x, radius 0.1, length 0.4)."""
+    tests/resources/environment.xacro:23-24 (xyz 1.535 0 0.43, direction x, radius 0.1, length 0.4).
+    obstacle_box = (hx, hy, hz): a box obstacle of those half extents instead (world axes)."""
     t = panda_table(armature)
     for name, (parent, placement, radius, halflen) in PANDA_CAPSULES.items():
         t = t.with_geometry(name, parent, placement, radius, halflen)
+    if obstacle_box is not None:
+        return t.with_geometry("obstacle", -1, se3(None, list(obstacle_xyz)), box=obstacle_box)
     # capsule axis (local z) along world x
     return t.with_geometry("obstacle", -1, se3(_ry(np.pi / 2), list(obstacle_xyz)), obstacle_radius, obstacle_length / 2)
 

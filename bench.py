@@ -217,7 +217,7 @@ def main():
     B, T, dt = args.batch, args.horizon, 0.01
     table, tcp, po = make_problem(T, args.workload)
     hip = backend.HipOcp(table, po, B, device=local_rank)
-    n_points = args.warmup + max(args.steps, 200) + T + 2 + 10
+    n_points = args.warmup + max(args.steps, 200) + T + 2 + 32  # + in-situ profile steps + full-download steps
     # per-instance seeds follow the GLOBAL instance index so every rank works on different instances
     nv = table.nv
     q0, amp, puls, scale, t0 = workloads.sine_batch_params(B, nv=nv, seed0=1234 + rank * B, q0=(None if nv == 7 else np.zeros(nv)),
@@ -257,7 +257,7 @@ def main():
             torch.cuda.synchronize()
         hip.sync()
 
-    iters = []
+    iters, iters_max = [], []
     for k in range(args.warmup):
         st = step(k)[3]
     sync_all()
@@ -265,6 +265,7 @@ def main():
     for k in range(args.warmup, args.warmup + args.steps):
         st = step(k)[3]
         iters.append(float(st["iter"].mean()))
+        iters_max.append(int(st["iter"].max()))
     sync_all()
     elapsed = time.perf_counter() - t_start
     solved_frac = float(st["solved"].mean())
@@ -327,6 +328,7 @@ def main():
                 "termination_tolerance": 1e-3,
                 "parallelism": f"batch-sharded x{world}, no data-path collective",
                 "mean_sqp_iters_per_step": float(np.mean(iters)),
+                "mean_sqp_iters_of_slowest_instance": float(np.mean(iters_max)),  # what a batch step costs
                 "solved_fraction_last_step": solved_frac,
                 "step_includes": "window select, x0<-xs[1], warm-start shift, SQP solve, D2H of us[0],K[0],x1,status",
             },
@@ -371,9 +373,22 @@ def main():
                                 "steps": int(len(lat)), "value": 1e3 / ms1, "unit": "MPC steps/s",
                                 "workload": "same, batch = 1 (BASELINE.json configs[1]); per-step host wall time incl. D2H"}
             h1.close()
+        if world == 1 and not args.no_batch1 and args.max_iter != 3:
+            # also the pick-and-place iteration cap (max_iter 3) on the same workload
+            ka = args.warmup + args.steps + min(10, T // 2)
+            na = 8
+            hip.sync()
+            t1 = time.perf_counter()
+            for k in range(ka, ka + na):
+                hip.mpc_step(k, 3, first=False)
+                hip.download_first(copy=False)
+            hip.sync()
+            msa = (time.perf_counter() - t1) / na * 1e3
+            result["max_iter_3"] = {"ms_per_step": msa, "value": B / (msa * 1e-3), "unit": "MPC steps/s",
+                                    "note": "same workload with the pick-and-place cap max_iter = 3"}
         if world == 1 and not args.no_batch1:
             # the same step with the FULL result download (xs, us, K of every node) into pageable memory
-            kf = args.warmup + args.steps + min(10, T // 2)
+            kf = args.warmup + args.steps + min(10, T // 2) + 8
             t1 = time.perf_counter()
             nfull = 3
             for k in range(kf, kf + nfull):

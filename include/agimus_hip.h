@@ -106,6 +106,10 @@ typedef struct agx_model_desc {
    * carries the capsule segment; halflen = 0 is a sphere.  NULL = no geometry.  */
   const double *frame_radius;    /* [nframes]                                   */
   const double *frame_halflen;   /* [nframes]                                   */
+  /* Box geometry (coal.Box is kept as is by factory/robot_model.py:296-302): half extents along the
+   * frame's axes, all 0 = not a box.  Pairs box / capsule and box / sphere are supported, box / box
+   * is refused by agx_ocp_create.  NULL = no boxes.                              */
+  const double *frame_box;       /* [nframes][3]                                */
 } agx_model_desc;
 
 /* Shooting problem + solver knobs:

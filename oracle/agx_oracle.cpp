@@ -84,6 +84,7 @@ struct Model {
   std::vector<int> parent, frame_parent;
   std::vector<double> placement, axis, mass, com, inertia, armature, effort_limit, frame_placement;
   std::vector<double> frame_radius, frame_halflen;  // collision geometry carried by frames (0 = none / sphere)
+  std::vector<double> frame_box;                    // [nframes][3] box half extents (0 = not a box)
   double gravity[3] = {0, 0, -9.81};
 };
 
@@ -105,6 +106,8 @@ void copy_model(const agx_model_desc *d, Model &m) {
     m.frame_halflen.assign(d->nframes, 0.0);
     if (d->frame_radius) m.frame_radius.assign(d->frame_radius, d->frame_radius + d->nframes);
     if (d->frame_halflen) m.frame_halflen.assign(d->frame_halflen, d->frame_halflen + d->nframes);
+    m.frame_box.assign(3 * d->nframes, 0.0);
+    if (d->frame_box) m.frame_box.assign(d->frame_box, d->frame_box + 3 * d->nframes);
   }
 }
 
@@ -537,29 +540,91 @@ void closest_seg_seg(const double *a0, const double *a1, const double *b0, const
   else if (t > 1.0) { t = 1.0; s = clamp01((b - c) / a); }
 }
 
-// signed distance of two capsule / sphere geometry frames: |pa - pb| - ra - rb with pa, pb the
-// closest points of the segments; the segment parameters are held fixed while differentiating,
+// parameter s in [-h, h] of the point of the segment c + s d closest to the box |x_i| <= b_i (box
+// frame): dist^2 is convex along the segment, bisection on its monotone derivative
+double seg_box_param(const double *c, const double *d, double h, const double *b) {
+  auto fp = [&](double s) {
+    double g = 0.0;
+    for (int i = 0; i < 3; ++i) {
+      const double x = c[i] + s * d[i], e = fabs(x) - b[i];
+      if (e > 0.0) g += (x > 0.0 ? e : -e) * d[i];
+    }
+    return g;
+  };
+  if (!(h > 0.0)) return 0.0;
+  double lo = -h, hi = h;
+  if (fp(lo) >= 0.0) return lo;
+  if (fp(hi) <= 0.0) return hi;
+  for (int it = 0; it < 60; ++it) {
+    const double mid = 0.5 * (lo + hi);
+    if (fp(mid) < 0.0) lo = mid; else hi = mid;
+  }
+  return 0.5 * (lo + hi);
+}
+
+// signed distance of two geometry frames: sgn |pa - pb| - ra - rb with pa, pb the witness points
+// (closest points of the capsule segments; for a box against a capsule / sphere the closest point of
+// the segment and its clamp on the box, or -- segment point inside the box, sgn = -1 -- its projection
+// on the nearest face).  The witness points are held fixed in their bodies while differentiating,
 // which gives exactly  d'(q) = n' (Ja(pa) - Jb(pb))  (App. A.6).
 template <class S> S collision_distance(const Model &m, int fa, int fb, const S *q) {
   S Ra[9], pa[3], Rb[9], pb[3];
   frame_placement(m, fa, q, Ra, pa);
   frame_placement(m, fb, q, Rb, pb);
   const double ha = m.frame_halflen[fa], hb = m.frame_halflen[fb];
-  double a0[3], a1[3], b0[3], b1[3];
-  for (int k = 0; k < 3; ++k) {
-    a0[k] = val(pa[k]) - ha * val(Ra[3 * k + 2]); a1[k] = val(pa[k]) + ha * val(Ra[3 * k + 2]);
-    b0[k] = val(pb[k]) - hb * val(Rb[3 * k + 2]); b1[k] = val(pb[k]) + hb * val(Rb[3 * k + 2]);
-  }
-  double sa, sb;
-  closest_seg_seg(a0, a1, b0, b1, sa, sb);
+  const bool box_a = m.frame_box[3 * fa] > 0.0, box_b = m.frame_box[3 * fb] > 0.0;
   S d2 = S(0.0);
-  for (int k = 0; k < 3; ++k) {
-    S ca = pa[k] + ((2.0 * sa - 1.0) * ha) * Ra[3 * k + 2];
-    S cb = pb[k] + ((2.0 * sb - 1.0) * hb) * Rb[3 * k + 2];
-    S e = ca - cb;
-    d2 = d2 + e * e;
+  double sgn = 1.0;
+  if (box_a || box_b) {
+    const S *Rx = box_b ? Rb : Ra, *px = box_b ? pb : pa, *Rc = box_b ? Ra : Rb, *pc = box_b ? pa : pb;
+    const double *half = &m.frame_box[3 * (box_b ? fb : fa)];
+    const double hc = box_b ? ha : hb;
+    double cl[3], dl[3];
+    for (int i = 0; i < 3; ++i) {
+      cl[i] = 0.0; dl[i] = 0.0;
+      for (int k = 0; k < 3; ++k) {
+        cl[i] += val(Rx[3 * k + i]) * (val(pc[k]) - val(px[k]));
+        dl[i] += val(Rx[3 * k + i]) * val(Rc[3 * k + 2]);
+      }
+    }
+    const double s = seg_box_param(cl, dl, hc, half);
+    double x[3], y[3];
+    bool inside = true;
+    for (int i = 0; i < 3; ++i) {
+      x[i] = cl[i] + s * dl[i];
+      y[i] = x[i] < -half[i] ? -half[i] : (x[i] > half[i] ? half[i] : x[i]);
+      inside = inside && (y[i] == x[i]);
+    }
+    if (inside) {
+      int best = 0;
+      double depth = half[0] - fabs(x[0]);
+      for (int i = 1; i < 3; ++i)
+        if (half[i] - fabs(x[i]) < depth) { depth = half[i] - fabs(x[i]); best = i; }
+      y[best] = x[best] < 0.0 ? -half[best] : half[best];
+      sgn = -1.0;
+    }
+    for (int k = 0; k < 3; ++k) {
+      S cc = pc[k] + s * Rc[3 * k + 2];
+      S cx = px[k] + (Rx[3 * k + 0] * y[0] + Rx[3 * k + 1] * y[1] + Rx[3 * k + 2] * y[2]);
+      S e = cc - cx;
+      d2 = d2 + e * e;
+    }
+  } else {
+    double a0[3], a1[3], b0[3], b1[3];
+    for (int k = 0; k < 3; ++k) {
+      a0[k] = val(pa[k]) - ha * val(Ra[3 * k + 2]); a1[k] = val(pa[k]) + ha * val(Ra[3 * k + 2]);
+      b0[k] = val(pb[k]) - hb * val(Rb[3 * k + 2]); b1[k] = val(pb[k]) + hb * val(Rb[3 * k + 2]);
+    }
+    double sa, sb;
+    closest_seg_seg(a0, a1, b0, b1, sa, sb);
+    for (int k = 0; k < 3; ++k) {
+      S ca = pa[k] + ((2.0 * sa - 1.0) * ha) * Ra[3 * k + 2];
+      S cb = pb[k] + ((2.0 * sb - 1.0) * hb) * Rb[3 * k + 2];
+      S e = ca - cb;
+      d2 = d2 + e * e;
+    }
   }
-  return sqrt(d2) - (m.frame_radius[fa] + m.frame_radius[fb]);
+  return sgn * sqrt(d2) - (m.frame_radius[fa] + m.frame_radius[fb]);
 }
 
 // ---------------------------------------------------------------------------

@@ -58,9 +58,37 @@ def test_capsule_capsule_cases():
         assert res[0] == pytest.approx(want - 0.12, abs=1e-12)
 
 
-@pytest.mark.parametrize("rows", ["collision", "collision_exp"])
-def test_collision_cost_gradient_matches_finite_differences(rows):
-    table = rt.panda_collision_table(0.1, obstacle_xyz=(0.45, 0.1, 0.45), obstacle_radius=0.08, obstacle_length=0.3)
+def test_box_against_sphere_and_capsule_cases():
+    """coal.Box geometry (kept by factory/robot_model.py:296-302) against spheres / capsules: face,
+    edge, corner, rotated-box and penetrating configurations against hand results."""
+    base = rt.pendulum_table()
+    half = (0.5, 0.3, 0.2)
+    rz45 = rt.rpy(0.0, 0.0, np.pi / 4)
+    cases = [
+        # (box placement, other placement, radius, halflen, signed distance)
+        (rt.se3(None, [0, 0, 0]), rt.se3(None, [2.0, 0, 0]), 0.1, 0.0, 1.5 - 0.1),  # sphere, face
+        (rt.se3(None, [0, 0, 0]), rt.se3(None, [1.5, 1.3, 0]), 0.1, 0.0, np.sqrt(2.0) - 0.1),  # sphere, edge
+        (rt.se3(None, [0, 0, 0]), rt.se3(None, [1.5, 1.3, 1.2]), 0.1, 0.0, np.sqrt(3.0) - 0.1),  # sphere, corner
+        (rt.se3(None, [0, 0, 0]), rt.se3(None, [0.4, 0.0, 0.0]), 0.05, 0.0, -0.1 - 0.05),  # sphere centre inside: nearest face x
+        (rt.se3(None, [0, 0, 0]), rt.se3(None, [1.0, 0, 0]), 0.1, 0.6, 0.5 - 0.1),  # capsule parallel to a face (axis z)
+        (rt.se3(None, [0, 0, 0]), rt.se3(rt._ry(np.pi / 2), [0.2, 0, 1.0]), 0.1, 0.5, 0.8 - 0.1),  # capsule along x above the top face
+        (rt.se3(None, [0, 0, 0]), rt.se3(rt._ry(np.pi / 2), [2.0, 0, 0]), 0.1, 0.5, 1.0 - 0.1),  # capsule end cap to the x face
+        (rt.se3(rz45, [0, 0, 0]), rt.se3(None, [2.0, 0, 0]), 0.1, 0.0, np.hypot(2.0 - 0.8 / np.sqrt(2.0), 0.2 / np.sqrt(2.0)) - 0.1),  # rotated box: vertical edge at R (0.5, -0.3)
+    ]
+    for swap in (False, True):
+        for pb, po_, rad, hl, want in cases:
+            t = base.with_geometry("box", -1, pb, box=half).with_geometry("other", -1, po_, rad, hl)
+            a, b = ("other", "box") if swap else ("box", "other")
+            rows = [_abi.RowSpec(_abi.RES_COLLISION, frame=t.frame_id(a), frame_b=t.frame_id(b))]
+            po = _abi.PackedOcp(1, [0.01], rows, rows)
+            o = _oracle(t, po)
+            _, _, res = o.node_calc(True, 0.0, np.zeros(2), None, po.new_ref_tile(1)[0, 0])
+            assert res[0] == pytest.approx(want, abs=1e-9), (swap, want)
+
+
+@pytest.mark.parametrize("rows,box", [("collision", None), ("collision_exp", None), ("collision", (0.1, 0.15, 0.08))])
+def test_collision_cost_gradient_matches_finite_differences(rows, box):
+    table = rt.panda_collision_table(0.1, obstacle_xyz=(0.45, 0.1, 0.45), obstacle_radius=0.08, obstacle_length=0.3, obstacle_box=box)
     tcp = table.frame_id("panda_hand_tcp")
     po, ref, x0, xs, us = workloads.random_goal_problem(table, 3, 0.01, 2, 11, frame=tcp, rows=rows)
     o = _oracle(table, po, 2)
@@ -109,11 +137,11 @@ def test_yaml_lowering_of_the_collision_avoidance_definition():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("rows", ["collision", "collision_exp"])
-def test_hip_collision_tiles_and_solve_match_the_checker(rows):
+@pytest.mark.parametrize("rows,box", [("collision", None), ("collision_exp", None), ("collision", (0.1, 0.15, 0.08))])
+def test_hip_collision_tiles_and_solve_match_the_checker(rows, box):
     from agimus_controller_amd import backend
 
-    table = rt.panda_collision_table(0.1, obstacle_xyz=(0.45, 0.1, 0.45), obstacle_radius=0.08, obstacle_length=0.3)
+    table = rt.panda_collision_table(0.1, obstacle_xyz=(0.45, 0.1, 0.45), obstacle_radius=0.08, obstacle_length=0.3, obstacle_box=box)
     tcp = table.frame_id("panda_hand_tcp")
     B, T = 6, 12
     po, ref, x0, xs, us = workloads.random_goal_problem(table, T, 0.01, B, 23, frame=tcp, rows=rows)
