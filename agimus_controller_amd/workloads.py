@@ -166,5 +166,100 @@ def generic_batch_arrays(B: int, n_points: int, dt: float, nv: int = 7, seed0: i
     return q, dq, ddq
 
 
+def _log6_batch(R, p):
+    """pinocchio.log6 of n placements (R [n,3,3], p [n,3]) -> [n,6] (linear | angular); the branch near
+    theta = pi of log3 is not needed for inverse-kinematics errors and falls back to the scalar code."""
+    from .se3 import SE3, log6
+
+    n = R.shape[0]
+    ct = 0.5 * (np.clip(np.trace(R, axis1=1, axis2=2), -1.0, 3.0) - 1.0)
+    theta = np.arccos(ct)
+    if np.any(theta >= np.pi - 1e-2):
+        return np.stack([log6(SE3(R[i], p[i])).vector for i in range(n)])
+    small = theta <= 1e-8
+    tt = 0.5 * np.where(small, 1.0, theta / np.where(small, 1.0, np.sin(theta)))
+    w = tt[:, None] * np.stack([R[:, 2, 1] - R[:, 1, 2], R[:, 0, 2] - R[:, 2, 0], R[:, 1, 0] - R[:, 0, 1]], axis=1)
+    t2 = np.einsum("ni,ni->n", w, w)
+    t = np.sqrt(t2)
+    tiny = t2 < 1e-12
+    t2s, ts = np.where(tiny, 1.0, t2), np.where(tiny, 1.0, t)
+    st, ctt = np.sin(ts), np.cos(ts)
+    i22 = 1.0 / np.where(tiny, 1.0, 2.0 * (1.0 - ctt))
+    alpha = np.where(tiny, 1.0 - t2 / 12.0, ts * st * i22)
+    beta = np.where(tiny, 1.0 / 12.0 + t2 / 720.0, 1.0 / t2s - st / ts * i22)
+    v = alpha[:, None] * p - 0.5 * np.cross(w, p) + (beta * np.einsum("ni,ni->n", w, p))[:, None] * w
+    return np.concatenate([v, w], axis=1)
+
+
+def cartesian_sine_batch_arrays(dyn, frame: int, n_points: int, dt: float, q0, amp_xyz, pulsation, scale_duration=0.2,
+                                precision=1e-5, it_max=200):
+    """q, dq, ddq [B][n_points][nv] of B sine_wave_cartesian_space trajectories
+    (trajectories/sine_wave_cartesian_space.py:62-111 upstream; tests/test_sin_wave_cartesian_space.py:58-62
+    for the parameters): the end effector `frame` follows  p0 + A s(t) sin(w t)  with the initial
+    orientation, joint positions from the iterative inverse kinematics  dq = -J' (J J')^-1 log6(des^-1 cur)
+    (LOCAL Jacobian, warm-started from the previous point), joint velocities from the
+    LOCAL_WORLD_ALIGNED Jacobian, zero accelerations.  The B instances advance in lockstep: forward
+    kinematics and Jacobians of all of them in one device call (`dyn`: a backend.HipOcp)."""
+    q0 = np.asarray(q0, dtype=float)
+    B, nv = q0.shape
+    amp = np.broadcast_to(np.asarray(amp_xyz, dtype=float), (B, 3))
+    w = np.broadcast_to(np.asarray(pulsation, dtype=float), (B, 3))
+    P0 = dyn.frame_placement(frame, q0)
+    R0, p0 = P0[:, :9].reshape(B, 3, 3), P0[:, 9:]
+    q = q0.copy()
+    qs, dqs = np.empty((B, n_points, nv)), np.empty((B, n_points, nv))
+    d = float(scale_duration)
+    for i in range(n_points):
+        t = i * dt
+        s = min(max(t / d, 0.0), 1.0)
+        quint = 10 * s**3 - 15 * s**4 + 6 * s**5
+        dquint = (30 * s**2 - 60 * s**3 + 30 * s**4) / d if 0.0 < t < d else 0.0
+        des_p = p0 + amp * quint * np.sin(w * t)
+        des_v = np.zeros((B, 6))
+        des_v[:, :3] = amp * (dquint * np.sin(w * t) + quint * w * np.cos(w * t))
+        active = np.arange(B)
+        for it in range(it_max + 1):
+            P = dyn.frame_placement(frame, q[active])
+            R, pp = P[:, :9].reshape(-1, 3, 3), P[:, 9:]
+            Ra = R0[active]
+            Rrel = np.einsum("nji,njk->nik", Ra, R)  # des^-1 * cur
+            prel = np.einsum("nji,nj->ni", Ra, pp - des_p[active])
+            err = _log6_batch(Rrel, prel)
+            keep = np.linalg.norm(err, axis=1) >= precision
+            active, err = active[keep], err[keep]
+            if active.size == 0:
+                break
+            if it == it_max:
+                raise RuntimeError(f"inverse kinematics failed to converge for instances {active.tolist()} at point {i}")
+            J = dyn.frame_jacobian(frame, q[active], local=True)
+            JJt = np.einsum("nij,nkj->nik", J, J)
+            q[active] -= np.einsum("nji,nj->ni", J, np.linalg.solve(JJt, err[:, :, None])[:, :, 0])
+        J = dyn.frame_jacobian(frame, q, local=False)
+        JJt = np.einsum("nij,nkj->nik", J, J)
+        dqs[:, i] = np.einsum("nji,nj->ni", J, np.linalg.solve(JJt, des_v[:, :, None])[:, :, 0])
+        qs[:, i] = q
+    return qs, dqs, np.zeros_like(qs)
+
+
+def cartesian_sine_batch_params(B: int, seed0: int = 1234, lower=None, upper=None):
+    """Per-instance parameters of the cartesian sine wave: instance 0 is the reference's test case
+    (amplitude (0.1, 0.1, 0.0) m, period 4 s, q0 of the Panda tests); instance b draws from
+    default_rng(seed0 + b): amplitude scaled by U(0.5, 1.2), period ~ U(2, 6) s per axis, q0 perturbed by
+    N(0, 0.02^2) clipped to the joint limits."""
+    q0 = np.empty((B, PANDA_Q0.size))
+    amp, puls = np.empty((B, 3)), np.empty((B, 3))
+    for b in range(B):
+        rng = np.random.default_rng(seed0 + b)
+        a = np.array([0.1, 0.1, 0.0]) * rng.uniform(0.5, 1.2)
+        period = rng.uniform(2.0, 6.0, 3)
+        qq = PANDA_Q0 + rng.normal(0.0, 0.02, PANDA_Q0.size)
+        if b == 0:
+            a, period, qq = np.array([0.1, 0.1, 0.0]), np.full(3, 4.0), PANDA_Q0.copy()
+        if lower is not None:
+            qq = np.clip(qq, lower, upper)
+        q0[b], amp[b], puls[b] = qq, a, 2.0 * np.pi / period
+    return q0, amp, puls
+
+
 # Weights of the reference's sine-wave test (tests/test_sin_wave_configuration_space.py:138-144).
 SINE_WEIGHTS = dict(w_q=1.0, w_qdot=0.1, w_effort=3e-4, w_pose=0.1)

@@ -50,7 +50,7 @@ def parse():
     ap.add_argument("--loop", choices=("prediction", "feedback"), default="prediction",
                     help="how the next measured state is produced: previous xs[1] (the reference's dummy_mpc_test) or the Riccati "
                          "feedback law rolled out on the model at 1 kHz (SURVEY 8(f-3))")
-    ap.add_argument("--workload", choices=("sine", "generic", "humanoid", "collision"), default="sine",
+    ap.add_argument("--workload", choices=("sine", "generic", "humanoid", "collision", "cartesian"), default="sine",
                     help="sine: BASELINE configs[1] (the headline); generic: configs[3] generic_trajectory + pick-and-place costs; "
                          "humanoid: configs[4] synthetic 30-DoF tree (use --horizon 50 --batch 512); "
                          "collision: configs[2] shape, collision-avoidance cost + distance constraint (use --horizon 200 --batch 256)")
@@ -76,11 +76,13 @@ def make_problem(T, workload="sine"):
         running, terminal = workloads.goal_reaching_rows(tcp)
         po = _abi.PackedOcp(30, [0.01] * T, running, terminal, termination_tolerance=1e-3, max_qp_iters=100)
         return table, tcp, po
-    if workload == "collision":
+    if workload in ("collision", "cartesian"):
         # ocp_traj_tracking_collision_avoidance.yaml: QuadExp(alpha 1e-4) cost + distance >= 1 cm on one pair; the sphere
         # obstacle sits where the link-7 capsule of part of the batch comes close (the reference's test obstacle at
-        # x = 1.535 m is out of the arm's reach and would never be active)
-        table = rt.panda_collision_table(0.1, obstacle_xyz=(0.27, 0.22, 0.70), obstacle_radius=0.06, obstacle_length=0.0)
+        # x = 1.535 m is out of the arm's reach and would never be active); for the cartesian sine the sphere sits 0.24 m
+        # in front of the link-7 capsule: the references of ~ 1/4 of the batch pass within the 1 cm bound
+        xyz = (0.27, 0.22, 0.70) if workload == "collision" else (0.49, 0.222, 0.487)
+        table = rt.panda_collision_table(0.1, obstacle_xyz=xyz, obstacle_radius=0.06, obstacle_length=0.0)
         tcp = table.frame_id("panda_hand_tcp")
         running, terminal = workloads.collision_avoidance_rows(table, tcp, alpha=1e-4)
         fa, fb = table.frame_id("panda_link7_capsule_0"), table.frame_id("obstacle")
@@ -230,6 +232,16 @@ def main():
         hip.sine_trajectory(n_points, dt, q0, amp, puls, scale, t0, w["w_q"], w["w_qdot"], w["w_effort"], w["w_pose"], tcp)
         workload_name = ("Panda 7-DoF sine_wave_configuration_space, collision-avoidance costs + distance >= 1 cm constraint "
                          "(ocp_traj_tracking_collision_avoidance.yaml; ADMM, max_qp_iters 100)")
+    elif args.workload == "cartesian":
+        # BASELINE configs[2] as written: sine_wave_cartesian_space references (lockstep inverse kinematics of the batch,
+        # outside the timed region) resident in HBM as q/dq/ddq arrays, collision-avoidance costs + constraint
+        cq0, camp, cpuls = workloads.cartesian_sine_batch_params(B, seed0=1234 + rank * B, lower=table.lower_position_limit,
+                                                                 upper=table.upper_position_limit)
+        gq, gdq, gddq = workloads.cartesian_sine_batch_arrays(hip, tcp, n_points, dt, cq0, camp, cpuls)
+        hip.generic_trajectory(gq, gdq, gddq, w["w_q"], w["w_qdot"], w["w_effort"], w["w_pose"], tcp)
+        workload_name = ("Panda 7-DoF sine_wave_cartesian_space (amplitude (0.1, 0.1, 0) m x U(0.5, 1.2), IK on the host at setup), "
+                         "collision-avoidance costs + distance >= 1 cm constraint (ocp_traj_tracking_collision_avoidance.yaml; ADMM, "
+                         "max_qp_iters 100)")
     elif args.workload == "sine":
         hip.sine_trajectory(n_points, dt, q0, amp, puls, scale, t0, w["w_q"], w["w_qdot"], w["w_effort"], w["w_pose"], tcp)
         workload_name = "Panda 7-DoF sine_wave_configuration_space, ocp_goal_reaching.yaml costs"
@@ -345,7 +357,7 @@ def main():
             },
             "kernels": kernels,
         }
-        if args.workload == "collision":
+        if args.workload in ("collision", "cartesian"):
             result["metric"] = f"MPC steps/sec (horizon={T}, Panda 7-DoF, collision avoidance)"
             result["roofline"]["kernel"] = "k_calc_qp<7> (one lane per node: problems with a collision cost row do not use the 8-lane kernel yet)"
         if args.workload == "humanoid":

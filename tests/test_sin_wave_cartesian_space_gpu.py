@@ -91,3 +91,25 @@ def test_ik_3D(dyn):
     ik_ee_pos = obj.get_end_effector_pose_from_q_as_se3(ik_q)
     np.testing.assert_allclose(ik_dq, np.zeros(7), atol=1e-3)
     np.testing.assert_allclose(ik_ee_pos.translation, ee_pos.translation, atol=1e-3)
+
+
+def test_batch_arrays_match_the_trajectory_class(dyn):
+    """workloads.cartesian_sine_batch_arrays (lockstep inverse kinematics of B instances, used by
+    bench.py --workload cartesian) against SinusWaveCartesianSpace point by point."""
+    table = rt.panda_table(0.1)
+    tcp = table.frame_id("panda_hand_tcp")
+    q0, amp, puls = workloads.cartesian_sine_batch_params(3, lower=table.lower_position_limit, upper=table.upper_position_limit)
+    n, dt = 40, 0.01
+    qs, dqs, ddqs = workloads.cartesian_sine_batch_arrays(dyn, tcp, n, dt, q0, amp, puls)
+    assert not np.any(ddqs)
+    for b in (0, 2):
+        sp = SinWaveParams(amplitude=amp[b], period=2.0 * np.pi / puls[b], scale_duration=np.array([0.2, 0.2, 0.2]))
+        obj = SinusWaveCartesianSpace(sine_wave_params=sp, **PARAMS)
+        obj.initialize(panda_robot_models().robot_model, q0[b], dyn)
+        for i in range(n):
+            pt = obj.get_traj_point_at_t(i * dt).point
+            np.testing.assert_allclose(qs[b, i], pt.robot_configuration, atol=1e-9)
+            np.testing.assert_allclose(dqs[b, i], pt.robot_velocity, atol=1e-8)
+    # the end effector of every instance follows its own sine: x moves, z stays
+    P = dyn.frame_placement(tcp, qs[1])
+    assert np.ptp(P[:, 9]) > 1e-3 and np.ptp(P[:, 11]) < 1e-4
