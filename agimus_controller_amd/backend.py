@@ -39,18 +39,56 @@ EXPORTED_SYMBOLS = [
 ]  # fmt: skip
 
 
-def build(force: bool = False, verbose: bool = False) -> pathlib.Path:
-    """Compile the HIP sources for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
-    srcs = [_CSRC / "agimus_hip.hip"] + sorted(_CSRC.glob("*.hpp")) + [_CSRC.parent.parent / "include" / "agimus_hip.h"]
-    if not force and LIB_PATH.exists() and LIB_PATH.stat().st_mtime >= max(s.stat().st_mtime for s in srcs):
-        return LIB_PATH
-    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-o", str(LIB_PATH), str(srcs[0])]
+def _run(cmd, verbose):
     res = subprocess.run(cmd, capture_output=True, text=True)
     if verbose or res.returncode != 0:
         print(res.stdout, res.stderr)
     if res.returncode != 0:
-        raise RuntimeError(f"hipcc failed ({res.returncode}): {res.stderr[-2000:]}")
+        raise RuntimeError(f"{cmd[0]} failed ({res.returncode}): {res.stderr[-2000:]}")
+
+
+def build(force: bool = False, verbose: bool = False) -> pathlib.Path:
+    """Compile the HIP sources for gfx950 in-tree (hipcc cross-compiles without a GPU).
+
+    The kernels are templates over the model size; one translation unit with every size takes ~6
+    minutes on one core, so the source is compiled once per group of sizes (csrc/agx_front.py: GROUPS)
+    in parallel processes -- namespace and entry points suffixed per group -- and linked with a
+    generated front that forwards each call to the group owning the handle.  AGX_BUILD_SPLIT=0 builds
+    the single translation unit instead."""
+    hdr = _CSRC.parent.parent / "include" / "agimus_hip.h"
+    srcs = [_CSRC / "agimus_hip.hip"] + sorted(_CSRC.glob("*.hpp")) + [hdr, _CSRC / "agx_front.py"]
+    if not force and LIB_PATH.exists() and LIB_PATH.stat().st_mtime >= max(s.stat().st_mtime for s in srcs):
+        return LIB_PATH
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    base = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
+    if os.environ.get("AGX_BUILD_SPLIT", "1") == "0":
+        _run(base + ["-shared", "-o", str(LIB_PATH), str(srcs[0])], verbose)
+        return LIB_PATH
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("agx_front", _CSRC / "agx_front.py")
+    front = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(front)
+    obj = _CSRC.parent.parent / "build" / "obj"
+    obj.mkdir(parents=True, exist_ok=True)
+    names = [n for _, n, _ in front.prototypes(hdr.read_text())]
+    procs = []
+    for g in front.GROUPS:
+        cmd = base + ["-c", f"-I{hdr.parent}"] + front.rename_flags(names, g) + ["-o", str(obj / f"agx_g{g}.o"), str(srcs[0])]
+        procs.append((cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)))
+    (obj / "agx_front.cpp").write_text(front.front_source(hdr.read_text()))
+    _run(["g++", "-O2", "-std=c++17", "-fPIC", f"-I{hdr.parent}", "-c", "-o", str(obj / "agx_front.o"), str(obj / "agx_front.cpp")], verbose)
+    failed = None
+    for cmd, p in procs:
+        out, err = p.communicate()
+        if verbose or p.returncode != 0:
+            print(out, err)
+        if p.returncode != 0 and failed is None:
+            failed = RuntimeError(f"hipcc failed ({p.returncode}) for {cmd[-1]} [{cmd[-3]}]: {err[-2000:]}")
+    if failed:
+        raise failed
+    _run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", str(LIB_PATH)] + [str(obj / f"agx_g{g}.o") for g in front.GROUPS]
+         + [str(obj / "agx_front.o")], verbose)
     return LIB_PATH
 
 

@@ -169,10 +169,17 @@ int fill_cons(const agx_constraint_row *rows, int n, int nv, const DevModel &m, 
 }
 
 // ---- dispatch over the compiled (NV, CHAIN) instantiations --------------------
-#ifdef AGX_ONLY_NV7  // development builds: one instantiation, short compile
+// The library is built as one translation unit per group of sizes (AGX_GROUP = 0..3, compiled in
+// parallel by backend.build(), namespace and entry points suffixed per group, csrc/agx_front.py
+// generates the forwarding entry points) or, without AGX_GROUP, as a single translation unit.
+#if defined(AGX_ONLY_NV7) || (defined(AGX_GROUP) && AGX_GROUP == 0)  // AGX_ONLY_NV7: development builds, short compile
 #define AGX_FOR_NV(MACRO) MACRO(7)
-#elif defined(AGX_ONLY_NV30)
+#elif defined(AGX_ONLY_NV30) || (defined(AGX_GROUP) && AGX_GROUP == 1)
 #define AGX_FOR_NV(MACRO) MACRO(30)
+#elif defined(AGX_GROUP) && AGX_GROUP == 2
+#define AGX_FOR_NV(MACRO) MACRO(1) MACRO(2) MACRO(3)
+#elif defined(AGX_GROUP) && AGX_GROUP == 3
+#define AGX_FOR_NV(MACRO) MACRO(4) MACRO(6)
 #else
 #define AGX_FOR_NV(MACRO) MACRO(1) MACRO(2) MACRO(3) MACRO(4) MACRO(6) MACRO(7) MACRO(30)
 #endif

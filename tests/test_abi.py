@@ -54,6 +54,38 @@ def test_model_create_validates(lib):
     assert b"parent" in lib.agx_last_error()
 
 
+def test_front_forwards_by_handle_and_refuses_unknown_ones(lib):
+    """Split build (backend.build): the generated front covers every declared entry point, routes a
+    handle to the translation unit of its model size, and fails loudly on a handle it never issued."""
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("agx_front", ROOT / "agimus_controller_amd" / "csrc" / "agx_front.py")
+    front = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(front)
+    protos = front.prototypes((ROOT / "include" / "agimus_hip.h").read_text())
+    assert {n for _, n, _ in protos} == set(backend.EXPORTED_SYMBOLS)
+    assert sorted(nv for sizes in front.GROUPS.values() for nv in sizes) == [1, 2, 3, 4, 6, 7, 30]
+    # models of different groups live side by side
+    handles = []
+    for table in (rt.panda_table(), rt.pendulum_table(), rt.chain_table(4, seed=1)):
+        pm = _abi.PackedModel(table)
+        h = C.c_void_p()
+        assert lib.agx_model_create(C.byref(pm.desc), C.byref(h)) == 0
+        handles.append(h)
+    for h in handles:
+        lib.agx_model_destroy(h)
+    bogus = C.c_void_p(0x1234)
+    lib.agx_ocp_sync.argtypes = [C.c_void_p]
+    assert lib.agx_ocp_sync(bogus) != 0
+    assert b"unknown handle" in lib.agx_last_error()
+    # a destroyed handle is forgotten
+    out = C.c_void_p()
+    po = _abi.PackedOcp(7, [0.01] * 2, [_abi.RowSpec(_abi.RES_STATE)], [_abi.RowSpec(_abi.RES_STATE)])
+    lib.agx_ocp_create.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+    assert lib.agx_ocp_create(handles[0], C.byref(po.desc), 1, 0, C.byref(out)) != 0
+    assert b"unknown handle" in lib.agx_last_error()
+
+
 def test_no_silent_cpu_fallback(lib):
     """Without a HIP device the product path must fail loudly, never compute on the CPU."""
     if backend.device_count() > 0:
