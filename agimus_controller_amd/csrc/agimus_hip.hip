@@ -514,12 +514,14 @@ int admm_direction(agx_ocp *o) {
 }
 
 // The SQP loop of SolverCSQP::solve on the resident buffers.
-int solve_resident(agx_ocp *o, int max_iter, double max_time) {
+int solve_resident(agx_ocp *o, int max_iter, double max_time, bool prologue_done = false) {
   if (max_iter <= 0) max_iter = 1000;
   o->last_max_iter = max_iter;
   auto t0 = std::chrono::steady_clock::now();
-  if (reset_state(o)) return -1;
-  hipLaunchKernelGGL(agx::k_pin_x0, dim3((o->B * o->nx + 255) / 256), dim3(256), 0, o->stream, o->d_xs, o->d_x0, o->B, o->T, o->nx);
+  if (!prologue_done) {  // k_mpc_prologue has reset the state and pinned x0 already
+    if (reset_state(o)) return -1;
+    hipLaunchKernelGGL(agx::k_pin_x0, dim3((o->B * o->nx + 255) / 256), dim3(256), 0, o->stream, o->d_xs, o->d_x0, o->B, o->T, o->nx);
+  }
   // The derivative pass of iteration it+1 is enqueued BEFORE the host waits for iteration it's
   // "everyone finished" word: it skips finished instances, so when the loop ends it was an empty
   // launch, and when it does not the GPU never idles over the host round trip.
@@ -1425,13 +1427,32 @@ int agx_ocp_mpc_step(agx_ocp *o, int k0, int max_iter, int first) {
   if (!o) return fail("null handle");
   if (set_device(o)) return -1;
   if (agx_traj_set_window(o, k0)) return -1;
+  bool prologue_done = false;
   if (first == 1) {
     if (ws_from_ref(o, k0, 1)) return -1;
   } else {
-    if (first == 0 && agx_ocp_x0_from_prediction(o)) return -1;  // first == 2: x0 was set by the caller / the feedback rollout
-    if (agx_ocp_shift_warmstart(o)) return -1;
+    // x0 <- xs[1] (first == 0; first == 2: x0 was set by the caller / the feedback rollout), warm-start
+    // shift, x0 pin and state reset: one launch when the shifted nodes of an instance fit in LDS
+    const size_t lds = sizeof(double) * (size_t)o->T * (o->nx + o->nu);
+    if (o->nv <= 8 && lds <= 60 * 1024) {
+      int rc = dispatch(o->nv, o->chain, [&](auto NVc, auto CHc) -> int {
+        constexpr int NV = decltype(NVc)::value;
+        constexpr bool CH = decltype(CHc)::value;
+        if constexpr (NV <= 8) {
+          hipLaunchKernelGGL((agx::k_mpc_prologue<NV, CH>), dim3(o->B), dim3(128), lds, o->stream, o->d_model, o->d_ocp, o->d_dt, o->d_xs,
+                             o->d_us, o->d_x0, o->d_state, o->d_ndone, first == 0 ? 1 : 0);
+          HIPCHK(hipGetLastError());
+        }
+        return 0;
+      });
+      if (rc) return rc;
+      prologue_done = true;
+    } else {
+      if (first == 0 && agx_ocp_x0_from_prediction(o)) return -1;
+      if (agx_ocp_shift_warmstart(o)) return -1;
+    }
   }
-  return solve_resident(o, max_iter, 0.0);
+  return solve_resident(o, max_iter, 0.0, prologue_done);
 }
 
 }  // extern "C"
