@@ -527,7 +527,12 @@ int solve_resident(agx_ocp *o, int max_iter, double max_time, bool prologue_done
   // launch, and when it does not the GPU never idles over the host round trip.
   const bool ahead = o->queue_ahead && !o->prof && max_time <= 0.0;
   bool k1_queued = false;
+  // the exit fix-up of the gains is launched only if an instance can have finished (or the loop can
+  // have ended) in an iteration whose direction sweep was not paired with the gains sweep
+  bool need_fixup = false;
+  int prev_done = 0;
   for (int it = 0; it < max_iter; ++it) {
+    const bool pair = o->speculate && it >= 1 && !o->has_con && o->nv <= 7;  // large models: gains only on exit
     // derivative pass: running and terminal nodes in one launch; under agx_ocp_profile the running
     // nodes get their own launch so that the kernel the roofline is quoted on is timed alone
     if (!k1_queued) {
@@ -541,13 +546,13 @@ int solve_resident(agx_ocp *o, int max_iter, double max_time, bool prologue_done
     k1_queued = false;
     if (prof_mark(o, 1, true)) return -1;
     // from the second iteration on (where warm-started MPC steps converge) the gains sweep rides along
-    if (launch_riccati(o, 1, o->speculate && it >= 1 && !o->has_con, it)) return -1;
+    if (launch_riccati(o, 1, pair, it)) return -1;
     if (o->has_con && admm_direction(o)) return -1;
     if (prof_mark(o, 1, false)) return -1;
     if (prof_mark(o, 2, true)) return -1;
     if (launch_step(o, it, max_iter, 1, !o->has_con, true)) return -1;
     if (prof_mark(o, 2, false)) return -1;
-    if (it + 1 == max_iter) break;
+    if (it + 1 == max_iter) { need_fixup = need_fixup || !pair; break; }
     // early exit once every instance has finished (one 4-byte read back)
     const int seq = ++o->seq;
     if (o->poll) {
@@ -563,13 +568,16 @@ int solve_resident(agx_ocp *o, int max_iter, double max_time, bool prologue_done
     // waits for the finished count only, not for the pass queued behind it
     if (o->poll) { if (wait_stamp(o, 1, seq)) return -1; }
     else HIPCHK(hipEventSynchronize(o->ev_done));
-    if (__atomic_load_n(o->h_ndone, __ATOMIC_ACQUIRE) >= o->B) break;
+    const int n_done = __atomic_load_n(o->h_ndone, __ATOMIC_ACQUIRE);
+    if (!pair && n_done > prev_done) need_fixup = true;
+    prev_done = n_done;
+    if (n_done >= o->B) break;
     if (max_time > 0.0) {
       const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-      if (el > max_time) break;
+      if (el > max_time) { need_fixup = need_fixup || !pair; break; }
     }
   }
-  if (!o->has_con && launch_gains(o, 2)) return -1;  // instances whose last direction has no gains sweep yet
+  if (!o->has_con && need_fixup && launch_gains(o, 2)) return -1;  // instances whose last direction has no gains sweep yet
   return prof_collect(o);
 }
 

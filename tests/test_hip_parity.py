@@ -167,16 +167,26 @@ def test_residual_readback(hip_backend, panda):
                 np.testing.assert_allclose(got[b, t], res[offs[row]:offs[row + 1]], rtol=1e-11, atol=1e-13)
 
 
-def test_resident_sine_trajectory_and_mpc_steps(hip_backend, panda):
-    """Device-resident reference generator + receding-horizon steps vs a host restatement built on the oracle."""
+@pytest.mark.parametrize("factors", [None, [1, 1, 1, 2, 2, 2, 4, 4]])
+def test_resident_sine_trajectory_and_mpc_steps(hip_backend, panda, factors):
+    """Device-resident reference generator + receding-horizon steps vs a host restatement built on the
+    oracle; with dt factors (OCPParamsBaseCroco.timesteps, TrajectoryBuffer.compute_horizon_indexes) the
+    warm-start shift integrates the nodes whose dt differs from the first one
+    (warm_start_shift_previous_solution.py:95-104)."""
     tcp = panda.frame_id("panda_hand_tcp")
-    B, T, dt, NP = 3, 16, 0.01, 24
+    B, dt = 3, 0.01
+    T = 16 if factors is None else len(factors)
+    fac = np.ones(T, dtype=int) if factors is None else np.asarray(factors)
+    hidx = np.concatenate([[0], np.cumsum(fac)]).astype(np.int32)  # trajectory point of node t, relative to the window start
+    NP = int(hidx[-1]) + 8
     running, terminal = workloads.goal_reaching_rows(tcp)
-    po = _abi.PackedOcp(7, [dt] * T, running, terminal)
+    po = _abi.PackedOcp(7, list(dt * fac), running, terminal)
     h, o = hip_backend.HipOcp(panda, po, B), Oracle(panda, po, B)
     q0, amp, puls, scale, t0 = workloads.sine_batch_params(B)
     w = workloads.SINE_WEIGHTS
     h.sine_trajectory(NP, dt, q0, amp, puls, scale, t0, w["w_q"], w["w_qdot"], w["w_effort"], w["w_pose"], tcp)
+    if factors is not None:
+        h.set_horizon_indexes(hidx)
     # host restatement of sine_wave_configuration_space.py:41-72 with oracle RNEA / FK
     def sample(k):
         t = t0 + k * dt
@@ -196,7 +206,7 @@ def test_resident_sine_trajectory_and_mpc_steps(hip_backend, panda):
     def window_tile(k0):
         ref = po.new_ref_tile(B)
         for t in range(T + 1):
-            q, dq, ddq, u, pose = sample(k0 + t)
+            q, dq, ddq, u, pose = sample(k0 + int(hidx[t]))
             term = t == T
             rows = terminal if term else running
             offs = po.terminal_offsets if term else po.running_offsets
@@ -219,7 +229,7 @@ def test_resident_sine_trajectory_and_mpc_steps(hip_backend, panda):
         xs_h, us_h, K_h, st_h = h.download()
         ref = window_tile(step)
         if step == 0:
-            pts = [sample(t) for t in range(T + 1)]
+            pts = [sample(int(hidx[t])) for t in range(T + 1)]
             xs_ws = np.stack([np.concatenate([p[0], p[1]], 1) for p in pts], 1)
             us_ws = np.stack([p[3] for p in pts[:T]], 1)
             x0 = xs_ws[:, 0].copy()
