@@ -8,7 +8,8 @@
 //   k_admm_update  node parallel   du, C d, z / y update, residual norms, the node's KKT share
 //   k_admm_reduce  one block / instance: norms, rho adaptation, convergence
 //
-// Supported constraint kinds: Control (ConstraintModelControlLimit), State, collision distance.
+// Supported constraint kinds: Control (ConstraintModelControlLimit), State, collision distance,
+// FrameTranslation (its three components are handled like three collision rows: dense gradients in q).
 // In the acceleration-input coordinates of the QP tiles (du = M w + taux dx) a constraint row with
 // Jacobians (Gx, Gu) has the row  c = [Gx + Gu taux | Gu M]  on (dx, w).
 //
@@ -145,16 +146,18 @@ __global__ void __launch_bounds__(128) k_admm_tile(const DevOcp *__restrict__ op
     q2[Q::Hqq + j * Q::LD + j] += add_qq_diag;
     q2[Q::Hvv + j * Q::LD + j] += add_vv_diag;
   }
-  // collision rows: rank one on the qq block
+  // rows with dense gradients in q (collision distance: 1 component, frame translation: 3): rank one each on the qq block
   for (int r = 0; r < c.n; ++r) {
-    if (c.kind[r] != AGX_RES_COLLISION) continue;
-    const int off = c.off[r];
-    const double *gj = cjac + (unit * AGX_MAX_CONS + c.coll_slot[r]) * 8;
-    const double rho = admm_rho(c.lb[off], c.ub[off], rs);
-    const double h = y[off] - rho * z[off];
-    gq += h * gj[j];
-    if (wr && full)
-      for (int i = 0; i < NV; ++i) q2[Q::Hqq + i * Q::LD + j] += rho * gj[i] * gj[j];
+    if (c.kind[r] != AGX_RES_COLLISION && c.kind[r] != AGX_RES_FRAME_TRANSLATION) continue;
+    for (int e = 0; e < c.nr[r]; ++e) {
+      const int off = c.off[r] + e;
+      const double *gj = cjac + (unit * AGX_MAX_CONS + c.coll_slot[r] + e) * 8;
+      const double rho = admm_rho(c.lb[off], c.ub[off], rs);
+      const double h = y[off] - rho * z[off];
+      gq += h * gj[j];
+      if (wr && full)
+        for (int i = 0; i < NV; ++i) q2[Q::Hqq + i * Q::LD + j] += rho * gj[i] * gj[j];
+    }
   }
   double gwv = 0.0;
   if (t < T) {
@@ -379,13 +382,15 @@ __global__ void __launch_bounds__(256) k_admm_update(const DevOcp *__restrict__ 
         hn_v += bq.y - admm_rho(c.lb[off + NV + jj], c.ub[off + NV + jj], rs) * bq.x;
         if (act) { z[off + jj] = a.x; y[off + jj] = a.y; z[off + NV + jj] = bq.x; y[off + NV + jj] = bq.y; }
       }
-    } else if (c.kind[r] == AGX_RES_COLLISION) {
-      const double gj = jl ? cjac[(nid * AGX_MAX_CONS + c.coll_slot[r]) * 8 + jj] : 0.0;
-      double Cd = gj * dq;
-      Cd += dpp_xor4(Cd); Cd += dpp_xor2(Cd); Cd += dpp_xor1(Cd);
-      const double2 zy = comp(off, Cd, dual_q, drel_q, e_q, gj);  // identical on every lane of the group
-      hn_q += (zy.y - admm_rho(c.lb[off], c.ub[off], rs) * zy.x) * gj;
-      if (act && l8 == 0) { z[off] = zy.x; y[off] = zy.y; }
+    } else if (c.kind[r] == AGX_RES_COLLISION || c.kind[r] == AGX_RES_FRAME_TRANSLATION) {
+      for (int e = 0; e < c.nr[r]; ++e) {
+        const double gj = jl ? cjac[(nid * AGX_MAX_CONS + c.coll_slot[r] + e) * 8 + jj] : 0.0;
+        double Cd = gj * dq;
+        Cd += dpp_xor4(Cd); Cd += dpp_xor2(Cd); Cd += dpp_xor1(Cd);
+        const double2 zy = comp(off + e, Cd, dual_q, drel_q, e_q, gj);  // identical on every lane of the group
+        hn_q += (zy.y - admm_rho(c.lb[off + e], c.ub[off + e], rs) * zy.x) * gj;
+        if (act && l8 == 0) { z[off + e] = zy.x; y[off + e] = zy.y; }
+      }
     }
   }
   // KKT shares

@@ -49,7 +49,7 @@ struct DevRows {
 struct DevCons {
   int n, nc, ncoll, pad;
   int kind[AGX_MAX_CONS], frame[AGX_MAX_CONS], frame_b[AGX_MAX_CONS], off[AGX_MAX_CONS], nr[AGX_MAX_CONS];
-  int coll_slot[AGX_MAX_CONS];  // index of a collision row among the collision rows (Jacobian slot)
+  int coll_slot[AGX_MAX_CONS];  // first Jacobian slot of a row whose components have dense gradients in q (collision: 1, frame translation: 3)
   double ref[AGX_MAX_CONS][2 * AGX_MAX_NV];
   double lb[AGX_MAX_NC], ub[AGX_MAX_NC];
 };
@@ -1044,6 +1044,25 @@ AGX_DEV void constraints_eval(const DevModel &m, const DevCons &c, const double 
     } else if (kind == AGX_RES_CONTROL) {
 #pragma unroll
       for (int i = 0; i < NV; ++i) g[off + i] = u[i] - c.ref[r][i];
+    } else if (kind == AGX_RES_FRAME_TRANSLATION) {
+      // r = p(q) - pref; row e of the Jacobian is the LOCAL_WORLD_ALIGNED linear frame Jacobian
+      double RF[9], pF[3];
+      int jf;
+      frame_world<NV>(m, k, c.frame[r], RF, pF, &jf);
+#pragma unroll
+      for (int e = 0; e < 3; ++e) g[off + e] = pF[e] - c.ref[r][e];
+      if (JAC) {
+AGX_UNROLL_NV
+        for (int j = 0; j < NV; ++j) {
+          const bool on = (jf >= 0) && (CHAIN ? (j <= jf) : ((m.anc[jf >= 0 ? jf : 0] >> j) & 1u));
+          double d[3], tl[3];
+#pragma unroll
+          for (int e = 0; e < 3; ++e) d[e] = pF[e] - k.p[j][e];
+          cross3(k.S[j] + 3, d, tl);
+#pragma unroll
+          for (int e = 0; e < 3; ++e) cj[c.coll_slot[r] + e][j] = on ? tl[e] : 0.0;
+        }
+      }
     } else if (kind == AGX_RES_COLLISION) {
       double ca[3], cb[3], n[3];
       int ja, jb;

@@ -85,6 +85,46 @@ def test_collision_constraint_keeps_the_pair_apart():
     assert np.all(np.isfinite(K))
 
 
+def _translation_box_problem(T=12, B=2, seed=23, max_qp=400, with_collision=False):
+    """goal reaching with the end effector confined to a box around a point (ConstraintModelResidual on
+    ResidualModelFrameTranslation, ocp_croco_generic.py:252-275, 594-620): lower <= p(q) - pref <= upper."""
+    table = rt.panda_collision_table(0.1, obstacle_xyz=(0.45, 0.1, 0.45), obstacle_radius=0.08, obstacle_length=0.3)
+    tcp = table.frame_id("panda_hand_tcp")
+    running, terminal = workloads.goal_reaching_rows(tcp)
+    _, ref, x0, xs, us = workloads.random_goal_problem(table, T, 0.01, B, seed, frame=tcp)
+    return table, tcp, running, terminal, ref, x0, xs, us
+
+
+def test_frame_translation_constraint_confines_the_end_effector():
+    table, tcp, running, terminal, ref, x0, xs, us = _translation_box_problem()
+    T, B = 12, 2
+    o0 = _oracle(table, _abi.PackedOcp(7, [0.01] * T, running, terminal), B)
+    xs_u = o0.solve(ref, None, x0, xs, us, 60)[0]
+    p0 = o0.frame_placement(tcp, x0[:, :7])[:, 9:]
+    pu = np.stack([o0.frame_placement(tcp, xs_u[:, t, :7])[:, 9:] for t in range(T + 1)], 1)
+    travel = np.abs(pu - p0[:, None, :]).max()
+    assert travel > 0.02  # the unconstrained solution moves the end effector by more than the box allows
+    half = 0.4 * travel
+    for b in range(B):
+        con = [_abi.ConstraintSpec(_abi.RES_FRAME_TRANSLATION, lower=-half, upper=half, ref=p0[b], frame=tcp, name="ee_box")]
+        po = _abi.PackedOcp(7, [0.01] * T, running, terminal, max_qp_iters=400, running_constraints=con, terminal_constraints=con)
+        o = _oracle(table, po, 1)
+        xs_c, us_c, K, st = o.solve(ref[b:b + 1], None, x0[b:b + 1], xs[b:b + 1], us[b:b + 1], 60)
+        pc = np.stack([o.frame_placement(tcp, xs_c[:, t, :7])[0, 9:] for t in range(T + 1)])
+        assert np.abs(pc[1:] - p0[b]).max() <= half + 2e-3
+        assert np.all(np.isfinite(K))
+        # Jacobian rows of the constraint = finite differences of the frame translation
+        g, Gx, Gu = o.node_constraints(False, xs_c[0, 3], us_c[0, 3])
+        h = 1e-6
+        for j in range(7):
+            e = np.zeros(14)
+            e[j] = h
+            gp = o.node_constraints(False, xs_c[0, 3] + e, us_c[0, 3])[0]
+            gm = o.node_constraints(False, xs_c[0, 3] - e, us_c[0, 3])[0]
+            np.testing.assert_allclose(Gx[:, j], (gp - gm) / (2 * h), atol=1e-7)
+        assert not np.any(Gx[:, 7:]) and not np.any(Gu)
+
+
 def test_yaml_constraints_lower_to_rows():
     from agimus_controller_amd.ocp import ocp_croco_generic as g
     from agimus_controller_amd.factory.robot_model import RobotModelParameters, RobotModels
@@ -98,18 +138,24 @@ def test_yaml_constraints_lower_to_rows():
             {"name": "collision", "constraint": {"class": "ConstraintModelResidual", "lower": 0.01, "upper": "inf",
                                                    "residual": {"class": "ResidualDistanceCollision", "collision_pair_id": 0}}},
             {"name": "torque", "constraint": {"class": "ConstraintModelControlLimit"}},
+            {"name": "ee_box", "constraint": {"class": "ConstraintModelResidual", "lower": [-0.1, -0.1, 0.0], "upper": [0.1, 0.1, 0.3],
+                                                "residual": {"class": "ResidualModelFrameTranslation", "id": "panda_hand_tcp",
+                                                             "pref": [0.4, 0.0, 0.4]}}},
         ],
     })
     data = g.BuildData(rm.robot_model, 7, rm.collision_model)
     run = diff.lower_constraints(data, False)
-    assert [c.kind for c in run] == [_abi.RES_COLLISION, _abi.RES_CONTROL]
+    assert [c.kind for c in run] == [_abi.RES_COLLISION, _abi.RES_CONTROL, _abi.RES_FRAME_TRANSLATION]
+    assert run[2].frame == table.frame_id("panda_hand_tcp")
+    np.testing.assert_allclose(run[2].ref, [0.4, 0.0, 0.4])
+    np.testing.assert_allclose(run[2].upper, [0.1, 0.1, 0.3])
     assert float(np.asarray(run[0].lower).reshape(-1)[0]) == pytest.approx(0.01) and np.isinf(np.asarray(run[0].upper)).all()
     np.testing.assert_allclose(run[1].upper, table.effort_limit)
     np.testing.assert_allclose(run[1].lower, -table.effort_limit)
     term = diff.lower_constraints(data, True)
     assert term[0].active and not term[1].active  # no control at the terminal node
     po = _abi.PackedOcp(7, [0.01] * 4, diff.lower(data), diff.lower(data), running_constraints=run, terminal_constraints=term)
-    assert po.desc.n_running_constraints == 2 and po.desc.n_terminal_constraints == 2
+    assert po.desc.n_running_constraints == 3 and po.desc.n_terminal_constraints == 3
 
 
 @pytest.mark.gpu
@@ -166,6 +212,38 @@ def test_hip_collision_constraint_matches_the_checker():
     np.testing.assert_allclose(r_h[2], r_o[2], rtol=1e-5, atol=1e-5)
     np.testing.assert_allclose(r_h[3]["kkt"], r_o[3]["kkt"], rtol=1e-5, atol=1e-8)
     hb.close()
+
+
+@pytest.mark.gpu
+def test_hip_frame_translation_constraint_matches_the_checker():
+    """end effector confined to a box (three components with dense Jacobian rows) next to a collision
+    constraint (the fourth Jacobian slot): HIP ADMM loop against the CPU checker."""
+    from agimus_controller_amd import backend
+
+    table, tcp, running, terminal, ref, x0, xs, us = _translation_box_problem(T=10, B=3)
+    T, B = 10, 3
+    o0 = _oracle(table, _abi.PackedOcp(7, [0.01] * T, running, terminal), B)
+    p0 = o0.frame_placement(tcp, x0[:, :7])[:, 9:]
+    fa, fb = table.frame_id("panda_link7_capsule_0"), table.frame_id("obstacle")
+    con = [_abi.ConstraintSpec(_abi.RES_FRAME_TRANSLATION, lower=[-0.02, -0.03, -0.01], upper=[0.02, 0.01, 0.03], ref=p0.mean(0), frame=tcp, name="ee_box"),
+           _abi.ConstraintSpec(_abi.RES_COLLISION, lower=0.05, upper=np.inf, frame=fa, frame_b=fb, name="collision")]
+    po = _abi.PackedOcp(7, [0.01] * T, running, terminal, max_qp_iters=100, running_constraints=con, terminal_constraints=con)
+    o = _oracle(table, po, B)
+    hb = backend.HipOcp(table, po, B)
+    hb.set_refs(ref)
+    r_o = o.solve(ref, None, x0, xs, us, 2)
+    r_h = hb.solve(x0, xs, us, 2)
+    assert np.array_equal(r_h[3]["qp_iters"], r_o[3]["qp_iters"])
+    np.testing.assert_allclose(r_h[0], r_o[0], rtol=1e-7, atol=1e-8)
+    np.testing.assert_allclose(r_h[1], r_o[1], rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(r_h[2], r_o[2], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(r_h[3]["kkt"], r_o[3]["kkt"], rtol=1e-5, atol=1e-8)
+    hb.close()
+    # a fifth dense-Jacobian component does not fit
+    con2 = con + [_abi.ConstraintSpec(_abi.RES_COLLISION, lower=0.0, upper=np.inf, frame=table.frame_id("panda_link5_capsule_0"), frame_b=fb, name="c2")]
+    po2 = _abi.PackedOcp(7, [0.01] * T, running, terminal, running_constraints=con2)
+    with pytest.raises(backend.HipError, match="dense Jacobian"):
+        backend.HipOcp(table, po2, 1)
 
 
 @pytest.mark.gpu
