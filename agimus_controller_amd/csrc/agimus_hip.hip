@@ -142,8 +142,8 @@ int fill_cons(const agx_constraint_row *rows, int n, int nv, const DevModel &m, 
     const agx_constraint_row &c = rows[r];
     if (!c.active) continue;
     if (d.n >= AGX_MAX_CONS) return fail("agx_ocp_create: at most 4 active constraint rows per node type");
-    if (c.kind != AGX_RES_STATE && c.kind != AGX_RES_CONTROL && c.kind != AGX_RES_COLLISION && c.kind != AGX_RES_FRAME_TRANSLATION)
-      return fail("agx_ocp_create: constraints are implemented for State, Control (ControlLimit), FrameTranslation and collision-distance residuals");
+    if (c.kind != AGX_RES_STATE && c.kind != AGX_RES_CONTROL && !agx::cons_dense_q(c.kind))
+      return fail("agx_ocp_create: constraints are implemented for State, Control (ControlLimit), FrameTranslation / Rotation / Placement and collision-distance residuals");
     const int nr = agx_row_nr(c.kind, nv), nref = agx_row_nref(c.kind, nv);
     if (off + nr > AGX_MAX_NC) return fail("agx_ocp_create: more than 32 constraint components per node");
     if (!c.lower || !c.upper) return fail("agx_ocp_create: constraint bounds missing");
@@ -162,12 +162,12 @@ int fill_cons(const agx_constraint_row *rows, int n, int nv, const DevModel &m, 
         return fail("agx_ocp_create: box / box collision pairs are not supported");
       d.coll_slot[i] = d.ncoll++;
     }
-    if (c.kind == AGX_RES_FRAME_TRANSLATION) {  // three scalar rows with dense gradients in q: three Jacobian slots
+    if (c.kind != AGX_RES_COLLISION && agx::cons_dense_q(c.kind)) {  // nr scalar rows with dense gradients in q: nr Jacobian slots
       if (c.frame < 0 || c.frame >= m.nframes) return fail("agx_ocp_create: constraint frame id out of range");
       d.coll_slot[i] = d.ncoll;
-      d.ncoll += 3;
+      d.ncoll += nr;
     }
-    if (d.ncoll > AGX_MAX_CONS) return fail("agx_ocp_create: at most 4 constraint components with a dense Jacobian (collision pairs, frame translations) per node type");
+    if (d.ncoll > AGX_MAX_DENSE) return fail("agx_ocp_create: at most 8 constraint components with a dense Jacobian (collision pairs, frame residuals) per node type");
     off += nr;
   }
   d.nc = off;
@@ -794,7 +794,7 @@ int agx_ocp_create(const agx_model *m, const agx_ocp_desc *d, int batch, int dev
   if (o->has_con) {
     ALLOC(o->d_qt2, B * (T + 1) * (size_t)o->qt_size);
     ALLOC(o->d_cg, B * (T + 1) * AGX_MAX_NC);
-    ALLOC(o->d_cjac, B * (T + 1) * AGX_MAX_CONS * 8);
+    ALLOC(o->d_cjac, B * (T + 1) * AGX_MAX_DENSE * 8);
     ALLOC(o->d_y, B * (T + 1) * AGX_MAX_NC);
     ALLOC(o->d_z, B * (T + 1) * AGX_MAX_NC);
     ALLOC(o->d_cx, B * (T + 1) * nx);

@@ -9,7 +9,8 @@
 //   k_admm_reduce  one block / instance: norms, rho adaptation, convergence
 //
 // Supported constraint kinds: Control (ConstraintModelControlLimit), State, collision distance,
-// FrameTranslation (its three components are handled like three collision rows: dense gradients in q).
+// FrameTranslation / FrameRotation / FramePlacement (their components are handled like collision rows:
+// scalar rows with dense gradients in q).
 // In the acceleration-input coordinates of the QP tiles (du = M w + taux dx) a constraint row with
 // Jacobians (Gx, Gu) has the row  c = [Gx + Gu taux | Gu M]  on (dx, w).
 //
@@ -23,7 +24,7 @@ constexpr double kRhoMin = 1e-6, kRhoMax = 1e3, kAdaptiveRhoTol = 5.0;
 constexpr int kRhoInterval = 25;
 
 // g, collision Jacobians and the l1 violation of every node at the current (xs, us).
-// One lane per node.  cg [B][T+1][AGX_MAX_NC], cjac [B][T+1][AGX_MAX_CONS][8].
+// One lane per node.  cg [B][T+1][AGX_MAX_NC], cjac [B][T+1][AGX_MAX_DENSE][8].
 template <int NV, bool CHAIN>
 __global__ void __launch_bounds__(64) k_con_eval(const DevModel *__restrict__ mp, const DevOcp *__restrict__ op,
                                                  const double *__restrict__ xs, const double *__restrict__ us,
@@ -38,7 +39,7 @@ __global__ void __launch_bounds__(64) k_con_eval(const DevModel *__restrict__ mp
   const int b = (int)(node / (T + 1)), t = (int)(node % (T + 1));
   if (st[b].done) return;
   const DevCons &c = o.cons[t == T ? 1 : 0];
-  double x[NX], u[NU], g[AGX_MAX_NC], cj[AGX_MAX_CONS][8];
+  double x[NX], u[NU], g[AGX_MAX_NC], cj[AGX_MAX_DENSE][8];
 #pragma unroll
   for (int i = 0; i < NX; ++i) x[i] = xs[node * NX + i];
 #pragma unroll
@@ -47,7 +48,7 @@ __global__ void __launch_bounds__(64) k_con_eval(const DevModel *__restrict__ mp
   constraints_eval<NV, CHAIN, true>(m, c, x, u, g, cj);
   for (int k = 0; k < c.nc; ++k) cg[node * AGX_MAX_NC + k] = g[k];
   for (int r = 0; r < c.ncoll; ++r)
-    for (int j = 0; j < 8; ++j) cjac[(node * AGX_MAX_CONS + r) * 8 + j] = (j < NV) ? cj[r][j] : 0.0;
+    for (int j = 0; j < 8; ++j) cjac[(node * AGX_MAX_DENSE + r) * 8 + j] = (j < NV) ? cj[r][j] : 0.0;
   nodestat[node * 4 + 3] = violation_l1(c, g);
 }
 
@@ -148,10 +149,10 @@ __global__ void __launch_bounds__(128) k_admm_tile(const DevOcp *__restrict__ op
   }
   // rows with dense gradients in q (collision distance: 1 component, frame translation: 3): rank one each on the qq block
   for (int r = 0; r < c.n; ++r) {
-    if (c.kind[r] != AGX_RES_COLLISION && c.kind[r] != AGX_RES_FRAME_TRANSLATION) continue;
+    if (!cons_dense_q(c.kind[r])) continue;
     for (int e = 0; e < c.nr[r]; ++e) {
       const int off = c.off[r] + e;
-      const double *gj = cjac + (unit * AGX_MAX_CONS + c.coll_slot[r] + e) * 8;
+      const double *gj = cjac + (unit * AGX_MAX_DENSE + c.coll_slot[r] + e) * 8;
       const double rho = admm_rho(c.lb[off], c.ub[off], rs);
       const double h = y[off] - rho * z[off];
       gq += h * gj[j];
@@ -382,9 +383,9 @@ __global__ void __launch_bounds__(256) k_admm_update(const DevOcp *__restrict__ 
         hn_v += bq.y - admm_rho(c.lb[off + NV + jj], c.ub[off + NV + jj], rs) * bq.x;
         if (act) { z[off + jj] = a.x; y[off + jj] = a.y; z[off + NV + jj] = bq.x; y[off + NV + jj] = bq.y; }
       }
-    } else if (c.kind[r] == AGX_RES_COLLISION || c.kind[r] == AGX_RES_FRAME_TRANSLATION) {
+    } else if (cons_dense_q(c.kind[r])) {
       for (int e = 0; e < c.nr[r]; ++e) {
-        const double gj = jl ? cjac[(nid * AGX_MAX_CONS + c.coll_slot[r] + e) * 8 + jj] : 0.0;
+        const double gj = jl ? cjac[(nid * AGX_MAX_DENSE + c.coll_slot[r] + e) * 8 + jj] : 0.0;
         double Cd = gj * dq;
         Cd += dpp_xor4(Cd); Cd += dpp_xor2(Cd); Cd += dpp_xor1(Cd);
         const double2 zy = comp(off + e, Cd, dual_q, drel_q, e_q, gj);  // identical on every lane of the group

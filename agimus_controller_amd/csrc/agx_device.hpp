@@ -45,11 +45,12 @@ struct DevRows {
 
 // ConstraintListItem rows of one node type:  lb <= g(x, u) <= ub, g stacked over the rows.
 #define AGX_MAX_CONS 4
+#define AGX_MAX_DENSE 8  // constraint components with a dense Jacobian in q per node type (collision 1, translation / rotation 3, placement 6)
 #define AGX_MAX_NC 32
 struct DevCons {
   int n, nc, ncoll, pad;
   int kind[AGX_MAX_CONS], frame[AGX_MAX_CONS], frame_b[AGX_MAX_CONS], off[AGX_MAX_CONS], nr[AGX_MAX_CONS];
-  int coll_slot[AGX_MAX_CONS];  // first Jacobian slot of a row whose components have dense gradients in q (collision: 1, frame translation: 3)
+  int coll_slot[AGX_MAX_CONS];  // first Jacobian slot (of AGX_MAX_DENSE) of a row whose components have dense gradients in q
   double ref[AGX_MAX_CONS][2 * AGX_MAX_NV];
   double lb[AGX_MAX_NC], ub[AGX_MAX_NC];
 };
@@ -1044,23 +1045,57 @@ AGX_DEV void constraints_eval(const DevModel &m, const DevCons &c, const double 
     } else if (kind == AGX_RES_CONTROL) {
 #pragma unroll
       for (int i = 0; i < NV; ++i) g[off + i] = u[i] - c.ref[r][i];
-    } else if (kind == AGX_RES_FRAME_TRANSLATION) {
-      // r = p(q) - pref; row e of the Jacobian is the LOCAL_WORLD_ALIGNED linear frame Jacobian
+    } else if (kind == AGX_RES_FRAME_TRANSLATION || kind == AGX_RES_FRAME_ROTATION || kind == AGX_RES_FRAME_PLACEMENT) {
+      // the residuals of the cost rows (node_costs) as constraints: translation p(q) - pref with the
+      // LOCAL_WORLD_ALIGNED linear frame Jacobian, rotation log3(Rref' R) with Jlog3 * LOCAL angular
+      // Jacobian, placement log6(Mref^-1 M) with Jlog6 * LOCAL Jacobian
       double RF[9], pF[3];
       int jf;
       frame_world<NV>(m, k, c.frame[r], RF, pF, &jf);
+      const double *rr = c.ref[r];
+      double res[6], TL[9], TR[9];
+      if (kind == AGX_RES_FRAME_TRANSLATION) {
 #pragma unroll
-      for (int e = 0; e < 3; ++e) g[off + e] = pF[e] - c.ref[r][e];
+        for (int e = 0; e < 3; ++e) res[e] = pF[e] - rr[e];
+      } else if (kind == AGX_RES_FRAME_ROTATION) {
+        double Rrel[9];
+        mtm3(rr, RF, Rrel);
+        log3(Rrel, res);
+        if (JAC) jlog3(res, TL);
+      } else {
+        double Rrel[9], d[3], prel[3];
+        mtm3(rr, RF, Rrel);
+        d[0] = pF[0] - rr[9]; d[1] = pF[1] - rr[10]; d[2] = pF[2] - rr[11];
+        mtv3(rr, d, prel);
+        log6<JAC>(Rrel, prel, res, TL, TR);
+      }
+      for (int e = 0; e < c.nr[r]; ++e) g[off + e] = res[e];
       if (JAC) {
 AGX_UNROLL_NV
         for (int j = 0; j < NV; ++j) {
           const bool on = (jf >= 0) && (CHAIN ? (j <= jf) : ((m.anc[jf >= 0 ? jf : 0] >> j) & 1u));
-          double d[3], tl[3];
+          double d[3], t[3], lin[3], ang[3], out[6];
 #pragma unroll
           for (int e = 0; e < 3; ++e) d[e] = pF[e] - k.p[j][e];
-          cross3(k.S[j] + 3, d, tl);
+          cross3(k.S[j] + 3, d, t);  // z x (pF - pj)
+          if (kind == AGX_RES_FRAME_TRANSLATION) {
 #pragma unroll
-          for (int e = 0; e < 3; ++e) cj[c.coll_slot[r] + e][j] = on ? tl[e] : 0.0;
+            for (int e = 0; e < 3; ++e) out[e] = t[e];
+          } else {
+            mtv3(RF, t, lin);
+            mtv3(RF, k.S[j] + 3, ang);
+#pragma unroll
+            for (int e = 0; e < 3; ++e) {
+              const double bot = TL[3 * e] * ang[0] + TL[3 * e + 1] * ang[1] + TL[3 * e + 2] * ang[2];
+              if (kind == AGX_RES_FRAME_ROTATION) out[e] = bot;
+              else {
+                out[e] = TL[3 * e] * lin[0] + TL[3 * e + 1] * lin[1] + TL[3 * e + 2] * lin[2] +
+                         TR[3 * e] * ang[0] + TR[3 * e + 1] * ang[1] + TR[3 * e + 2] * ang[2];
+                out[3 + e] = bot;
+              }
+            }
+          }
+          for (int e = 0; e < c.nr[r]; ++e) cj[c.coll_slot[r] + e][j] = on ? out[e] : 0.0;
         }
       }
     } else if (kind == AGX_RES_COLLISION) {
@@ -1083,6 +1118,10 @@ AGX_UNROLL_NV
       }
     }
   }
+}
+// constraint kinds whose components are scalar rows with dense gradients in q (Jacobian slots)
+AGX_HD bool cons_dense_q(int kind) {
+  return kind == AGX_RES_COLLISION || kind == AGX_RES_FRAME_TRANSLATION || kind == AGX_RES_FRAME_ROTATION || kind == AGX_RES_FRAME_PLACEMENT;
 }
 // l1 norm of the violation of lb <= g <= ub (SolverCSQP::calc / tryStep constraint_norm)
 AGX_DEV double violation_l1(const DevCons &c, const double *g) {

@@ -75,9 +75,10 @@ typedef struct agx_cost_row {
  * ConstraintModelControlLimit (:624-640) is the AGX_RES_CONTROL row with zero
  * reference and -/+ effort limit.  Constraints are not updated per node
  * (:720-721), so reference and bounds are static.  Implemented kinds: State,
- * Control, FrameTranslation (pref in ref) and collision distance; at most 4 rows
- * and 4 components with a dense Jacobian (collision = 1, translation = 3) per
- * node type; other kinds are refused by agx_ocp_create.                          */
+ * Control, FrameTranslation / FrameRotation / FramePlacement (pref in ref, laid
+ * out like the cost rows' references) and collision distance; at most 4 rows and
+ * 8 components with a dense Jacobian (collision 1, translation / rotation 3,
+ * placement 6) per node type; other kinds are refused by agx_ocp_create.        */
 typedef struct agx_constraint_row {
   int32_t kind;        /* agx_residual_kind                                     */
   int32_t active;      /* ConstraintListItem.active                             */

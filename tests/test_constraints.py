@@ -239,11 +239,48 @@ def test_hip_frame_translation_constraint_matches_the_checker():
     np.testing.assert_allclose(r_h[2], r_o[2], rtol=1e-5, atol=1e-5)
     np.testing.assert_allclose(r_h[3]["kkt"], r_o[3]["kkt"], rtol=1e-5, atol=1e-8)
     hb.close()
-    # a fifth dense-Jacobian component does not fit
-    con2 = con + [_abi.ConstraintSpec(_abi.RES_COLLISION, lower=0.0, upper=np.inf, frame=table.frame_id("panda_link5_capsule_0"), frame_b=fb, name="c2")]
+    # a tenth dense-Jacobian component does not fit (placement 6 + translation 3 + collision 1)
+    P0 = o0.frame_placement(tcp, x0[:1, :7])[0]
+    con2 = con + [_abi.ConstraintSpec(_abi.RES_FRAME_PLACEMENT, lower=-1.0, upper=1.0, ref=P0, frame=tcp, name="pose")]
     po2 = _abi.PackedOcp(7, [0.01] * T, running, terminal, running_constraints=con2)
     with pytest.raises(backend.HipError, match="dense Jacobian"):
         backend.HipOcp(table, po2, 1)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("which", ["rotation+translation", "placement"])
+def test_hip_frame_rotation_and_placement_constraints_match_the_checker(which):
+    """ConstraintModelResidual on ResidualModelFrameRotation (log3, 3 components) and
+    ResidualModelFramePlacement (log6, 6 components) next to a collision constraint."""
+    from agimus_controller_amd import backend
+
+    table, tcp, running, terminal, ref, x0, xs, us = _translation_box_problem(T=10, B=3)
+    T, B = 10, 3
+    o0 = _oracle(table, _abi.PackedOcp(7, [0.01] * T, running, terminal), B)
+    P0 = o0.frame_placement(tcp, x0[:1, :7])[0]
+    fa, fb = table.frame_id("panda_link7_capsule_0"), table.frame_id("obstacle")
+    coll = _abi.ConstraintSpec(_abi.RES_COLLISION, lower=0.05, upper=np.inf, frame=fa, frame_b=fb, name="collision")
+    if which == "placement":
+        con = [_abi.ConstraintSpec(_abi.RES_FRAME_PLACEMENT, lower=[-0.03, -0.03, -0.03, -0.05, -0.05, -0.05],
+                                   upper=[0.03, 0.03, 0.03, 0.05, 0.05, 0.05], ref=P0, frame=tcp, name="pose"), coll]
+    else:
+        con = [_abi.ConstraintSpec(_abi.RES_FRAME_ROTATION, lower=-0.04, upper=0.04, ref=P0[:9], frame=tcp, name="rot"),
+               _abi.ConstraintSpec(_abi.RES_FRAME_TRANSLATION, lower=-0.03, upper=0.03, ref=P0[9:], frame=tcp, name="box"), coll]
+    po = _abi.PackedOcp(7, [0.01] * T, running, terminal, max_qp_iters=100, running_constraints=con, terminal_constraints=con)
+    o = _oracle(table, po, B)
+    hb = backend.HipOcp(table, po, B)
+    hb.set_refs(ref)
+    r_o = o.solve(ref, None, x0, xs, us, 2)
+    r_h = hb.solve(x0, xs, us, 2)
+    assert np.array_equal(r_h[3]["qp_iters"], r_o[3]["qp_iters"])
+    np.testing.assert_allclose(r_h[0], r_o[0], rtol=1e-7, atol=1e-8)
+    np.testing.assert_allclose(r_h[1], r_o[1], rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(r_h[2], r_o[2], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(r_h[3]["kkt"], r_o[3]["kkt"], rtol=1e-5, atol=1e-8)
+    # the constraint really bites: without it the end effector leaves the bounds
+    r_u = o0.solve(ref, None, x0, xs, us, 2)
+    assert np.abs(r_u[0] - r_o[0]).max() > 1e-3
+    hb.close()
 
 
 @pytest.mark.gpu
