@@ -135,15 +135,17 @@ void fill_rows(const agx_cost_row *rows, int n, int nv, DevRows &d) {
   }
 }
 
-int fill_cons(const agx_constraint_row *rows, int n, int nv, const DevModel &m, DevCons &d) {
+int fill_cons(const agx_constraint_row *rows, int n, int nv, const DevModel &m, DevCons &d, bool terminal) {
   std::memset(&d, 0, sizeof(d));
   int off = 0;
   for (int r = 0; r < n; ++r) {
     const agx_constraint_row &c = rows[r];
     if (!c.active) continue;
+    // the terminal node has no control: residuals on u vanish there (crocoddyl evaluates them with nu = 0)
+    if (terminal && (c.kind == AGX_RES_CONTROL || c.kind == AGX_RES_CONTROL_GRAV)) continue;
     if (d.n >= AGX_MAX_CONS) return fail("agx_ocp_create: at most 4 active constraint rows per node type");
     if (c.kind != AGX_RES_STATE && c.kind != AGX_RES_CONTROL && !agx::cons_dense_q(c.kind))
-      return fail("agx_ocp_create: constraints are implemented for State, Control (ControlLimit), FrameTranslation / Rotation / Placement and collision-distance residuals");
+      return fail("agx_ocp_create: unknown constraint residual kind");
     const int nr = agx_row_nr(c.kind, nv), nref = agx_row_nref(c.kind, nv);
     if (off + nr > AGX_MAX_NC) return fail("agx_ocp_create: more than 32 constraint components per node");
     if (!c.lower || !c.upper) return fail("agx_ocp_create: constraint bounds missing");
@@ -167,7 +169,8 @@ int fill_cons(const agx_constraint_row *rows, int n, int nv, const DevModel &m, 
       d.coll_slot[i] = d.ncoll;
       d.ncoll += nr;
     }
-    if (d.ncoll > AGX_MAX_DENSE) return fail("agx_ocp_create: at most 8 constraint components with a dense Jacobian (collision pairs, frame residuals) per node type");
+    if (c.kind == AGX_RES_FRAME_VELOCITY && (c.frame_b < 0 || c.frame_b > 2)) return fail("agx_ocp_create: FrameVelocity constraint: reference frame must be 0 (WORLD), 1 (LOCAL) or 2 (LOCAL_WORLD_ALIGNED)");
+    if (d.ncoll > AGX_MAX_DENSE) return fail("agx_ocp_create: at most 8 constraint components with a dense Jacobian (collision pairs, frame residuals, ControlGrav) per node type");
     off += nr;
   }
   d.nc = off;
@@ -344,12 +347,13 @@ int launch_step(agx_ocp *o, int iter, int max_iter, int mode, bool with_node_kkt
     }
     if (!with_step) { HIPCHK(hipGetLastError()); return 0; }
     if constexpr (NV <= 7) {
-      if (o->ho.use_filter)
-        hipLaunchKernelGGL((agx::k_step<NV, CH, false, true>), dim3(o->B), dim3(128), 0, o->stream, o->d_model, o->d_ocp, o->d_dt, o->d_xs,
-                           o->d_us, o->rv, o->d_qt, o->d_aux, o->d_dx, o->d_nodestat, o->d_du, o->d_state, iter, max_iter, mode, o->d_ndone);
-      else
-        hipLaunchKernelGGL((agx::k_step<NV, CH>), dim3(o->B), dim3(128), 0, o->stream, o->d_model, o->d_ocp, o->d_dt, o->d_xs, o->d_us,
-                           o->rv, o->d_qt, o->d_aux, o->d_dx, o->d_nodestat, o->d_du, o->d_state, iter, max_iter, mode, o->d_ndone);
+#define AGX_LAUNCH_STEP(FILTER, CON)                                                                                                  \
+  hipLaunchKernelGGL((agx::k_step<NV, CH, false, FILTER, CON>), dim3(o->B), dim3(128), 0, o->stream, o->d_model, o->d_ocp, o->d_dt, \
+                     o->d_xs, o->d_us, o->rv, o->d_qt, o->d_aux, o->d_dx, o->d_nodestat, o->d_du, o->d_state, iter, max_iter, mode, \
+                     o->d_ndone)
+      if (o->ho.use_filter) { if (o->has_con) AGX_LAUNCH_STEP(true, true); else AGX_LAUNCH_STEP(true, false); }
+      else { if (o->has_con) AGX_LAUNCH_STEP(false, true); else AGX_LAUNCH_STEP(false, false); }
+#undef AGX_LAUNCH_STEP
     } else {
       // large models: convergence test in k_step, line search node parallel
       const bool split = (mode & 1) && !(mode & 4);
@@ -732,8 +736,8 @@ int agx_ocp_create(const agx_model *m, const agx_ocp_desc *d, int batch, int dev
   o->ho.tol = d->termination_tolerance;
   o->ho.mu_dyn = d->mu_dynamic;
   o->ho.mu_con = d->mu_constraint;
-  if (fill_cons(d->running_constraints, d->n_running_constraints, o->nv, m->h, o->ho.cons[0]) ||
-      fill_cons(d->terminal_constraints, d->n_terminal_constraints, o->nv, m->h, o->ho.cons[1])) { delete o; return -1; }
+  if (fill_cons(d->running_constraints, d->n_running_constraints, o->nv, m->h, o->ho.cons[0], false) ||
+      fill_cons(d->terminal_constraints, d->n_terminal_constraints, o->nv, m->h, o->ho.cons[1], true)) { delete o; return -1; }
   o->has_con = o->ho.cons[0].nc + o->ho.cons[1].nc > 0;
   o->general = o->ho.rows[0].general || o->ho.rows[1].general;
   if (o->general && o->has_con) { delete o; return fail("agx_ocp_create: constraints together with ControlGrav / FrameVelocity cost rows are not implemented"); }
@@ -794,7 +798,7 @@ int agx_ocp_create(const agx_model *m, const agx_ocp_desc *d, int batch, int dev
   if (o->has_con) {
     ALLOC(o->d_qt2, B * (T + 1) * (size_t)o->qt_size);
     ALLOC(o->d_cg, B * (T + 1) * AGX_MAX_NC);
-    ALLOC(o->d_cjac, B * (T + 1) * AGX_MAX_DENSE * 8);
+    ALLOC(o->d_cjac, B * (T + 1) * AGX_MAX_DENSE * 24);
     ALLOC(o->d_y, B * (T + 1) * AGX_MAX_NC);
     ALLOC(o->d_z, B * (T + 1) * AGX_MAX_NC);
     ALLOC(o->d_cx, B * (T + 1) * nx);

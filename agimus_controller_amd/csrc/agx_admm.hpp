@@ -8,9 +8,9 @@
 //   k_admm_update  node parallel   du, C d, z / y update, residual norms, the node's KKT share
 //   k_admm_reduce  one block / instance: norms, rho adaptation, convergence
 //
-// Supported constraint kinds: Control (ConstraintModelControlLimit), State, collision distance,
-// FrameTranslation / FrameRotation / FramePlacement (their components are handled like collision rows:
-// scalar rows with dense gradients in q).
+// Supported constraint kinds: Control (ConstraintModelControlLimit) and State (identity Jacobians, lane
+// local), and every other residual as scalar rows with dense Jacobians [Gq | Gv | Gu]: collision
+// distance, FrameTranslation / FrameRotation / FramePlacement, FrameVelocity, ControlGrav.
 // In the acceleration-input coordinates of the QP tiles (du = M w + taux dx) a constraint row with
 // Jacobians (Gx, Gu) has the row  c = [Gx + Gu taux | Gu M]  on (dx, w).
 //
@@ -24,7 +24,7 @@ constexpr double kRhoMin = 1e-6, kRhoMax = 1e3, kAdaptiveRhoTol = 5.0;
 constexpr int kRhoInterval = 25;
 
 // g, collision Jacobians and the l1 violation of every node at the current (xs, us).
-// One lane per node.  cg [B][T+1][AGX_MAX_NC], cjac [B][T+1][AGX_MAX_DENSE][8].
+// One lane per node.  cg [B][T+1][AGX_MAX_NC], cjac [B][T+1][AGX_MAX_DENSE][24] (d/dq | d/dv | d/du, 8 each).
 template <int NV, bool CHAIN>
 __global__ void __launch_bounds__(64) k_con_eval(const DevModel *__restrict__ mp, const DevOcp *__restrict__ op,
                                                  const double *__restrict__ xs, const double *__restrict__ us,
@@ -39,7 +39,7 @@ __global__ void __launch_bounds__(64) k_con_eval(const DevModel *__restrict__ mp
   const int b = (int)(node / (T + 1)), t = (int)(node % (T + 1));
   if (st[b].done) return;
   const DevCons &c = o.cons[t == T ? 1 : 0];
-  double x[NX], u[NU], g[AGX_MAX_NC], cj[AGX_MAX_DENSE][8];
+  double x[NX], u[NU], g[AGX_MAX_NC], cj[AGX_MAX_DENSE][24];
 #pragma unroll
   for (int i = 0; i < NX; ++i) x[i] = xs[node * NX + i];
 #pragma unroll
@@ -48,7 +48,7 @@ __global__ void __launch_bounds__(64) k_con_eval(const DevModel *__restrict__ mp
   constraints_eval<NV, CHAIN, true>(m, c, x, u, g, cj);
   for (int k = 0; k < c.nc; ++k) cg[node * AGX_MAX_NC + k] = g[k];
   for (int r = 0; r < c.ncoll; ++r)
-    for (int j = 0; j < 8; ++j) cjac[(node * AGX_MAX_DENSE + r) * 8 + j] = (j < NV) ? cj[r][j] : 0.0;
+    for (int j = 0; j < 24; ++j) cjac[(node * AGX_MAX_DENSE + r) * 24 + j] = ((j & 7) < NV) ? cj[r][j] : 0.0;
   nodestat[node * 4 + 3] = violation_l1(c, g);
 }
 
@@ -147,23 +147,49 @@ __global__ void __launch_bounds__(128) k_admm_tile(const DevOcp *__restrict__ op
     q2[Q::Hqq + j * Q::LD + j] += add_qq_diag;
     q2[Q::Hvv + j * Q::LD + j] += add_vv_diag;
   }
-  // rows with dense gradients in q (collision distance: 1 component, frame translation: 3): rank one each on the qq block
+  // rows with dense Jacobians (collision distance, frame residuals, ControlGrav): every component is a
+  // scalar row G = [Gq | Gv | Gu]; in tile coordinates  c = [Gq + Gu taux | Gu M]  on (dx, w): rank one
+  // on every block; the gradient terms of the u part ride in hu[] with those of the control rows
+  const double *Mm = sh, *tq = sh + B2, *tv = sh + 2 * B2;
   for (int r = 0; r < c.n; ++r) {
     if (!cons_dense_q(c.kind[r])) continue;
     for (int e = 0; e < c.nr[r]; ++e) {
       const int off = c.off[r] + e;
-      const double *gj = cjac + (unit * AGX_MAX_DENSE + c.coll_slot[r] + e) * 8;
+      const double *gj = cjac + (unit * AGX_MAX_DENSE + c.coll_slot[r] + e) * 24;
       const double rho = admm_rho(c.lb[off], c.ub[off], rs);
       const double h = y[off] - rho * z[off];
       gq += h * gj[j];
-      if (wr && full)
-        for (int i = 0; i < NV; ++i) q2[Q::Hqq + i * Q::LD + j] += rho * gj[i] * gj[j];
+      gv += h * gj[8 + j];
+      double cq = gj[j], cv = gj[8 + j], cw = 0.0;
+      if (t < T) {
+#pragma unroll
+        for (int l = 0; l < NV; ++l) {
+          const double gu = gj[16 + l];
+          hu[l] += h * gu;
+          cw += Mm[l * LD + j] * gu; cq += tq[l * LD + j] * gu; cv += tv[l * LD + j] * gu;
+        }
+      }
+      if (full) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+          const double cqi = __shfl(cq, i, 8), cvi = __shfl(cv, i, 8), cwi = __shfl(cw, i, 8);
+          if (wr) {
+            q2[Q::Hqq + i * Q::LD + j] += rho * cqi * cq;
+            q2[Q::Hqv + i * Q::LD + j] += rho * cqi * cv;
+            q2[Q::Hvv + i * Q::LD + j] += rho * cvi * cv;
+            if (t < T) {
+              q2[Q::Hww + i * Q::LD + j] += rho * cwi * cw;
+              q2[Q::Hqw + i * Q::LD + j] += rho * cqi * cw;
+              q2[Q::Hvw + i * Q::LD + j] += rho * cvi * cw;
+            }
+          }
+        }
+      }
     }
   }
   double gwv = 0.0;
   if (t < T) {
     const double *du = dus + ((long long)b * T + t) * NV;
-    const double *Mm = sh, *tq = sh + B2, *tv = sh + 2 * B2;
     double Mc[NV], tqc[NV], tvc[NV];
 #pragma unroll
     for (int l = 0; l < NV; ++l) {
@@ -385,11 +411,18 @@ __global__ void __launch_bounds__(256) k_admm_update(const DevOcp *__restrict__ 
       }
     } else if (cons_dense_q(c.kind[r])) {
       for (int e = 0; e < c.nr[r]; ++e) {
-        const double gj = jl ? cjac[(nid * AGX_MAX_DENSE + c.coll_slot[r] + e) * 8 + jj] : 0.0;
-        double Cd = gj * dq;
+        const double *row = cjac + (nid * AGX_MAX_DENSE + c.coll_slot[r] + e) * 24;
+        const double gqj = jl ? row[jj] : 0.0, gvj = jl ? row[8 + jj] : 0.0, guj = (jl && t < T) ? row[16 + jj] : 0.0;
+        double Cd = gqj * dq + gvj * dv + guj * du;
         Cd += dpp_xor4(Cd); Cd += dpp_xor2(Cd); Cd += dpp_xor1(Cd);
-        const double2 zy = comp(off + e, Cd, dual_q, drel_q, e_q, gj);  // identical on every lane of the group
-        hn_q += (zy.y - admm_rho(c.lb[off + e], c.ub[off + e], rs) * zy.x) * gj;
+        // identical on every lane of the group; the three accumulator sets take the row's q / v / u entries
+        const double2 zy = comp(off + e, Cd, dual_q, drel_q, e_q, gqj);
+        const double rho = admm_rho(c.lb[off + e], c.ub[off + e], rs);
+        const double z0 = z[off + e], y0 = y[off + e];
+        const double hn = zy.y - rho * zy.x, de = rho * Cd + (y0 - rho * z0) - zy.y, dz = rho * (zy.x - z0);
+        dual_v += gvj * dz; drel_v += gvj * zy.y; e_v += gvj * de;
+        dual_u += guj * dz; drel_u += guj * zy.y; e_u += guj * de;
+        hn_q += hn * gqj; hn_v += hn * gvj; hn_u += hn * guj;
         if (act && l8 == 0) { z[off + e] = zy.x; y[off + e] = zy.y; }
       }
     }
@@ -453,6 +486,10 @@ __global__ void __launch_bounds__(128) k_admm_reduce(const DevOcp *__restrict__ 
   const int T = o.T, b = blockIdx.x, tid = threadIdx.x;
   DevState &S = st[b];
   if (S.done || S.admm_conv) return;
+  if (S.dir_fail) {  // the factorisation of this instance's augmented problem broke down: nothing to iterate on
+    if (tid == 0) { S.admm_conv = 1; S.admm_iter = iter; atomicAdd(n_conv, 1); }
+    return;
+  }
   double v[4] = {0.0, 0.0, 0.0, 0.0};
   for (int t = tid; t <= T; t += blockDim.x) {
     const double *as = admmstat + ((long long)b * (T + 1) + t) * 4;

@@ -1029,14 +1029,21 @@ AGX_UNROLL_NV
   }
 }
 
+}  // namespace agx
+#include "agx_general.hpp"
+namespace agx {
+
 // Constraints of one node (ConstraintModelManager of the node's differential model): g stacked over
-// the rows; JAC also returns d(distance)/dq of every collision row (the other supported kinds have
-// identity Jacobians: State on x, Control on u).
+// the rows; JAC also returns the Jacobian rows [d/dq (8) | d/dv (8) | d/du (8)] of every component of
+// the rows with dense Jacobians (slot coll_slot[r] + e); State / Control rows have identity Jacobians.
 template <int NV, bool CHAIN, bool JAC>
 AGX_DEV void constraints_eval(const DevModel &m, const DevCons &c, const double *x, const double *u, double *g,
-                              double (*cj)[8]) {
+                              double (*cj)[24]) {
   Kin<NV> k;
   if (c.ncoll > 0) kinematics<NV, CHAIN>(m, x, k);
+  if (JAC)
+    for (int s = 0; s < c.ncoll; ++s)
+      for (int j = 0; j < 24; ++j) cj[s][j] = 0.0;
   for (int r = 0; r < c.n; ++r) {
     const int kind = c.kind[r], off = c.off[r];
     if (kind == AGX_RES_STATE) {
@@ -1045,6 +1052,35 @@ AGX_DEV void constraints_eval(const DevModel &m, const DevCons &c, const double 
     } else if (kind == AGX_RES_CONTROL) {
 #pragma unroll
       for (int i = 0; i < NV; ++i) g[off + i] = u[i] - c.ref[r][i];
+    } else if (kind == AGX_RES_FRAME_VELOCITY) {
+      // v_frame(q, qd) - vref in the row's reference frame (frame_b: WORLD / LOCAL / LOCAL_WORLD_ALIGNED)
+      double vel[6], Rq[6][NV], Rv[6][NV];
+      frame_velocity<NV, CHAIN, JAC>(m, k, c.frame[r], c.frame_b[r], x + NV, vel, Rq, Rv);
+#pragma unroll
+      for (int e = 0; e < 6; ++e) g[off + e] = vel[e] - c.ref[r][e];
+      if (JAC) {
+        for (int e = 0; e < 6; ++e)
+AGX_UNROLL_NV
+          for (int j = 0; j < NV; ++j) { cj[c.coll_slot[r] + e][j] = Rq[e][j]; cj[c.coll_slot[r] + e][8 + j] = Rv[e][j]; }
+      }
+    } else if (kind == AGX_RES_CONTROL_GRAV) {
+      // u - g(q): d/du = I, d/dq = -dg/dq (RNEA derivative at zero velocity and acceleration)
+      Dyn<NV> d0;
+      double g0[NV], M0[NV][NV], zero[NV];
+#pragma unroll
+      for (int i = 0; i < NV; ++i) zero[i] = 0.0;
+      bias_and_inertia<NV, CHAIN>(m, k, zero, d0, g0, M0);
+#pragma unroll
+      for (int i = 0; i < NV; ++i) g[off + i] = u[i] - g0[i];
+      if (JAC) {
+        double Gq[NV][NV], Gv[NV][NV];
+        rnea_derivatives<NV, CHAIN>(m, k, d0, zero, zero, Gq, Gv);
+        for (int i = 0; i < NV; ++i) {
+AGX_UNROLL_NV
+          for (int j = 0; j < NV; ++j) cj[c.coll_slot[r] + i][j] = -Gq[i][j];
+          cj[c.coll_slot[r] + i][16 + i] = 1.0;
+        }
+      }
     } else if (kind == AGX_RES_FRAME_TRANSLATION || kind == AGX_RES_FRAME_ROTATION || kind == AGX_RES_FRAME_PLACEMENT) {
       // the residuals of the cost rows (node_costs) as constraints: translation p(q) - pref with the
       // LOCAL_WORLD_ALIGNED linear frame Jacobian, rotation log3(Rref' R) with Jlog3 * LOCAL angular
@@ -1121,7 +1157,8 @@ AGX_UNROLL_NV
 }
 // constraint kinds whose components are scalar rows with dense gradients in q (Jacobian slots)
 AGX_HD bool cons_dense_q(int kind) {
-  return kind == AGX_RES_COLLISION || kind == AGX_RES_FRAME_TRANSLATION || kind == AGX_RES_FRAME_ROTATION || kind == AGX_RES_FRAME_PLACEMENT;
+  return kind == AGX_RES_COLLISION || kind == AGX_RES_FRAME_TRANSLATION || kind == AGX_RES_FRAME_ROTATION || kind == AGX_RES_FRAME_PLACEMENT ||
+         kind == AGX_RES_FRAME_VELOCITY || kind == AGX_RES_CONTROL_GRAV;
 }
 // l1 norm of the violation of lb <= g <= ub (SolverCSQP::calc / tryStep constraint_norm)
 AGX_DEV double violation_l1(const DevCons &c, const double *g) {
@@ -1142,10 +1179,6 @@ AGX_DEV double admm_rho(double lb, double ub, double rho_sparse) {
   if (fabs(lb - ub) <= 1e-6) return 1e3 * rho_sparse;
   return rho_sparse;
 }
-
-}  // namespace agx
-#include "agx_general.hpp"
-namespace agx {
 
 // calc of a running node: forward dynamics + semi-implicit Euler + cost
 // (crocoddyl IntegratedActionModelEuler::calc).

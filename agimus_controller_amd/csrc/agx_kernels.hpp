@@ -30,6 +30,7 @@ struct DevState {
   int admm_conv, admm_iter;      // QP converged in this SQP iteration / ADMM iterations done
   int ls_acc;                    // split line search (large models): step accepted in this SQP iteration
   int admm_refactor;             // ADMM: the Hessian part of the augmented tiles changed (first iteration / new rho)
+  int dir_fail;                  // the last backward sweep met a non-positive / non-finite pivot (Quu not positive definite)
 };
 
 // Addressing of the reference tiles (host tile or a window of the resident trajectory).
@@ -618,6 +619,7 @@ __device__ __forceinline__ void riccati_body(const int b, const DevOcp *__restri
   const DevOcp &o = *op;
   const int T = o.T, lane = threadIdx.x;
   DevState &S = st[b];
+  bool bad_pivot = false;  // per lane: the reciprocal pivot of its grid row was not positive at some node
   // direction sweep: live instances.  Gains sweep, by gmode:
   //   0  every instance (agx_ocp_direction, timing), with the regularisation of its last direction;
   //   1  speculative, launched next to the direction sweep of SQP iteration `iter`: live instances, same dreg;
@@ -772,6 +774,7 @@ AGX_UNROLL_NV
     pivot(std::integral_constant<int, 0>()); pivot(std::integral_constant<int, 1>()); pivot(std::integral_constant<int, 2>());
     pivot(std::integral_constant<int, 3>()); pivot(std::integral_constant<int, 4>()); pivot(std::integral_constant<int, 5>());
     pivot(std::integral_constant<int, 6>());
+    bad_pivot = bad_pivot || !(rp_row > 0.0);  // lane (r, *) keeps the reciprocal of pivot r (1.0 outside the block)
     if constexpr (STORE) {
       double *ft = facs + ((long long)b * T + t) * FT<NV>::SIZE;
       if (c == 0) ft[FT<NV>::RP + r] = rp_row;
@@ -810,6 +813,16 @@ AGX_UNROLL_NV
   for (int t = T - 1; t >= 0; t -= 2) {
     step(ta, t);
     if (t >= 1) step(tb, t - 1);
+  }
+  if (!GAINS) {
+    // Quu of some node not positive definite (SolverCSQP: the LLT of the backward pass fails and the
+    // direction is discarded): the step kernel rejects the step and raises the regularisation, the ADMM
+    // loop stops for this instance
+    const bool any_bad = __any(bad_pivot);
+    if (lane == 0) {
+      S.dir_fail = any_bad ? 1 : 0;
+      if (any_bad) S.flags |= 1;
+    }
   }
   if (GAINS || !forward) return;
   riccati_forward<NV>(b, T, dts, qb, Kw, kw, dxs, wss);
@@ -916,7 +929,10 @@ AGX_UNROLL_NV
 // mode bit2: timing mode (no convergence exit, nothing committed) so that launches are repeatable.
 // mode bit3: convergence test only; the line search is done node-parallel by k_ls_trial / k_ls_accept (large models).
 // ---------------------------------------------------------------------------
-template <int NV, bool CHAIN, bool GEN = false, bool FILTER = false>
+// CON: the merit of a trial point includes the constraint violation.  A template flag rather than a
+// run-time test: compiled into the unconstrained kernel, the registers and scratch of every residual
+// kind a constraint may carry cost the hot path 0.155 -> 0.21 ms.
+template <int NV, bool CHAIN, bool GEN = false, bool FILTER = false, bool CON = false>
 __global__ void __launch_bounds__(128) k_step(const DevModel *__restrict__ mp, const DevOcp *__restrict__ op,
                                               const double *__restrict__ dts, double *__restrict__ xs,
                                               double *__restrict__ us, RefView rv, const double *__restrict__ qts,
@@ -976,7 +992,11 @@ __global__ void __launch_bounds__(128) k_step(const DevModel *__restrict__ mp, c
   // ---- line search
   double alpha = 1.0, used = 1.0;
   bool ok = false;
-  for (int n = 0; n < 10; ++n, alpha *= 0.5) {
+  // a direction from a failed factorisation is never accepted (the CPU restatement gets there through
+  // NaNs in the trial merit): all ten step lengths count as rejected
+  const int n_trials = S.dir_fail ? 0 : 10;
+  if (n_trials == 0) used = 1.0 / 512.0;
+  for (int n = 0; n < n_trials; ++n, alpha *= 0.5) {
     used = alpha;
     if constexpr (!FILTER) {
       // merit line search (the reference default): one accumulator, cost + mu_dyn gaps + mu_con violation
@@ -997,12 +1017,12 @@ AGX_UNROLL_NV
           for (int i = 0; i < NX; ++i)
             g += fabs(xn[i] - (X[(long long)(t + 1) * NX + i] + alpha * DX[(long long)(t + 1) * NX + i]));
           part += c + o.mu_dyn * g;
-          if (o.has_con) part += o.mu_con * constraint_violation<NV, CHAIN>(m, o.cons[0], x, u);
+          if constexpr (CON) part += o.mu_con * constraint_violation<NV, CHAIN>(m, o.cons[0], x, u);
         } else {
           double c;
           node_calc_terminal<NV, CHAIN, GEN>(m, o.rows[1], x, ref_at(rv, b, T, T), frames_at(rv, b, T, T), &c);
           part += c;
-          if (o.has_con) part += o.mu_con * constraint_violation<NV, CHAIN>(m, o.cons[1], x, x);
+          if constexpr (CON) part += o.mu_con * constraint_violation<NV, CHAIN>(m, o.cons[1], x, x);
         }
       }
       part = wave_sum(part);
@@ -1033,12 +1053,12 @@ AGX_UNROLL_NV
           for (int i = 0; i < NX; ++i)
             g += fabs(xn[i] - (X[(long long)(t + 1) * NX + i] + alpha * DX[(long long)(t + 1) * NX + i]));
           pc += c; pg += g;
-          if (o.has_con) pv += constraint_violation<NV, CHAIN>(m, o.cons[0], x, u);
+          if constexpr (CON) pv += constraint_violation<NV, CHAIN>(m, o.cons[0], x, u);
         } else {
           double c;
           node_calc_terminal<NV, CHAIN, GEN>(m, o.rows[1], x, ref_at(rv, b, T, T), frames_at(rv, b, T, T), &c);
           pc += c;
-          if (o.has_con) pv += constraint_violation<NV, CHAIN>(m, o.cons[1], x, x);
+          if constexpr (CON) pv += constraint_violation<NV, CHAIN>(m, o.cons[1], x, x);
         }
       }
       pc = wave_sum(pc); pg = wave_sum(pg); pv = wave_sum(pv);
@@ -1086,6 +1106,7 @@ AGX_UNROLL_NV
     S.gains_dreg = dreg;
     S.preg = pr;
     S.dreg = dr;
+    S.dir_fail = 0;
     if (stop) {
       S.done = 1;
       S.iter = iter + 1;
@@ -1107,7 +1128,7 @@ __global__ void k_reset_state(DevState *st, int B, int *n_done) {
   s.rho_sparse = st[b].rho_sparse; s.con = 0.0; s.admm_conv = 0; s.admm_iter = 0; s.ls_acc = 0; s.admm_refactor = 1;
   s.kkt = 0.0; s.cost = 0.0; s.merit = 0.0; s.gap = 0.0;
   s.preg = kRegMin; s.dreg = kRegMin;
-  s.iter = 0; s.qp_iters = 0; s.solved = 0; s.flags = 0; s.done = 0; s.gains_iter = -1; s.dir_iter = -1;
+  s.iter = 0; s.qp_iters = 0; s.solved = 0; s.flags = 0; s.done = 0; s.gains_iter = -1; s.dir_iter = -1; s.dir_fail = 0;
   s.gains_preg = kRegMin; s.gains_dreg = kRegMin;
   st[b] = s;
 }
@@ -1275,7 +1296,7 @@ AGX_UNROLL_NV
     s.rho_sparse = st[b].rho_sparse; s.con = 0.0; s.admm_conv = 0; s.admm_iter = 0; s.ls_acc = 0; s.admm_refactor = 1;
     s.kkt = 0.0; s.cost = 0.0; s.merit = 0.0; s.gap = 0.0;
     s.preg = kRegMin; s.dreg = kRegMin;
-    s.iter = 0; s.qp_iters = 0; s.solved = 0; s.flags = 0; s.done = 0; s.gains_iter = -1; s.dir_iter = -1;
+    s.iter = 0; s.qp_iters = 0; s.solved = 0; s.flags = 0; s.done = 0; s.gains_iter = -1; s.dir_iter = -1; s.dir_fail = 0;
     s.gains_preg = kRegMin; s.gains_dreg = kRegMin;
     st[b] = s;
   }

@@ -572,21 +572,21 @@ class DifferentialActionModelFreeFwdDynamics(DifferentialActionModel):
             con = item.constraint
             res = con.residual
             kind = res.kind
-            if kind in (_abi.RES_CONTROL_GRAV, _abi.RES_FRAME_VELOCITY):
-                raise NotImplementedError(f"constraint '{item.name}': {type(res).__name__} is not implemented on the HIP path yet")
             nr = _abi.row_nr(kind, data.nv)
             if isinstance(con, ConstraintModelControlLimit):
                 lim = np.asarray(data.model.effortLimit, dtype=float)
                 lo, up = -lim, lim
             else:
                 lo, up = con.bounds(nr)
-            active = bool(item.active) and not (terminal and (kind == _abi.RES_CONTROL or not con.active_on_terminal_node))
+            active = bool(item.active) and not (terminal and (kind in (_abi.RES_CONTROL, _abi.RES_CONTROL_GRAV) or not con.active_on_terminal_node))
             fa = fb = 0
             if kind == _abi.RES_COLLISION:
                 fa, fb = res.geometry_frames(data)
                 ref = None
             else:
                 fa = res.frame(data)
+                if kind == _abi.RES_FRAME_VELOCITY:
+                    fb = res.reference_frame_id()  # 0 WORLD, 1 LOCAL, 2 LOCAL_WORLD_ALIGNED
                 ref = np.asarray(res.reference(data), dtype=float).reshape(-1)
             out.append(_abi.ConstraintSpec(kind=kind, lower=lo, upper=up, ref=ref, active=active, frame=fa, frame_b=fb, name=item.name))
         return out

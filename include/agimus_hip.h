@@ -74,11 +74,12 @@ typedef struct agx_cost_row {
  *   lower <= r(x, u) <= upper   with r one of the residual kinds above.
  * ConstraintModelControlLimit (:624-640) is the AGX_RES_CONTROL row with zero
  * reference and -/+ effort limit.  Constraints are not updated per node
- * (:720-721), so reference and bounds are static.  Implemented kinds: State,
- * Control, FrameTranslation / FrameRotation / FramePlacement (pref in ref, laid
- * out like the cost rows' references) and collision distance; at most 4 rows and
- * 8 components with a dense Jacobian (collision 1, translation / rotation 3,
- * placement 6) per node type; other kinds are refused by agx_ocp_create.        */
+ * (:720-721), so reference and bounds are static.  Every residual kind is
+ * implemented (references laid out like the cost rows'; FrameVelocity: frame_b =
+ * reference frame 0 WORLD / 1 LOCAL / 2 LOCAL_WORLD_ALIGNED); at most 4 rows and 8
+ * components with a dense Jacobian (collision 1, translation / rotation 3,
+ * placement / velocity 6, ControlGrav nv) per node type; residuals on u are
+ * dropped at the terminal node.                                                 */
 typedef struct agx_constraint_row {
   int32_t kind;        /* agx_residual_kind                                     */
   int32_t active;      /* ConstraintListItem.active                             */

@@ -284,6 +284,41 @@ def test_hip_frame_rotation_and_placement_constraints_match_the_checker(which):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("which", ["frame_velocity", "control_grav"])
+def test_hip_velocity_and_gravity_torque_constraints_match_the_checker(which):
+    """Residuals that depend on v and u as constraints (rows with dense Jacobians [Gq | Gv | Gu]):
+    ResidualModelFrameVelocity (LOCAL_WORLD_ALIGNED, bounded end-effector speed) and
+    ResidualModelControlGrav (bounded torque beyond gravity compensation)."""
+    from agimus_controller_amd import backend
+
+    table, tcp, running, terminal, ref, x0, xs, us = _translation_box_problem(T=10, B=3)
+    T, B = 10, 3
+    if which == "frame_velocity":
+        con = [_abi.ConstraintSpec(_abi.RES_FRAME_VELOCITY, lower=[-0.05, -0.05, -0.05, -0.5, -0.5, -0.5], upper=[0.05, 0.05, 0.05, 0.5, 0.5, 0.5],
+                                   ref=np.zeros(6), frame=tcp, frame_b=2, name="ee_speed")]
+        term = con
+    else:
+        con = [_abi.ConstraintSpec(_abi.RES_CONTROL_GRAV, lower=-4.0, upper=4.0, name="tau_minus_g")]
+        term = []
+    po = _abi.PackedOcp(7, [0.01] * T, running, terminal, max_qp_iters=100, running_constraints=con, terminal_constraints=term)
+    o = _oracle(table, po, B)
+    hb = backend.HipOcp(table, po, B)
+    hb.set_refs(ref)
+    r_o = o.solve(ref, None, x0, xs, us, 2)
+    r_h = hb.solve(x0, xs, us, 2)
+    assert np.array_equal(r_h[3]["qp_iters"], r_o[3]["qp_iters"])
+    np.testing.assert_allclose(r_h[0], r_o[0], rtol=1e-7, atol=1e-8)
+    np.testing.assert_allclose(r_h[1], r_o[1], rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(r_h[2], r_o[2], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(r_h[3]["kkt"], r_o[3]["kkt"], rtol=1e-5, atol=1e-8)
+    # the constraint changes the solution
+    o0 = _oracle(table, _abi.PackedOcp(7, [0.01] * T, running, terminal), B)
+    r_u = o0.solve(ref, None, x0, xs, us, 2)
+    assert np.abs(r_u[1] - r_o[1]).max() > 1e-2
+    hb.close()
+
+
+@pytest.mark.gpu
 def test_hip_config3_full_size_properties():
     """BASELINE.json configs[2] shape (horizon 200, batch 256, collision-avoidance costs + distance
     constraint) on the resident sine-wave workload: after MPC steps every solved instance keeps the
