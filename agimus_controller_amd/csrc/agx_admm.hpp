@@ -342,7 +342,8 @@ __global__ void __launch_bounds__(256) k_admm_update(const DevOcp *__restrict__ 
   const long long nid = ok ? node : 0;
   const int b = (int)(nid / (T + 1)), t = (int)(nid % (T + 1));
   const DevState &S = st[b];
-  const bool act = ok && !S.done && !S.admm_conv;
+  // dir_fail: the sweep of this iteration broke down (k_admm_reduce stops the instance): multipliers stay
+  const bool act = ok && !S.done && !S.admm_conv && !S.dir_fail;
   if (!__any(act)) return;
   const double preg = S.preg, dreg = S.dreg, rs = S.rho_sparse, sig = kSigma;
   const bool jl = l8 < NV;

@@ -1196,7 +1196,12 @@ bool direction_admm(int nv, int T, const double *tiles, const std::vector<ConNod
           }
       }
     }
-    ok = direction(nv, T, aug.data(), d, kSigma, preg, dreg, cx.data(), cu.data()) && ok;
+    const bool ok_iter = direction(nv, T, aug.data(), d, kSigma, preg, dreg, cx.data(), cu.data());
+    ok = ok_iter && ok;
+    if (!ok_iter) {  // Quu of the augmented problem not positive definite: the direction is discarded, multipliers stay
+      a.qp_iters = iter;
+      break;
+    }
     // update_lagrangian_parameters
     double norm_primal = 0.0, norm_dual = 0.0, norm_primal_rel = 0.0, norm_dual_rel = 0.0;
     for (int t = 0; t <= T; ++t) {

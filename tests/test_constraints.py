@@ -319,6 +319,71 @@ def test_hip_velocity_and_gravity_torque_constraints_match_the_checker(which):
 
 
 @pytest.mark.gpu
+def test_hip_breakdown_of_the_factorisation_is_handled_like_the_checker():
+    """An instance of the collision workload whose reference ends inside the obstacle: the QuadExp cost
+    has negative curvature there, Quu loses positive definiteness, the direction is discarded (flags
+    bit 0), the step rejected (bit 1), the regularisation raised -- and after enough iterations the
+    solve proceeds.  HIP (sign of the reciprocal pivots) and checker (LLT failure) must walk the same path."""
+    import bench
+    from agimus_controller_amd import backend
+
+    T, dt = 200, 0.01
+    table, tcp, po = bench.make_problem(T, "collision")
+    sel = [14, 0]  # instance 14 of the benchmark batch is such a case, instance 0 is a regular one
+    q0, amp, puls, scale, t0 = workloads.sine_batch_params(16, nv=7, seed0=1234, lower=table.lower_position_limit, upper=table.upper_position_limit)
+    q0, amp, puls, scale, t0 = q0[sel], amp[sel], puls[sel], scale[sel], t0[sel]
+    B = len(sel)
+    o = _oracle(table, po, B)
+    w = workloads.SINE_WEIGHTS
+    ref = po.new_ref_tile(B)
+    xs, us = np.empty((B, T + 1, 14)), np.empty((B, T, 7))
+    for t in range(T + 1):
+        tt = t0 + t * dt
+        s_ = np.clip(tt[:, None] / scale, 0.0, 1.0)
+        ramp = 10 * s_**3 - 15 * s_**4 + 6 * s_**5
+        dramp = np.where((s_ > 0) & (s_ < 1), (30 * s_**2 - 60 * s_**3 + 30 * s_**4) / scale, 0.0)
+        ddramp = np.where((s_ > 0) & (s_ < 1), (60 * s_ - 180 * s_**2 + 120 * s_**3) / scale**2, 0.0)
+        sw, cw = np.sin(puls * tt[:, None]), np.cos(puls * tt[:, None])
+        q = q0 + amp * ramp * sw
+        dq = amp * (dramp * sw + ramp * puls * cw)
+        ddq = amp * (ddramp * sw + 2 * dramp * puls * cw - ramp * puls**2 * sw)
+        u, pose = o.rnea(q, dq, ddq).reshape(B, 7), o.frame_placement(tcp, q)
+        xs[:, t] = np.concatenate([q, dq], 1)
+        if t < T:
+            us[:, t] = u
+        rows, offs = (po.terminal, po.terminal_offsets) if t == T else (po.running, po.running_offsets)
+        for r, off in zip(rows, offs):
+            seg = ref[:, t, off:]
+            seg[:, 0] = 1.0
+            if r.kind == _abi.RES_STATE:
+                seg[:, 1:15], seg[:, 15:22], seg[:, 22:29] = xs[:, t], w["w_q"], w["w_qdot"]
+            elif r.kind == _abi.RES_CONTROL:
+                seg[:, 1:8], seg[:, 8:15] = u, w["w_effort"]
+            elif r.kind == _abi.RES_FRAME_PLACEMENT:
+                seg[:, 1:13], seg[:, 13:19] = pose, w["w_pose"]
+            else:
+                seg[:, 1] = 0.0
+    x0 = xs[:, 0].copy()
+    dist = np.array([o.node_constraints(False, xs[0, t], us[0, t])[0][0] for t in range(T)])
+    assert dist.min() < 0.0 < dist[0]  # the reference of the first instance really enters the obstacle
+    for iters in (2, 10):
+        r_o = _oracle(table, po, B).solve(ref, None, x0, xs, us, iters)
+        hb = backend.HipOcp(table, po, B)
+        hb.set_refs(ref)
+        r_h = hb.solve(x0, xs, us, iters)
+        hb.close()
+        assert np.array_equal(r_h[3]["iter"], r_o[3]["iter"]) and np.array_equal(r_h[3]["qp_iters"], r_o[3]["qp_iters"])
+        assert np.array_equal(r_h[3]["flags"], r_o[3]["flags"])
+        np.testing.assert_allclose(r_h[0], r_o[0], rtol=1e-6, atol=1e-7)
+        np.testing.assert_allclose(r_h[1], r_o[1], rtol=1e-5, atol=1e-5)
+        if iters == 2:
+            assert r_o[3]["flags"][0] == 3 and np.array_equal(r_o[0][0], xs[0])  # discarded direction, rejected step
+        else:
+            assert r_o[3]["qp_iters"][0] > 1 and not np.array_equal(r_o[0][0], xs[0])  # it got going again
+    assert np.all(np.isfinite(r_h[2]))
+
+
+@pytest.mark.gpu
 def test_hip_config3_full_size_properties():
     """BASELINE.json configs[2] shape (horizon 200, batch 256, collision-avoidance costs + distance
     constraint) on the resident sine-wave workload: after MPC steps every solved instance keeps the
