@@ -144,7 +144,7 @@ int fill_cons(const agx_constraint_row *rows, int n, int nv, const DevModel &m, 
     // the terminal node has no control: residuals on u vanish there (crocoddyl evaluates them with nu = 0)
     if (terminal && (c.kind == AGX_RES_CONTROL || c.kind == AGX_RES_CONTROL_GRAV)) continue;
     if (d.n >= AGX_MAX_CONS) return fail("agx_ocp_create: at most 4 active constraint rows per node type");
-    if (c.kind != AGX_RES_STATE && c.kind != AGX_RES_CONTROL && !agx::cons_dense_q(c.kind))
+    if (c.kind != AGX_RES_STATE && c.kind != AGX_RES_CONTROL && !agx::cons_has_dense_rows(c.kind))
       return fail("agx_ocp_create: unknown constraint residual kind");
     const int nr = agx_row_nr(c.kind, nv), nref = agx_row_nref(c.kind, nv);
     if (off + nr > AGX_MAX_NC) return fail("agx_ocp_create: more than 32 constraint components per node");
@@ -164,7 +164,7 @@ int fill_cons(const agx_constraint_row *rows, int n, int nv, const DevModel &m, 
         return fail("agx_ocp_create: box / box collision pairs are not supported");
       d.coll_slot[i] = d.ncoll++;
     }
-    if (c.kind != AGX_RES_COLLISION && agx::cons_dense_q(c.kind)) {  // nr scalar rows with dense gradients in q: nr Jacobian slots
+    if (c.kind != AGX_RES_COLLISION && agx::cons_has_dense_rows(c.kind)) {  // nr scalar rows with dense gradients in q: nr Jacobian slots
       if (c.frame < 0 || c.frame >= m.nframes) return fail("agx_ocp_create: constraint frame id out of range");
       d.coll_slot[i] = d.ncoll;
       d.ncoll += nr;

@@ -152,7 +152,7 @@ __global__ void __launch_bounds__(128) k_admm_tile(const DevOcp *__restrict__ op
   // on every block; the gradient terms of the u part ride in hu[] with those of the control rows
   const double *Mm = sh, *tq = sh + B2, *tv = sh + 2 * B2;
   for (int r = 0; r < c.n; ++r) {
-    if (!cons_dense_q(c.kind[r])) continue;
+    if (!cons_has_dense_rows(c.kind[r])) continue;
     for (int e = 0; e < c.nr[r]; ++e) {
       const int off = c.off[r] + e;
       const double *gj = cjac + (unit * AGX_MAX_DENSE + c.coll_slot[r] + e) * 24;
@@ -410,7 +410,7 @@ __global__ void __launch_bounds__(256) k_admm_update(const DevOcp *__restrict__ 
         hn_v += bq.y - admm_rho(c.lb[off + NV + jj], c.ub[off + NV + jj], rs) * bq.x;
         if (act) { z[off + jj] = a.x; y[off + jj] = a.y; z[off + NV + jj] = bq.x; y[off + NV + jj] = bq.y; }
       }
-    } else if (cons_dense_q(c.kind[r])) {
+    } else if (cons_has_dense_rows(c.kind[r])) {
       for (int e = 0; e < c.nr[r]; ++e) {
         const double *row = cjac + (nid * AGX_MAX_DENSE + c.coll_slot[r] + e) * 24;
         const double gqj = jl ? row[jj] : 0.0, gvj = jl ? row[8 + jj] : 0.0, guj = (jl && t < T) ? row[16 + jj] : 0.0;

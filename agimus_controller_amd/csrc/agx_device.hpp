@@ -48,7 +48,7 @@ struct DevRows {
 #define AGX_MAX_DENSE 8  // constraint components with a dense Jacobian in q per node type (collision 1, translation / rotation 3, placement 6)
 #define AGX_MAX_NC 32
 struct DevCons {
-  int n, nc, ncoll, pad;
+  int n, nc, ncoll, pad;  // rows, components, Jacobian slots in use (ncoll: historically the collision rows)
   int kind[AGX_MAX_CONS], frame[AGX_MAX_CONS], frame_b[AGX_MAX_CONS], off[AGX_MAX_CONS], nr[AGX_MAX_CONS];
   int coll_slot[AGX_MAX_CONS];  // first Jacobian slot (of AGX_MAX_DENSE) of a row whose components have dense gradients in q
   double ref[AGX_MAX_CONS][2 * AGX_MAX_NV];
@@ -1155,8 +1155,8 @@ AGX_UNROLL_NV
     }
   }
 }
-// constraint kinds whose components are scalar rows with dense gradients in q (Jacobian slots)
-AGX_HD bool cons_dense_q(int kind) {
+// constraint kinds whose components are scalar rows with dense Jacobians [Gq | Gv | Gu] (Jacobian slots)
+AGX_HD bool cons_has_dense_rows(int kind) {
   return kind == AGX_RES_COLLISION || kind == AGX_RES_FRAME_TRANSLATION || kind == AGX_RES_FRAME_ROTATION || kind == AGX_RES_FRAME_PLACEMENT ||
          kind == AGX_RES_FRAME_VELOCITY || kind == AGX_RES_CONTROL_GRAV;
 }
