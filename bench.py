@@ -41,8 +41,9 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=1024, help="MPC instances per GPU")
-    ap.add_argument("--horizon", type=int, default=100)
+    ap.add_argument("--batch", type=int, default=None, help="MPC instances per GPU (default: the BASELINE.json shape of the workload: "
+                                                            "1024; collision / cartesian 256; humanoid 512)")
+    ap.add_argument("--horizon", type=int, default=None, help="default: 100; collision / cartesian 200; humanoid 50")
     ap.add_argument("--max-iter", type=int, default=10, help="SQP iteration cap (ROS default 10)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-batch1", action="store_true", help="skip the batch = 1 latency leg (profiling runs)")
@@ -54,7 +55,13 @@ def parse():
                     help="sine: BASELINE configs[1] (the headline); generic: configs[3] generic_trajectory + pick-and-place costs; "
                          "humanoid: configs[4] synthetic 30-DoF tree (use --horizon 50 --batch 512); "
                          "collision: configs[2] shape, collision-avoidance cost + distance constraint (use --horizon 200 --batch 256)")
-    return ap.parse_args()
+    args = ap.parse_args()
+    shape = {"collision": (256, 200), "cartesian": (256, 200), "humanoid": (512, 50)}.get(args.workload, (1024, 100))
+    if args.batch is None:
+        args.batch = shape[0]
+    if args.horizon is None:
+        args.horizon = shape[1]
+    return args
 
 
 def algo_doubles(nv):
