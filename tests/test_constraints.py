@@ -318,14 +318,10 @@ def test_hip_velocity_and_gravity_torque_constraints_match_the_checker(which):
     hb.close()
 
 
-@pytest.mark.gpu
-def test_hip_breakdown_of_the_factorisation_is_handled_like_the_checker():
-    """An instance of the collision workload whose reference ends inside the obstacle: the QuadExp cost
-    has negative curvature there, Quu loses positive definiteness, the direction is discarded (flags
-    bit 0), the step rejected (bit 1), the regularisation raised -- and after enough iterations the
-    solve proceeds.  HIP (sign of the reciprocal pivots) and checker (LLT failure) must walk the same path."""
+def _obstacle_entering_problem():
+    """Two instances of the collision workload of bench.py (T = 200): the reference of the first one ends
+    inside the obstacle (instance 14 of the benchmark batch), the second one is a regular instance."""
     import bench
-    from agimus_controller_amd import backend
 
     T, dt = 200, 0.01
     table, tcp, po = bench.make_problem(T, "collision")
@@ -366,6 +362,32 @@ def test_hip_breakdown_of_the_factorisation_is_handled_like_the_checker():
     x0 = xs[:, 0].copy()
     dist = np.array([o.node_constraints(False, xs[0, t], us[0, t])[0][0] for t in range(T)])
     assert dist.min() < 0.0 < dist[0]  # the reference of the first instance really enters the obstacle
+    return table, po, ref, x0, xs, us, B
+
+
+def test_checker_discards_the_direction_when_quu_is_not_positive_definite():
+    """the CPU checker on the case above: LLT failure -> direction discarded (flags bit 0), step rejected
+    (bit 1), regularisation x10 per iteration; the multipliers stay finite and the solve gets going
+    again once the regularisation is large enough."""
+    table, po, ref, x0, xs, us, B = _obstacle_entering_problem()
+    o = _oracle(table, po, B)
+    xs2, us2, K2, st2 = o.solve(ref, None, x0, xs, us, 2)
+    assert st2["flags"][0] == 3 and st2["qp_iters"][0] == 1 and np.array_equal(xs2[0], xs[0])
+    assert st2["flags"][1] == 0 and st2["solved"][1] == 1
+    xs10, us10, K10, st10 = _oracle(table, po, B).solve(ref, None, x0, xs, us, 10)
+    assert st10["qp_iters"][0] > 1 and not np.array_equal(xs10[0], xs[0])
+    assert np.all(np.isfinite(xs10)) and np.all(np.isfinite(us10))
+
+
+@pytest.mark.gpu
+def test_hip_breakdown_of_the_factorisation_is_handled_like_the_checker():
+    """The QuadExp cost has negative curvature near the obstacle: Quu loses positive definiteness, the
+    direction is discarded (flags bit 0), the step rejected (bit 1), the regularisation raised -- and
+    after enough iterations the solve proceeds.  HIP (sign of the reciprocal pivots) and checker (LLT
+    failure) must walk the same path."""
+    from agimus_controller_amd import backend
+
+    table, po, ref, x0, xs, us, B = _obstacle_entering_problem()
     for iters in (2, 10):
         r_o = _oracle(table, po, B).solve(ref, None, x0, xs, us, iters)
         hb = backend.HipOcp(table, po, B)
