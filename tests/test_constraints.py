@@ -159,6 +159,27 @@ def test_yaml_constraints_lower_to_rows():
 
 
 @pytest.mark.gpu
+def test_hip_constraints_with_the_filter_line_search():
+    """use_filter_line_search (ocp_param_base.py:64) together with constraints: the filter compares cost,
+    gaps and constraint violation of the trial point (k_step<FILTER, CON>)."""
+    from agimus_controller_amd import backend
+
+    lim = np.full(7, 15.0)
+    table, po0, ref, x0, xs, us = _control_limit_problem(lim, T=12, B=3, max_qp=100)
+    po = _abi.PackedOcp(7, [0.01] * 12, po0.running, po0.terminal, max_qp_iters=100, running_constraints=po0.running_constraints,
+                        use_filter_line_search=True)
+    o = _oracle(table, po, 3)
+    hb = backend.HipOcp(table, po, 3)
+    hb.set_refs(ref)
+    r_o = o.solve(ref, None, x0, xs, us, 12)
+    r_h = hb.solve(x0, xs, us, 12)
+    assert np.array_equal(r_h[3]["iter"], r_o[3]["iter"]) and np.array_equal(r_h[3]["solved"], r_o[3]["solved"])
+    np.testing.assert_allclose(r_h[0], r_o[0], rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(r_h[1], r_o[1], rtol=1e-5, atol=1e-5)
+    hb.close()
+
+
+@pytest.mark.gpu
 def test_hip_control_limits_match_the_checker():
     from agimus_controller_amd import backend
 
