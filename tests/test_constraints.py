@@ -210,10 +210,11 @@ def test_hip_control_limits_match_the_checker():
 
 
 @pytest.mark.gpu
-def test_hip_collision_constraint_matches_the_checker():
+@pytest.mark.parametrize("box", [None, (0.1, 0.15, 0.08)])
+def test_hip_collision_constraint_matches_the_checker(box):
     from agimus_controller_amd import backend
 
-    table = rt.panda_collision_table(0.1, obstacle_xyz=(0.45, 0.1, 0.45), obstacle_radius=0.08, obstacle_length=0.3)
+    table = rt.panda_collision_table(0.1, obstacle_xyz=(0.45, 0.1, 0.45), obstacle_radius=0.08, obstacle_length=0.3, obstacle_box=box)
     tcp = table.frame_id("panda_hand_tcp")
     T, B = 10, 3
     running, terminal = workloads.collision_avoidance_rows(table, tcp, alpha=0.05)
