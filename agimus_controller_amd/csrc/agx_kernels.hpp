@@ -974,6 +974,7 @@ __global__ void __launch_bounds__(128) k_step(const DevModel *__restrict__ mp, c
     double kk = 0.0, cc = 0.0, gg = 0.0, vv = 0.0;
     for (int w = 0; w < nw; ++w) { kk = fmax(kk, red[w]); cc += red[2 + w]; gg += red[4 + w]; vv += red[8 + w]; }
     kk = fmax(kk, vv);  // checkKKTConditions: KKT = max(KKT, constraint_norm)
+    if (S.dir_fail) kk = __builtin_nan("");  // discarded direction: its KKT residual is undefined (never "converged")
     S.kkt = kk; S.cost = cc; S.gap = gg; S.con = vv; S.merit = cc + o.mu_dyn * gg + o.mu_con * vv;
     S.qp_iters = o.has_con ? S.admm_iter : 1;
     S.admm_conv = 0;  // the next SQP iteration's plain LQR pass runs for this instance again

@@ -1360,6 +1360,7 @@ void solve_one(const Model &m, const Ocp &o, const double *ref, const int32_t *f
       ok = direction(nv, T, w.tiles.data(), w.dir, 0.0, preg, dreg);
     }
     have_dir = true;
+    if (!ok) w.dir.kkt = std::nan("");  // discarded direction: its KKT residual is undefined (never "converged")
     st->kkt = w.dir.kkt; st->cost = cost; st->merit = merit; st->gap_norm = gap1; st->qp_iters = has_con ? admm->qp_iters : 1;
     if (!ok) st->flags |= 1;
     if (w.dir.kkt <= o.tol) { st->solved = 1; break; }

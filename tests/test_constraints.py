@@ -395,6 +395,7 @@ def test_checker_discards_the_direction_when_quu_is_not_positive_definite():
     o = _oracle(table, po, B)
     xs2, us2, K2, st2 = o.solve(ref, None, x0, xs, us, 2)
     assert st2["flags"][0] == 3 and st2["qp_iters"][0] == 1 and np.array_equal(xs2[0], xs[0])
+    assert np.isnan(st2["kkt"][0])  # no KKT residual for a discarded direction
     assert st2["flags"][1] == 0 and st2["solved"][1] == 1
     xs10, us10, K10, st10 = _oracle(table, po, B).solve(ref, None, x0, xs, us, 10)
     assert st10["qp_iters"][0] > 1 and not np.array_equal(xs10[0], xs[0])
@@ -418,6 +419,7 @@ def test_hip_breakdown_of_the_factorisation_is_handled_like_the_checker():
         hb.close()
         assert np.array_equal(r_h[3]["iter"], r_o[3]["iter"]) and np.array_equal(r_h[3]["qp_iters"], r_o[3]["qp_iters"])
         assert np.array_equal(r_h[3]["flags"], r_o[3]["flags"])
+        np.testing.assert_allclose(r_h[3]["kkt"], r_o[3]["kkt"], rtol=1e-5, atol=1e-8, equal_nan=True)
         np.testing.assert_allclose(r_h[0], r_o[0], rtol=1e-6, atol=1e-7)
         np.testing.assert_allclose(r_h[1], r_o[1], rtol=1e-5, atol=1e-5)
         if iters == 2:
