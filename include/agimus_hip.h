@@ -63,7 +63,8 @@ typedef struct agx_cost_row {
   int32_t activation; /* agx_activation_kind                                    */
   int32_t active;     /* CostModelSumItem.active                                */
   int32_t frame;      /* default frame id (may be overridden per node); collision: first geometry frame */
-  int32_t frame_b;    /* collision: second geometry frame of the pair (:499-533) */
+  int32_t frame_b;    /* collision: second geometry frame of the pair (:499-533);
+                         FrameVelocity: reference frame 0 WORLD / 1 LOCAL / 2 LOCAL_WORLD_ALIGNED (:360-432) */
   int32_t pad_;
   double alpha;       /* Exp / QuadExp parameter                                */
   double weight;      /* CostModelSumItem.weight of the YAML: the item weight the device-resident
@@ -84,7 +85,7 @@ typedef struct agx_constraint_row {
   int32_t kind;        /* agx_residual_kind                                     */
   int32_t active;      /* ConstraintListItem.active                             */
   int32_t frame;
-  int32_t frame_b;
+  int32_t frame_b;     /* as in agx_cost_row                                    */
   const double *ref;   /* [agx_row_nref(kind)] or NULL = zeros                  */
   const double *lower; /* [agx_row_nr(kind)], -inf allowed                      */
   const double *upper; /* [agx_row_nr(kind)], +inf allowed                      */
