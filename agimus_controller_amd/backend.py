@@ -16,12 +16,6 @@ import numpy as np
 
 from . import _abi
 
-# Note for large models (nv > 8): their kernels keep per-lane arrays in scratch (tens of KB per lane).
-# By default the HSA runtime hands such scratch out per dispatch and reclaims it afterwards (tens of ms
-# each time); exporting HSA_NO_SCRATCH_RECLAIM=1 before the process touches the GPU keeps it allocated
-# (bench.py --workload humanoid does).  It is NOT set here: mixing small and large models in one
-# process with it made the runtime abort (seen in the test suite).
-
 _CSRC = pathlib.Path(__file__).resolve().parent / "csrc"
 LIB_PATH = pathlib.Path(os.environ.get("AGX_LIB", _CSRC / "libagimus_hip.so"))  # AGX_LIB: development override
 _LIB = None
@@ -35,7 +29,7 @@ EXPORTED_SYMBOLS = [
     "agx_ocp_shift_warmstart", "agx_ocp_x0_from_prediction", "agx_ocp_integrate", "agx_model_rnea",
     "agx_model_frame_placement", "agx_ocp_get_residuals", "agx_ocp_calc_diff", "agx_ocp_direction",
     "agx_ocp_time_kernel", "agx_ocp_profile", "agx_traj_sine_create", "agx_traj_set_window",
-    "agx_traj_get_point", "agx_traj_warmstart_from_reference", "agx_ocp_mpc_step",
+    "agx_traj_get_point", "agx_traj_warmstart_from_reference", "agx_ocp_mpc_step", "agx_ocp_qp_tiles",
 ]  # fmt: skip
 
 
@@ -297,6 +291,27 @@ class HipOcp:
         tiles = np.empty((self.B, self.T + 1, self.tile)) if want_tiles else None
         _chk(lib().agx_ocp_calc_diff(self._h, _p(tiles)))
         return tiles
+
+    def qp_tiles(self):
+        """QP tile and aux tile of every node at the resident point: dicts of blocks (see agx_ocp_qp_tiles)."""
+        qs, as_ = C.c_int(0), C.c_int(0)
+        _chk(lib().agx_ocp_qp_tiles(self._h, None, None, C.byref(qs), C.byref(as_)))
+        qt = np.empty((self.B, self.T + 1, qs.value))
+        aux = np.empty((self.B, self.T + 1, as_.value))
+        _chk(lib().agx_ocp_qp_tiles(self._h, _p(qt), _p(aux), C.byref(qs), C.byref(as_)))
+        nv, ld = self.nv, (8 if self.nv <= 8 else 32)
+        b2 = nv * ld
+        blk = lambda a, off: a[..., off:off + b2].reshape(self.B, self.T + 1, nv, ld)[..., :nv]  # noqa: E731
+        q = {name: blk(qt, k * b2) for k, name in enumerate(("Hqq", "Hqv", "Hvv", "Hqw", "Hvw", "Hww"))}
+        o = 6 * b2
+        q["gx"] = qt[..., o:o + 2 * nv]
+        q["gw"] = qt[..., o + 2 * ld:o + 2 * ld + nv]
+        q["f"] = qt[..., o + 3 * ld:o + 3 * ld + 2 * nv]
+        q["cost"] = qt[..., o + 5 * ld]
+        a = {name: blk(aux, k * b2) for k, name in enumerate(("M", "tq", "tv", "Lqq"))}
+        o = 4 * b2
+        a["Lvv"], a["Luu"], a["Lu"] = aux[..., o:o + nv], aux[..., o + ld:o + ld + nv], aux[..., o + 2 * ld:o + 2 * ld + nv]
+        return q, a
 
     def direction(self):
         K = np.empty((self.B, self.T, self.nu, self.nx))

@@ -54,7 +54,8 @@ struct agx_ocp {
   // multipliers y (persistent across solves), slack z, prox centre, per-node residual norms
   bool has_con = false;
   double *d_trial = nullptr;  // [B][T+1] merit shares of a line-search trial (large models)
-  double *d_jt = nullptr;     // large models: frame rows parked for the cooperative J'WJ, [B*T][1 + 2 (6 + 6 nv)]
+  std::vector<int> shift_nodes;  // large models: nodes with dt_i != dt_0 (integrated by the warm-start shift)
+  int *d_shift_nodes = nullptr;
   bool general = false;       // ControlGrav / FrameVelocity cost rows: one-lane GEN kernels (agx_general.hpp)
   double *d_auxg = nullptr;   // [B][T+1][3 nv 8]: Lqv | Lvvd | Lqu of every node (general problems)
   double *d_qt2 = nullptr, *d_cg = nullptr, *d_cjac = nullptr, *d_y = nullptr, *d_z = nullptr, *d_cx = nullptr, *d_admmstat = nullptr,
@@ -71,9 +72,12 @@ struct agx_ocp {
   bool frames_set = false;
   DevState *d_state = nullptr;
   int *d_ndone = nullptr;
-  int *h_ndone = nullptr;  // pinned; [0] finished-instance count, [1] its sequence stamp, [2] stamp of the packed results
-  int *h_ndone_dev = nullptr;  // the same words as the device sees them (mapped host memory)
-  int seq = 0;
+  // pinned, fine-grained (coherent) mapped host words, 64 bit each: [0] finished-instance count, [1] its sequence
+  // stamp, [2] stamp of the packed results, [3] scratch value, [4] ADMM converged count, [5] its stamp.
+  // Stamps are 64-bit and only ever grow (no wrap in practice); slots start at ~0, which no stamp takes.
+  unsigned long long *h_ndone = nullptr;
+  unsigned long long *h_ndone_dev = nullptr;  // the same words as the device sees them (mapped host memory)
+  unsigned long long seq = 0;
   bool poll = true;  // AGX_HOST_POLL=0: stream-ordered copies + synchronize instead of polled mapped words
   double *d_first = nullptr, *h_first = nullptr;  // packed first-node results [B][first_stride], device / pinned host
   int first_stride = 0;
@@ -273,22 +277,15 @@ int launch_calc_qp(agx_ocp *o, bool running_only = false, bool term_only = false
         hipLaunchKernelGGL((agx::k_calc_qp_lj<NV, true>), dim3((int)(((long long)o->B * 8 + 63) / 64)), dim3(64), 0, o->stream,
                            o->d_model, o->d_ocp, o->d_dt, o->d_xs, o->d_us, o->rv, o->d_qt, o->d_aux, o->d_state);
     }
-    if constexpr (NV > 8) if (!lanes && !term_only && !running_only) {
-      // large models: both node types in one launch of the one-lane kernel, then the cooperative transformation
-      const long long all = units + o->B;
-      hipLaunchKernelGGL((agx::k_calc_qp_all<NV, CH>), dim3((int)((all + 63) / 64)), dim3(64), 0, o->stream, o->d_model, o->d_ocp, o->d_dt,
-                         o->d_xs, o->d_us, o->rv, o->d_qt, o->d_aux, o->d_state, o->d_jt);
-      hipLaunchKernelGGL((agx::k_transform_big<NV>), dim3((int)units), dim3(256), 0, o->stream, o->d_ocp, o->d_qt, o->d_aux, o->d_state, o->d_jt);
-      HIPCHK(hipGetLastError());
-      return 0;
-    }
-    if (!lanes) {
-      if (!term_only) {
+    if constexpr (NV > 8) {
+      // large models: one workgroup per node, running and terminal nodes in one launch (agx_big_k1.hpp)
+      (void)lanes; (void)term_only; (void)running_only;
+      hipLaunchKernelGGL((agx::k_calc_qp_wg<NV>), dim3((int)(units + o->B)), dim3(256), 0, o->stream, o->d_model, o->d_ocp, o->d_dt, o->d_xs,
+                         o->d_us, o->rv, o->d_qt, o->d_aux, o->d_state);
+    } else if (!lanes) {
+      if (!term_only)
         hipLaunchKernelGGL((agx::k_calc_qp<NV, CH>), dim3((int)((units + 63) / 64)), dim3(64), 0, o->stream, o->d_model, o->d_ocp,
                            o->d_dt, o->d_xs, o->d_us, o->rv, o->d_qt, o->d_aux, o->d_state);
-        if constexpr (NV > 8)  // second half for large models: the O(nv^3) transformation, one workgroup per node
-          hipLaunchKernelGGL((agx::k_transform_big<NV>), dim3((int)units), dim3(256), 0, o->stream, o->d_ocp, o->d_qt, o->d_aux, o->d_state, (const double *)nullptr);
-      }
       if (!running_only)
         hipLaunchKernelGGL((agx::k_calc_qp_term<NV, CH>), dim3((o->B + 63) / 64), dim3(64), 0, o->stream, o->d_model, o->d_ocp,
                            o->d_xs, o->rv, o->d_qt, o->d_aux, o->d_state);
@@ -363,7 +360,7 @@ int launch_step(agx_ocp *o, int iter, int max_iter, int mode, bool with_node_kkt
       if (split) {
         double alpha = 1.0;
         for (int n = 0; n < 10; ++n, alpha *= 0.5) {
-          hipLaunchKernelGGL((agx::k_ls_trial<NV, CH>), dim3((int)((nodes + 63) / 64)), dim3(64), 0, o->stream, o->d_model, o->d_ocp, o->d_dt,
+          hipLaunchKernelGGL((agx::k_ls_trial_wg<NV>), dim3((int)nodes), dim3(256), 0, o->stream, o->d_model, o->d_ocp, o->d_dt,
                              o->d_xs, o->d_us, o->rv, o->d_dx, o->d_du, o->d_trial, o->d_state, alpha);
           hipLaunchKernelGGL((agx::k_ls_accept<NV>), dim3(o->B), dim3(128), 0, o->stream, o->d_ocp, o->d_xs, o->d_us, o->d_dx, o->d_du,
                              o->d_trial, o->d_state, alpha, n == 9 ? 1 : 0, iter, max_iter, o->d_ndone);
@@ -438,13 +435,13 @@ int prof_collect(agx_ocp *o) {
 
 // Hand-off of one word from the stream to the host without a copy or a synchronize: a one-thread
 // kernel stores value and sequence stamp into mapped pinned memory, the host spins on the stamp.
-int publish(agx_ocp *o, int slot_value, int slot_seq, const int *d_value, int seq) {
+int publish(agx_ocp *o, int slot_value, int slot_seq, const int *d_value, unsigned long long seq) {
   hipLaunchKernelGGL(agx::k_publish, dim3(1), dim3(1), 0, o->stream, d_value, o->h_ndone_dev + slot_value, o->h_ndone_dev + slot_seq, seq);
   HIPCHK(hipGetLastError());
   return 0;
 }
-int wait_stamp(agx_ocp *o, int slot_seq, int seq) {
-  volatile int *w = o->h_ndone + slot_seq;
+int wait_stamp(agx_ocp *o, int slot_seq, unsigned long long seq) {
+  volatile unsigned long long *w = o->h_ndone + slot_seq;
   const auto t_begin = std::chrono::steady_clock::now();
   for (unsigned long spins = 1;; ++spins) {
     if (__atomic_load_n(w, __ATOMIC_ACQUIRE) == seq) return 0;
@@ -464,15 +461,16 @@ int wait_stamp(agx_ocp *o, int slot_seq, int seq) {
 
 // stream-ordered read of one device int (polled stamp or copy + synchronize)
 int read_int(agx_ocp *o, const int *d_value, int slot_value, int slot_seq, int *out) {
-  const int seq = ++o->seq;
+  const unsigned long long seq = ++o->seq;
   if (o->poll) {
     if (publish(o, slot_value, slot_seq, d_value, seq)) return -1;
     if (wait_stamp(o, slot_seq, seq)) return -1;
   } else {
+    o->h_ndone[slot_value] = 0;  // the 4-byte copy below fills the low half (little endian)
     HIPCHK(hipMemcpyAsync(o->h_ndone + slot_value, d_value, sizeof(int), hipMemcpyDeviceToHost, o->stream));
     HIPCHK(hipStreamSynchronize(o->stream));
   }
-  *out = __atomic_load_n(o->h_ndone + slot_value, __ATOMIC_ACQUIRE);
+  *out = (int)__atomic_load_n(o->h_ndone + slot_value, __ATOMIC_ACQUIRE);
   return 0;
 }
 
@@ -564,10 +562,11 @@ int solve_resident(agx_ocp *o, int max_iter, double max_time, bool prologue_done
     if (prof_mark(o, 2, false)) return -1;
     if (it + 1 == max_iter) { need_fixup = need_fixup || !pair; break; }
     // early exit once every instance has finished (one 4-byte read back)
-    const int seq = ++o->seq;
+    const unsigned long long seq = ++o->seq;
     if (o->poll) {
       if (publish(o, 0, 1, o->d_ndone, seq)) return -1;
     } else {
+      o->h_ndone[0] = 0;
       HIPCHK(hipMemcpyAsync(o->h_ndone, o->d_ndone, sizeof(int), hipMemcpyDeviceToHost, o->stream));
       HIPCHK(hipEventRecord(o->ev_done, o->stream));
     }
@@ -578,7 +577,7 @@ int solve_resident(agx_ocp *o, int max_iter, double max_time, bool prologue_done
     // waits for the finished count only, not for the pass queued behind it
     if (o->poll) { if (wait_stamp(o, 1, seq)) return -1; }
     else HIPCHK(hipEventSynchronize(o->ev_done));
-    const int n_done = __atomic_load_n(o->h_ndone, __ATOMIC_ACQUIRE);
+    const int n_done = (int)__atomic_load_n(o->h_ndone, __ATOMIC_ACQUIRE);
     if (!pair && n_done > prev_done) need_fixup = true;
     prev_done = n_done;
     if (n_done >= o->B) break;
@@ -651,6 +650,8 @@ int agx_model_create(const agx_model_desc *d, agx_model **out) {
     if (d->parent[i] >= i || d->parent[i] < -1) { delete m; return fail("agx_model_create: parents must precede children"); }
     if (d->parent[i] != i - 1) h.is_chain = 0;
     h.anc[i] = (1u << i) | (d->parent[i] >= 0 ? h.anc[d->parent[i]] : 0u);
+    for (int j = 0; j <= i; ++j)
+      if ((h.anc[i] >> j) & 1u) h.desc[j] |= (1u << i);
     std::memcpy(h.placement[i], d->placement + 12 * i, sizeof(double) * 12);
     std::memcpy(h.axis[i], d->axis + 3 * i, sizeof(double) * 3);
     h.mass[i] = d->mass[i];
@@ -764,6 +765,18 @@ int agx_ocp_create(const agx_model *m, const agx_ocp_desc *d, int batch, int dev
     o->lanes_ok = o->stride <= agx::kLjRef && n_frame_rows(o->ho.rows[0]) <= 2 && n_frame_rows(o->ho.rows[1]) <= 2 &&
                   n_collision_rows(o->ho.rows[0]) + n_collision_rows(o->ho.rows[1]) == 0 && !o->general;
   }
+  if (o->nv > 8) {
+    // the workgroup-per-node kernels stage the reference tile and the dense residual rows of a node in LDS
+    auto n_dense = [](const DevRows &r) {
+      int n = 0;
+      for (int i = 0; i < r.n; ++i)
+        if (r.active[i])
+          n += r.kind[i] == AGX_RES_FRAME_PLACEMENT ? 6 : ((r.kind[i] == AGX_RES_FRAME_TRANSLATION || r.kind[i] == AGX_RES_FRAME_ROTATION) ? 3 : (r.kind[i] == AGX_RES_COLLISION ? 1 : 0));
+      return n;
+    };
+    if (o->stride > agx::kWgRef) { delete o; return fail("agx_ocp_create: reference tile of " + std::to_string(o->stride) + " doubles per node exceeds the large-model limit of " + std::to_string(agx::kWgRef)); }
+    if (n_dense(o->ho.rows[0]) > agx::kWgJ || n_dense(o->ho.rows[1]) > agx::kWgJ) { delete o; return fail("agx_ocp_create: more than 16 frame / collision residual components per node (large models)"); }
+  }
   // probe that a kernel instantiation exists
   if (dispatch(o->nv, o->chain, [](auto, auto) -> int { return 0; })) { delete o; return -1; }
   if (set_device(o)) { delete o; return -1; }
@@ -793,7 +806,14 @@ int agx_ocp_create(const agx_model *m, const agx_ocp_desc *d, int batch, int dev
   ALLOC(o->d_frames, B * (T + 1) * AGX_MAX_ROWS);
   ALLOC(o->d_state, B);
   ALLOC(o->d_ndone, 2);  // [0] finished instances, [1] instances whose ADMM loop has ended
-  if (o->nv > 8) ALLOC(o->d_jt, B * T * (size_t)(1 + 2 * (6 + 6 * o->nv)));
+  if (o->nv > 8) {
+    for (int t = 0; t < o->T; ++t)
+      if (o->dt[t] != o->dt[0]) o->shift_nodes.push_back(t);
+    if (!o->shift_nodes.empty()) {
+      ALLOC(o->d_shift_nodes, o->shift_nodes.size());
+      (void)hipMemcpy(o->d_shift_nodes, o->shift_nodes.data(), sizeof(int) * o->shift_nodes.size(), hipMemcpyHostToDevice);
+    }
+  }
   if (o->general) ALLOC(o->d_auxg, B * (T + 1) * (size_t)(3 * o->nv * 8));
   if (o->has_con) {
     ALLOC(o->d_qt2, B * (T + 1) * (size_t)o->qt_size);
@@ -806,9 +826,15 @@ int agx_ocp_create(const agx_model *m, const agx_ocp_desc *d, int batch, int dev
     ALLOC(o->d_fac, B * T * 192);
   }
 #undef ALLOC
-  if (hipHostMalloc((void **)&o->h_ndone, 8 * sizeof(int), hipHostMallocMapped) != hipSuccess) { agx_ocp_destroy(o); return fail("hipHostMalloc failed"); }
-  std::memset(o->h_ndone, 0, 8 * sizeof(int));
-  if (hipHostGetDevicePointer((void **)&o->h_ndone_dev, o->h_ndone, 0) != hipSuccess) o->poll = false;
+  // the polled hand-off needs FINE-GRAINED host memory (the stamp must not overtake the data it guards): ask for it
+  // explicitly; when the runtime cannot give it, fall back to stream-ordered copies + synchronize
+  if (hipHostMalloc((void **)&o->h_ndone, 8 * sizeof(unsigned long long), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) {
+    (void)hipGetLastError();
+    o->poll = false;
+    if (hipHostMalloc((void **)&o->h_ndone, 8 * sizeof(unsigned long long), hipHostMallocDefault) != hipSuccess) { agx_ocp_destroy(o); return fail("hipHostMalloc failed"); }
+  }
+  std::memset(o->h_ndone, 0xff, 8 * sizeof(unsigned long long));
+  if (o->poll && hipHostGetDevicePointer((void **)&o->h_ndone_dev, o->h_ndone, 0) != hipSuccess) o->poll = false;
   if (const char *e = getenv("AGX_HOST_POLL")) o->poll = o->poll && (e[0] != '0');
   if (hipMemcpy(o->d_model, &o->hm, sizeof(DevModel), hipMemcpyHostToDevice) != hipSuccess ||
       hipMemcpy(o->d_ocp, &o->ho, sizeof(DevOcp), hipMemcpyHostToDevice) != hipSuccess ||
@@ -837,7 +863,7 @@ void agx_ocp_destroy(agx_ocp *o) {
   if (o->stream) (void)hipStreamSynchronize(o->stream);
   void *ptrs[] = {o->d_model, o->d_ocp, o->d_dt, o->d_xs, o->d_us, o->d_x0, o->d_tiles, o->d_Kws, o->d_kws, o->d_Kout, o->d_dx,
                   o->d_du, o->d_ref, o->d_frames, o->d_state, o->d_ndone, o->d_scratch, o->d_traj, o->d_pts, o->d_sine, o->d_qt, o->d_aux, o->d_w, o->d_nodestat,
-                  o->d_qt2, o->d_cg, o->d_cjac, o->d_y, o->d_z, o->d_cx, o->d_admmstat, o->d_fac, o->d_hidx, o->d_trial, o->d_auxg, o->d_jt};
+                  o->d_qt2, o->d_cg, o->d_cjac, o->d_y, o->d_z, o->d_cx, o->d_admmstat, o->d_fac, o->d_hidx, o->d_trial, o->d_auxg, o->d_shift_nodes};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
   if (o->h_ndone) (void)hipHostFree(o->h_ndone);
@@ -981,7 +1007,11 @@ int agx_ocp_first_packed(agx_ocp *o, const double **host, int *stride) {
   if (set_device(o)) return -1;
   const int FS = o->nu + o->nu * o->nx + o->nx + 8;
   if (!o->h_first) {
-    HIPCHK(hipHostMalloc((void **)&o->h_first, sizeof(double) * (size_t)o->B * FS, hipHostMallocMapped));
+    if (o->poll && hipHostMalloc((void **)&o->h_first, sizeof(double) * (size_t)o->B * FS, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) {
+      (void)hipGetLastError();
+      o->poll = false;  // no fine-grained mapped memory: copy + synchronize from here on
+    }
+    if (!o->poll) HIPCHK(hipHostMalloc((void **)&o->h_first, sizeof(double) * (size_t)o->B * FS, hipHostMallocDefault));
     if (o->poll) {
       HIPCHK(hipHostGetDevicePointer((void **)&o->d_first, o->h_first, 0));  // the pack kernel writes host memory directly
     } else {
@@ -994,7 +1024,7 @@ int agx_ocp_first_packed(agx_ocp *o, const double **host, int *stride) {
                      o->d_first, o->B, o->T, o->nx, o->nu, o->last_max_iter);
   HIPCHK(hipGetLastError());
   if (o->poll) {
-    const int seq = ++o->seq;
+    const unsigned long long seq = ++o->seq;
     if (publish(o, 3, 2, o->d_ndone, seq)) return -1;
     if (wait_stamp(o, 2, seq)) return -1;
   } else {
@@ -1041,8 +1071,16 @@ int agx_ocp_shift_warmstart(agx_ocp *o) {
     constexpr int NV = decltype(NVc)::value;
     constexpr bool CH = decltype(CHc)::value;
     const long long units = (long long)o->B * o->T;
-    hipLaunchKernelGGL((agx::k_shift<NV, CH>), dim3((int)((units + 63) / 64)), dim3(64), 0, o->stream, o->d_model, o->d_ocp, o->d_dt, o->d_xs, o->d_us);
     const long long n = (long long)o->B * (o->T + 1) * o->nx;
+    if constexpr (NV > 8) {
+      // large models: plain copies for the nodes with dt_i == dt_0, one workgroup per node that has to be integrated
+      (void)units;
+      hipLaunchKernelGGL(agx::k_shift_copy, dim3((int)((n + 255) / 256)), dim3(256), 0, o->stream, o->d_dt, o->d_xs, o->d_us, o->B, o->T, o->nx, o->nu);
+      if (!o->shift_nodes.empty())
+        hipLaunchKernelGGL((agx::k_integrate_wg<NV>), dim3(o->B * (int)o->shift_nodes.size()), dim3(256), 0, o->stream, o->d_model, o->dt[0], o->d_xs,
+                           o->d_us, o->d_xs + n, o->d_shift_nodes, (int)o->shift_nodes.size(), o->T);
+    } else
+    hipLaunchKernelGGL((agx::k_shift<NV, CH>), dim3((int)((units + 63) / 64)), dim3(64), 0, o->stream, o->d_model, o->d_ocp, o->d_dt, o->d_xs, o->d_us);
     hipLaunchKernelGGL(agx::k_shift_commit, dim3((int)((n + 255) / 256)), dim3(256), 0, o->stream, o->d_xs, o->d_us, o->B, o->T, o->nx, o->nu);
     HIPCHK(hipGetLastError());
     return 0;
@@ -1068,7 +1106,10 @@ int agx_ocp_integrate(agx_ocp *o, int n, const double *x, const double *u, doubl
   int rc = dispatch(o->nv, o->chain, [&](auto NVc, auto CHc) -> int {
     constexpr int NV = decltype(NVc)::value;
     constexpr bool CH = decltype(CHc)::value;
-    hipLaunchKernelGGL((agx::k_integrate<NV, CH>), dim3((n + 63) / 64), dim3(64), 0, o->stream, o->d_model, o->dt[0], n, dx, du, dn);
+    if constexpr (NV > 8)
+      hipLaunchKernelGGL((agx::k_integrate_wg<NV>), dim3(n), dim3(256), 0, o->stream, o->d_model, o->dt[0], dx, du, dn, (const int *)nullptr, 0, 0);
+    else
+      hipLaunchKernelGGL((agx::k_integrate<NV, CH>), dim3((n + 63) / 64), dim3(64), 0, o->stream, o->d_model, o->dt[0], n, dx, du, dn);
     HIPCHK(hipGetLastError());
     return 0;
   });
@@ -1191,6 +1232,21 @@ int agx_ocp_direction(agx_ocp *o, double *K, double *k, double *dx, double *du, 
   HIPCHK(hipMemcpyAsync(hs.data(), o->d_state, sizeof(DevState) * B, hipMemcpyDeviceToHost, o->stream));
   HIPCHK(hipStreamSynchronize(o->stream));
   if (kkt) for (size_t b = 0; b < B; ++b) kkt[b] = hs[b].kkt;
+  return 0;
+}
+
+int agx_ocp_qp_tiles(agx_ocp *o, double *qt, double *aux, int *qt_size, int *aux_size) {
+  if (!o) return fail("null handle");
+  if (set_device(o)) return -1;
+  if (qt_size) *qt_size = o->qt_size;
+  if (aux_size) *aux_size = o->aux_size;
+  if (!qt && !aux) return 0;
+  if (reset_state(o)) return -1;
+  if (launch_calc_qp(o)) return -1;
+  const size_t n = (size_t)o->B * (o->T + 1);
+  if (qt) HIPCHK(hipMemcpyAsync(qt, o->d_qt, sizeof(double) * n * o->qt_size, hipMemcpyDeviceToHost, o->stream));
+  if (aux) HIPCHK(hipMemcpyAsync(aux, o->d_aux, sizeof(double) * n * o->aux_size, hipMemcpyDeviceToHost, o->stream));
+  HIPCHK(hipStreamSynchronize(o->stream));
   return 0;
 }
 

@@ -5,80 +5,13 @@
 // matrix (w | q | v blocks + gradient column) and the value function of node t+1 in LDS
 // (nv = 30: 66 KB + 29 KB) and eliminates the nv acceleration variables with nv Gauss-Jordan pivots,
 // two barriers each.  Same tiles (row stride 32), same acceleration-input QP, same outputs as the
-// nv <= 7 path; correctness first -- the derivative pass for these sizes is the one-lane-per-node
-// kernel with per-lane arrays in scratch (agx_kernels.hpp), the next step is an LDS-tiled / fp64-MFMA
-// version of both.
+// nv <= 7 path.  The derivative pass and the line-search trials of these sizes are the
+// workgroup-per-node kernels of agx_big_k1.hpp (LDS + fp64 MFMA, no scratch).
 //
 // (included at the end of agx_kernels.hpp)
 #pragma once
 
 namespace agx {
-
-// Second half of the derivative pass for large models: the node's QP blocks in acceleration-input
-// form from the aux tile (M, taux, cost Hessians) -- one 256-thread workgroup per running node,
-// M | tq | tv staged in LDS, thread (i, j) forms element [i][j] of the six blocks:
-//   Hww = M D M, Hxw = taux' D M, Hxx = Lxx + taux' D taux, gw = M Lu, gx = Lx + taux' Lu,  D = Luu + preg.
-template <int NV>
-__global__ void __launch_bounds__(256) k_transform_big(const DevOcp *__restrict__ op, double *__restrict__ qts,
-                                                       double *__restrict__ auxs, const DevState *__restrict__ st,
-                                                       const double *__restrict__ jtbuf) {
-  typedef QT<NV> Q;
-  typedef AUX<NV> A;
-  constexpr int JS = 6 + 6 * NV;
-  __shared__ double sM[NV * NV], sq[NV * NV], sv[NV * NV], sD[NV], slu[NV], sJ[2 * JS];
-  __shared__ int s_njt;
-  const DevOcp &o = *op;
-  const int T = o.T, tid = threadIdx.x, nt = blockDim.x;
-  const long long unit = blockIdx.x;  // b * T + t
-  const int b = (int)(unit / T), t = (int)(unit % T);
-  const DevState &S = st[b];
-  if (S.done) return;
-  double *qt = qts + ((long long)b * (T + 1) + t) * Q::SIZE;
-  double *ax = auxs + ((long long)b * (T + 1) + t) * A::SIZE;
-  for (int e = tid; e < NV * NV; e += nt) {
-    const int i = e / NV, j = e % NV;
-    sM[e] = ax[A::M + i * A::LD + j]; sq[e] = ax[A::tq + i * A::LD + j]; sv[e] = ax[A::tv + i * A::LD + j];
-  }
-  for (int i = tid; i < NV; i += nt) { sD[i] = ax[A::Luu + i] + S.preg; slu[i] = ax[A::Lu + i]; }
-  // frame rows parked by the one-lane pass: weights (already scaled by the node's dt) | J
-  const double *jt = jtbuf ? jtbuf + unit * (1 + 2 * JS) : nullptr;
-  if (tid == 0) s_njt = jt ? (int)jt[0] : 0;
-  for (int e = tid; e < 2 * JS; e += nt) sJ[e] = jt ? jt[1 + e] : 0.0;
-  __syncthreads();
-  const int njt = s_njt;
-  for (int e = tid; e < NV * NV; e += nt) {
-    const int i = e / NV, j = e % NV;
-    double lqq = ax[A::Lqq + i * A::LD + j];
-    for (int s2 = 0; s2 < njt; ++s2) {
-      const double *wv = sJ + s2 * JS, *Jm = wv + 6;
-      double acc = 0.0;
-#pragma unroll
-      for (int r = 0; r < 6; ++r) acc += wv[r] * Jm[r * NV + i] * Jm[r * NV + j];
-      lqq += acc;
-    }
-    if (njt > 0) ax[A::Lqq + i * A::LD + j] = lqq;  // the complete Lqq: K3 reads it for the KKT shares
-    double hww = 0.0, hqw = 0.0, hvw = 0.0, hqq = lqq, hqv = 0.0, hvv = (i == j) ? ax[A::Lvv + i] : 0.0;
-    for (int l = 0; l < NV; ++l) {
-      const double d = sD[l];
-      const double dm = d * sM[l * NV + j], dtq = d * sq[l * NV + j], dtv = d * sv[l * NV + j];
-      const double Mil = sM[i * NV + l], tqli = sq[l * NV + i], tvli = sv[l * NV + i];
-      hww += Mil * dm; hqw += tqli * dm; hvw += tvli * dm;
-      hqq += tqli * dtq; hqv += tqli * dtv; hvv += tvli * dtv;
-    }
-    const int o2 = i * Q::LD + j;
-    qt[Q::Hww + o2] = hww; qt[Q::Hqw + o2] = hqw; qt[Q::Hvw + o2] = hvw;
-    qt[Q::Hqq + o2] = hqq; qt[Q::Hqv + o2] = hqv; qt[Q::Hvv + o2] = hvv;
-  }
-  for (int i = tid; i < NV; i += nt) {
-    double gw = 0.0, gq = qt[Q::gx + i], gv = qt[Q::gx + NV + i];
-    for (int l = 0; l < NV; ++l) {
-      gw += sM[i * NV + l] * slu[l];
-      gq += sq[l * NV + i] * slu[l];
-      gv += sv[l * NV + i] * slu[l];
-    }
-    qt[Q::gw + i] = gw; qt[Q::gx + i] = gq; qt[Q::gx + NV + i] = gv;
-  }
-}
 
 // K2 for large nv.  gains_pass: backward sweep only, every instance, on the sigma-augmented tiles
 // (k_sigma_tile_big), gradient ignored.
@@ -413,49 +346,11 @@ __global__ void __launch_bounds__(256) k_sigma_tile_big(const DevOcp *__restrict
 }
 
 // ---------------------------------------------------------------------------
-// Line search for large models, split so that the trial evaluation is node parallel (the per-node
-// calc with per-lane scratch arrays is far too slow inside one workgroup per instance):
-//   k_ls_trial(alpha)   one lane per node: merit share of the node at xs + alpha dx, us + alpha du
-//   k_ls_accept(alpha)  one workgroup per instance: merit_try < merit ? commit the step : keep trying
+// Line search for large models, split so that the trial evaluation is node parallel:
+//   k_ls_trial_wg(alpha)  (agx_big_k1.hpp) one workgroup per node: merit share of the node at xs + alpha dx, us + alpha du
+//   k_ls_accept(alpha)    one workgroup per instance: merit_try < merit ? commit the step : keep trying
 // run for alpha = 1, 1/2, ... 2^-9; instances that accepted (or finished) drop out.
 // ---------------------------------------------------------------------------
-template <int NV, bool CHAIN>
-__global__ void __launch_bounds__(64) k_ls_trial(const DevModel *__restrict__ mp, const DevOcp *__restrict__ op,
-                                                 const double *__restrict__ dts, const double *__restrict__ xs,
-                                                 const double *__restrict__ us, RefView rv, const double *__restrict__ dxs,
-                                                 const double *__restrict__ dus, double *__restrict__ trial,
-                                                 const DevState *__restrict__ st, double alpha) {
-  constexpr int NX = 2 * NV, NU = NV;
-  const DevModel &m = *mp;
-  const DevOcp &o = *op;
-  const int T = o.T;
-  const long long node = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (node >= (long long)o.B * (T + 1)) return;
-  const int b = (int)(node / (T + 1)), t = (int)(node % (T + 1));
-  const DevState &S = st[b];
-  if (S.done || S.ls_acc) return;
-  double x[NX], u[NU];
-AGX_UNROLL_NV
-  for (int i = 0; i < NX; ++i) x[i] = xs[node * NX + i] + alpha * dxs[node * NX + i];
-  double part;
-  if (t < T) {
-    const long long un = (long long)b * T + t;
-AGX_UNROLL_NV
-    for (int i = 0; i < NU; ++i) u[i] = us[un * NU + i] + alpha * dus[un * NU + i];
-    double xn[NX], c;
-    node_calc_running<NV, CHAIN>(m, o.rows[0], dts[t], x, u, ref_at(rv, b, t, T), frames_at(rv, b, t, T), xn, &c);
-    double g = 0.0;
-AGX_UNROLL_NV
-    for (int i = 0; i < NX; ++i) g += fabs(xn[i] - (xs[(node + 1) * NX + i] + alpha * dxs[(node + 1) * NX + i]));
-    part = c + o.mu_dyn * g;
-  } else {
-    double c;
-    node_calc_terminal<NV, CHAIN>(m, o.rows[1], x, ref_at(rv, b, T, T), frames_at(rv, b, T, T), &c);
-    part = c;
-  }
-  trial[node] = part;
-}
-
 template <int NV>
 __global__ void __launch_bounds__(128) k_ls_accept(const DevOcp *__restrict__ op, double *__restrict__ xs, double *__restrict__ us,
                                                    const double *__restrict__ dxs, const double *__restrict__ dus,

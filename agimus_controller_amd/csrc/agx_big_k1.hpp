@@ -1,0 +1,729 @@
+// agx_big_k1.hpp -- node evaluation for large models (8 < nv <= 32, trees): ONE WORKGROUP PER NODE.
+//
+// The register-resident kernels (agx_k1_lanes.hpp) give a node 8 lanes; a 30-joint tree does not fit
+// that shape, and one lane per node needs ~58 KB of private arrays per lane (scratch).  Here a node
+// owns a 256-thread workgroup and ~52 KB of LDS, nothing lives in scratch:
+//   * per-joint quantities (placements, S, v, a, inertias, forces) are LDS vectors; recursions along the
+//     tree become masked sums over the ancestor / descendant bit sets of the model (no level
+//     synchronisation: v_i = sum_{j in anc(i)} S_j qd_j, f^C_i = sum_{j in desc(i)} f_j, ...),
+//     one thread per (joint, component);
+//   * all-pairs quantities (CRBA, the RNEA-derivative matrices) are one thread per matrix entry;
+//   * M qdd = u - nle is solved by one wave, a row per lane, Gauss-Jordan with v_readlane broadcasts;
+//   * the dense contractions of the acceleration-input transformation,
+//       [tq tv M]' diag(D) [tq tv M]   (six nv x nv x nv products)   and   J' W J  of the cost rows,
+//     run on the fp64 matrix cores (v_mfma_f64_16x16x4_f64, nv padded to 32: wave w owns output tile
+//     (w >> 1, w & 1) of every block, operands straight from LDS);
+//   * tiles leave as whole 128-byte row segments.
+// Same mathematics as agx_device.hpp (bias_and_inertia, rnea_derivatives, node_costs); same QP / aux
+// tiles as the one-lane kernel it replaces.  k_ls_trial_wg is the value-only variant for the line search.
+//
+// What this stands in for upstream: calc + calcDiff of IntegratedActionModelEuler(
+// DifferentialActionModelFreeFwdDynamics(CostModelSum)), agimus_controller/ocp/ocp_croco_generic.py:688-711,743-745.
+//
+// (included at the end of agx_kernels.hpp)
+#pragma once
+
+namespace agx {
+
+constexpr int kWgRef = 256;  // reference-tile doubles staged per node (agx_ocp_create refuses larger tiles for nv > 8)
+constexpr int kWgJ = 16;     // scalar residual rows with a dense gradient in q per node: FramePlacement 6,
+                             // FrameTranslation / FrameRotation 3, collision 1 (agx_ocp_create checks the total)
+
+typedef double agx_v4d __attribute__((ext_vector_type(4)));
+
+// workgroups (= waves per SIMD) of the derivative pass a CU is asked to hold: 2 leaves the kernel its ~200 VGPRs,
+// 3 (what the 52 KB of LDS allow) caps them at 168 and spills a few values
+#ifndef AGX_WG_MINWAVES
+#define AGX_WG_MINWAVES 2
+#endif
+
+template <int NV>
+struct WgNode {
+  static constexpr int LDM = 32;
+  double M[NV][LDM], tq[NV][LDM], tv[NV][LDM];  // columns >= NV stay zero (MFMA operands)
+  double S[NV][6], Sd[NV][6], v[NV][6], m6[NV][6], h[NV][6];
+  double Ib[NV][10], Ic[NV][10];
+  double x[2 * NV], u[NV], xn[2 * NV];
+  double nle[32], rhs[32], qdd[32], D[32], lu[32], Lq[32], Lv[32], Lvv[32], Luu[32], dqq[32], cpart[32], fq[32], fv[32];
+  union {
+    struct {  // kinematics + cost rows
+      double Rl[NV][12], Rw[NV][9], pw[NV][3], ref[kWgRef], J[kWgJ][LDM], wJ[kWgJ];
+    } c;
+    struct { double a[NV][6], f[NV][6], fc[NV][6]; } d1;  // bias forces
+    struct {                                              // RNEA derivatives
+      double a[NV][6], psi[NV][6];
+      union {
+        double pre[NV][18];  // fC (6) | f0 (3) | E (9) of the body; dead once the subtree sums exist
+        struct { double Dt[NV][3], colv[NV][6], colq[NV][6]; } col;
+      };
+      double cmp[NV][18];  // subtree sums of pre
+    } d3;
+  } w;
+  unsigned anc[32], desc[32];
+  int par[32];
+};
+
+// x = M^-1 rhs for the SPD joint-space inertia, one wave: lane i keeps row i of [M | rhs] in registers,
+// nv Gauss-Jordan pivots, the pivot row travels through v_readlane (no LDS, no barrier).
+template <int NV>
+__device__ __forceinline__ double wave_spd_solve(const double (*M)[32], const double *rhs, int lane) {
+  const int i = lane < NV ? lane : NV - 1;
+  double a[NV + 1];
+#pragma unroll
+  for (int j = 0; j < NV; ++j) a[j] = M[i][j];
+  a[NV] = rhs[i];
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    const double rp = fast_rcp(readlane_f64(a[k], k));
+    const double f = (lane == k) ? 0.0 : a[k] * rp;  // the pivot row itself stays
+#pragma unroll
+    for (int j = k + 1; j <= NV; ++j) a[j] -= f * readlane_f64(a[j], k);
+  }
+  double d = 1.0;
+#pragma unroll
+  for (int j = 0; j < NV; ++j)
+    if (j == i) d = a[j];
+  return a[NV] / d;
+}
+
+template <int NV>
+__device__ __forceinline__ void wg_frame_world(const WgNode<NV> &L, const DevModel &m, int frame, double *R, double *p, int *joint) {
+  const int par = m.frame_parent[frame];
+  *joint = par;
+  const double *fp = m.frame_placement[frame];
+  if (par >= 0) {
+    const double *Rp = L.w.c.Rw[par], *pp = L.w.c.pw[par];
+    mm3(Rp, fp, R);
+    double t[3];
+    mv3(Rp, fp + 9, t);
+    p[0] = pp[0] + t[0]; p[1] = pp[1] + t[1]; p[2] = pp[2] + t[2];
+  } else {
+#pragma unroll
+    for (int e = 0; e < 9; ++e) R[e] = fp[e];
+#pragma unroll
+    for (int e = 0; e < 3; ++e) p[e] = fp[9 + e];
+  }
+}
+
+// one MFMA k-step operand pair from an LDS matrix X[NV][32]:  A[m][k] = X[k][col_a],  B[k][n] = s_k X[k][col_b]
+template <int NV>
+__device__ __forceinline__ double wg_op(const double (*X)[32], int k, int col) { return k < NV ? X[k][col] : 0.0; }
+
+__device__ __forceinline__ void wg_store_tile(double *__restrict__ blk, const agx_v4d &acc, int ti, int tj, int lane, int nv) {
+  const int l15 = lane & 15, l4 = lane >> 4, col = 16 * tj + l15;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int row = 16 * ti + l4 + 4 * r;
+    if (row < nv) blk[row * 32 + col] = acc[r];  // columns nv..31 carry zeros: whole 128-byte segments
+  }
+}
+
+// Inputs of one node evaluation.  LS: the point is (xs + alpha dx, us + alpha du).
+struct WgIn {
+  const double *x, *dx, *u, *du, *xn, *dxn;  // node state / control / successor state (and the direction, may be null)
+  double alpha, dt, preg, mu_dyn;
+  const double *ref;  // the node's reference tile (stride doubles)
+  int stride;
+  const int *frames;
+};
+
+// DIFF = true: QP tile + aux tile (K1).  DIFF = false: returns cost + mu_dyn |gap|_1 on every thread (line search).
+template <int NV, bool TERM, bool DIFF>
+__device__ __forceinline__ double wg_node(WgNode<NV> &L, const DevModel &m, const DevRows &rows, const WgIn &in, double *__restrict__ qt,
+                                          double *__restrict__ ax) {
+  constexpr int NX = 2 * NV, NT = 256, LDM = 32;
+  typedef QT<NV> Q;
+  typedef AUX<NV> A;
+  static_assert(Q::LD == LDM && A::LD == LDM, "tile row stride of large models");
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const double dt = in.dt, sc = TERM ? 1.0 : dt;
+
+  // ---- phase 0: inputs and model index sets into LDS, accumulators cleared
+  for (int e = tid; e < NX; e += NT) {
+    L.x[e] = in.x[e] + (in.dx ? in.alpha * in.dx[e] : 0.0);
+    if (!TERM) L.xn[e] = in.xn[e] + (in.dxn ? in.alpha * in.dxn[e] : 0.0);
+  }
+  if (!TERM)
+    for (int e = tid; e < NV; e += NT) L.u[e] = in.u[e] + (in.du ? in.alpha * in.du[e] : 0.0);
+  for (int e = tid; e < in.stride; e += NT) L.w.c.ref[e] = in.ref[e];
+  if (tid < 32) {
+    L.anc[tid] = tid < NV ? m.anc[tid] : 0u;
+    L.desc[tid] = tid < NV ? m.desc[tid] : 0u;
+    L.par[tid] = tid < NV ? m.parent[tid] : -1;
+    L.nle[tid] = 0.0; L.rhs[tid] = 0.0; L.qdd[tid] = 0.0; L.D[tid] = 0.0; L.lu[tid] = 0.0; L.Lq[tid] = 0.0; L.Lv[tid] = 0.0;
+    L.Lvv[tid] = 0.0; L.Luu[tid] = 0.0; L.dqq[tid] = 0.0; L.cpart[tid] = 0.0; L.fq[tid] = 0.0; L.fv[tid] = 0.0;
+  }
+  if (DIFF) {
+    for (int e = tid; e < NV * LDM; e += NT) { (&L.M[0][0])[e] = 0.0; (&L.tq[0][0])[e] = 0.0; (&L.tv[0][0])[e] = 0.0; }
+    for (int e = tid; e < kWgJ * LDM; e += NT) (&L.w.c.J[0][0])[e] = 0.0;
+    if (tid < kWgJ) L.w.c.wJ[tid] = 0.0;
+  }
+  __syncthreads();
+
+  // ---- kinematics: local placements, then every joint composes its own path to the root
+  if (tid < NV) {
+    const int i = tid;
+    const double *ax3 = m.axis[i];
+    double s, c;
+    sincos(L.x[i], &s, &c);
+    const double omc = 1.0 - c;
+    double Rq[9], Rl[9];
+    Rq[0] = c + omc * ax3[0] * ax3[0];
+    Rq[1] = omc * ax3[0] * ax3[1] - s * ax3[2];
+    Rq[2] = omc * ax3[0] * ax3[2] + s * ax3[1];
+    Rq[3] = omc * ax3[1] * ax3[0] + s * ax3[2];
+    Rq[4] = c + omc * ax3[1] * ax3[1];
+    Rq[5] = omc * ax3[1] * ax3[2] - s * ax3[0];
+    Rq[6] = omc * ax3[2] * ax3[0] - s * ax3[1];
+    Rq[7] = omc * ax3[2] * ax3[1] + s * ax3[0];
+    Rq[8] = c + omc * ax3[2] * ax3[2];
+    mm3(m.placement[i], Rq, Rl);
+#pragma unroll
+    for (int e = 0; e < 9; ++e) L.w.c.Rl[i][e] = Rl[e];
+#pragma unroll
+    for (int e = 0; e < 3; ++e) L.w.c.Rl[i][9 + e] = m.placement[i][9 + e];
+  }
+  __syncthreads();
+  if (tid < NV) {
+    const int i = tid;
+    double R[9], p[3];
+#pragma unroll
+    for (int e = 0; e < 9; ++e) R[e] = L.w.c.Rl[i][e];
+#pragma unroll
+    for (int e = 0; e < 3; ++e) p[e] = L.w.c.Rl[i][9 + e];
+    for (int j = L.par[i]; j >= 0; j = L.par[j]) {  // X <- Rl[j] o X
+      const double *Tj = L.w.c.Rl[j];
+      double t3[3];
+      mv3(Tj, p, t3);
+      p[0] = Tj[9] + t3[0]; p[1] = Tj[10] + t3[1]; p[2] = Tj[11] + t3[2];
+      mm3(Tj, R, R);
+    }
+#pragma unroll
+    for (int e = 0; e < 9; ++e) L.w.c.Rw[i][e] = R[e];
+#pragma unroll
+    for (int e = 0; e < 3; ++e) L.w.c.pw[i][e] = p[e];
+    double z[3], S[6];
+    mv3(R, m.axis[i], z);
+    cross3(p, z, S);
+    S[3] = z[0]; S[4] = z[1]; S[5] = z[2];
+#pragma unroll
+    for (int e = 0; e < 6; ++e) L.S[i][e] = S[e];
+    if (!TERM) {
+      // body inertia about the world origin: {m, m c, Ixx, Ixy, Ixz, Iyy, Iyz, Izz}
+      double cw[3], Tm[9], Iw[9];
+      mv3(R, m.com[i], cw);
+      cw[0] += p[0]; cw[1] += p[1]; cw[2] += p[2];
+      const double ms = m.mass[i];
+      mm3(R, m.inertia[i], Tm);
+#pragma unroll
+      for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int c2 = 0; c2 < 3; ++c2) Iw[3 * a + c2] = Tm[3 * a] * R[3 * c2] + Tm[3 * a + 1] * R[3 * c2 + 1] + Tm[3 * a + 2] * R[3 * c2 + 2];
+      const double cc = dot3(cw, cw);
+      double *I = L.Ib[i];
+      I[0] = ms;
+      I[1] = ms * cw[0]; I[2] = ms * cw[1]; I[3] = ms * cw[2];
+      I[4] = Iw[0] + ms * (cc - cw[0] * cw[0]);
+      I[5] = 0.5 * (Iw[1] + Iw[3]) - ms * cw[0] * cw[1];
+      I[6] = 0.5 * (Iw[2] + Iw[6]) - ms * cw[0] * cw[2];
+      I[7] = Iw[4] + ms * (cc - cw[1] * cw[1]);
+      I[8] = 0.5 * (Iw[5] + Iw[7]) - ms * cw[1] * cw[2];
+      I[9] = Iw[8] + ms * (cc - cw[2] * cw[2]);
+    }
+  }
+  __syncthreads();
+
+  // ---- cost rows: thread j owns component j of the state / control terms and column j of every dense row
+  // (wave 0 only: lanes >= NV shadow the last joint and store nothing)
+  int nJ_total = 0;  // dense rows in use (uniform: a function of the row table)
+  for (int r = 0; r < rows.n; ++r) {
+    if (!rows.active[r]) continue;
+    const int kind = rows.kind[r];
+    nJ_total += kind == AGX_RES_FRAME_PLACEMENT ? 6 : ((kind == AGX_RES_FRAME_TRANSLATION || kind == AGX_RES_FRAME_ROTATION) ? 3 : (kind == AGX_RES_COLLISION ? 1 : 0));
+  }
+  if (wave == 0) {
+    int nJ = 0;
+    const int j = tid < NV ? tid : NV - 1;
+    const bool jl = tid < NV;
+    const double qj = L.x[j], vj = L.x[NV + j], uj = TERM ? 0.0 : L.u[j];
+    double cost = 0.0, Lq = 0.0, Lv = 0.0, Lu = 0.0, Lvv = 0.0, Luu = 0.0, dqq = 0.0;
+    for (int r = 0; r < rows.n; ++r) {
+      if (!rows.active[r]) continue;
+      const double *tile = L.w.c.ref + rows.off[r];
+      const double wi = tile[0];
+      const double *rr = tile + 1;
+      const double *aw = rr + rows.nref[r];
+      const int kind = rows.kind[r];
+      if (kind == AGX_RES_STATE) {
+        const double rq = qj - rr[j], rvv = vj - rr[NV + j];
+        const double wq = wi * aw[j], wv = wi * aw[NV + j];
+        cost += 0.5 * (wq * rq * rq + wv * rvv * rvv);
+        Lq += wq * rq; Lv += wv * rvv; Lvv += wv; dqq += wq;
+      } else if (kind == AGX_RES_CONTROL) {
+        if (!TERM) {
+          const double ru = uj - rr[j], wu = wi * aw[j];
+          cost += 0.5 * wu * ru * ru;
+          Lu += wu * ru; Luu += wu;
+        }
+      } else if (kind == AGX_RES_FRAME_PLACEMENT || kind == AGX_RES_FRAME_TRANSLATION || kind == AGX_RES_FRAME_ROTATION) {
+        int frame = in.frames ? in.frames[r] : -1;
+        if (frame < 0) frame = rows.frame[r];
+        double RF[9], pF[3];
+        int jf;
+        wg_frame_world<NV>(L, m, frame, RF, pF, &jf);
+        const bool on = (jf >= 0) && ((L.anc[jf >= 0 ? jf : 0] >> j) & 1u);
+        const double *Sj = L.S[j], *pj = L.w.c.pw[j];
+        double res[6], Jc[6], dl[3], tz[3], lin[3], ang[3];
+        int nr;
+        dl[0] = pF[0] - pj[0]; dl[1] = pF[1] - pj[1]; dl[2] = pF[2] - pj[2];
+        cross3(Sj + 3, dl, tz);  // z x (pF - pj)
+        if (kind == AGX_RES_FRAME_PLACEMENT) {
+          nr = 6;
+          double Rrel[9], d3[3], prel[3], TL[9], TR[9];
+          mtm3(rr, RF, Rrel);
+          d3[0] = pF[0] - rr[9]; d3[1] = pF[1] - rr[10]; d3[2] = pF[2] - rr[11];
+          mtv3(rr, d3, prel);
+          log6<DIFF>(Rrel, prel, res, TL, TR);
+          if (DIFF) {
+            mtv3(RF, tz, lin);
+            mtv3(RF, Sj + 3, ang);
+#pragma unroll
+            for (int e = 0; e < 3; ++e) {
+              Jc[e] = TL[3 * e] * lin[0] + TL[3 * e + 1] * lin[1] + TL[3 * e + 2] * lin[2] + TR[3 * e] * ang[0] + TR[3 * e + 1] * ang[1] + TR[3 * e + 2] * ang[2];
+              Jc[3 + e] = TL[3 * e] * ang[0] + TL[3 * e + 1] * ang[1] + TL[3 * e + 2] * ang[2];
+            }
+          }
+        } else if (kind == AGX_RES_FRAME_TRANSLATION) {
+          nr = 3;
+          res[0] = pF[0] - rr[0]; res[1] = pF[1] - rr[1]; res[2] = pF[2] - rr[2];
+          res[3] = res[4] = res[5] = 0.0;
+          Jc[0] = tz[0]; Jc[1] = tz[1]; Jc[2] = tz[2];
+          Jc[3] = Jc[4] = Jc[5] = 0.0;
+        } else {
+          nr = 3;
+          double Rrel[9], TL[9];
+          mtm3(rr, RF, Rrel);
+          log3(Rrel, res);
+          res[3] = res[4] = res[5] = 0.0;
+          Jc[3] = Jc[4] = Jc[5] = 0.0;
+          if (DIFF) {
+            jlog3(res, TL);
+            mtv3(RF, Sj + 3, ang);
+#pragma unroll
+            for (int e = 0; e < 3; ++e) Jc[e] = TL[3 * e] * ang[0] + TL[3 * e + 1] * ang[1] + TL[3 * e + 2] * ang[2];
+          }
+        }
+        double a = 0.0;
+#pragma unroll
+        for (int e = 0; e < 6; ++e) {
+          const double we = (e < nr) ? wi * aw[e] : 0.0;
+          a += 0.5 * we * res[e] * res[e];
+          if (DIFF && e < nr) {
+            const double jc = on ? Jc[e] : 0.0;
+            Lq += we * res[e] * jc;
+            if (jl) L.w.c.J[nJ + e][j] = jc;
+            if (tid == 0) { L.w.c.wJ[nJ + e] = we; }
+          }
+        }
+        if (tid == 0) cost += a;
+        nJ += nr;
+      } else if (kind == AGX_RES_COLLISION) {
+        // colmpc.ResidualDistanceCollision (ocp_croco_generic.py:524-533) with a scalar activation
+        double Ra[9], pa[3], Rb[9], pb[3], ca[3], cb[3], n[3];
+        int ja, jb;
+        wg_frame_world<NV>(L, m, rows.frame[r], Ra, pa, &ja);
+        wg_frame_world<NV>(L, m, rows.frame_b[r], Rb, pb, &jb);
+        const double d = collision_distance_placed(m, rows.frame[r], rows.frame_b[r], Ra, pa, Rb, pb, ca, cb, n);
+        double a, ar, arr;
+        activation1(rows.act[r], rows.alpha[r], aw[0], d, a, ar, arr);
+        if (tid == 0) cost += wi * a;
+        if (DIFF) {
+          const bool ona = (ja >= 0) && ((L.anc[ja >= 0 ? ja : 0] >> j) & 1u);
+          const bool onb = (jb >= 0) && ((L.anc[jb >= 0 ? jb : 0] >> j) & 1u);
+          const double *Sj = L.S[j], *pj = L.w.c.pw[j];
+          double da[3], db[3], ta[3], tb[3];
+#pragma unroll
+          for (int e = 0; e < 3; ++e) { da[e] = ca[e] - pj[e]; db[e] = cb[e] - pj[e]; }
+          cross3(Sj + 3, da, ta);
+          cross3(Sj + 3, db, tb);
+          const double g = (ona ? dot3(n, ta) : 0.0) - (onb ? dot3(n, tb) : 0.0);
+          Lq += wi * ar * g;
+          if (jl) L.w.c.J[nJ][j] = g;
+          if (tid == 0) L.w.c.wJ[nJ] = wi * arr;
+        }
+        nJ += 1;
+      }
+    }
+    if (jl) {
+      L.cpart[j] = cost;
+      if (DIFF) { L.Lq[j] = sc * Lq; L.Lv[j] = sc * Lv; L.Lvv[j] = sc * Lvv; L.Luu[j] = sc * Luu; L.lu[j] = sc * Lu; L.dqq[j] = dqq; L.D[j] = sc * Luu + in.preg; }
+    }
+  }
+  __syncthreads();
+  // Lqq = J' W J + diag(state weights) on the matrix cores: wave w owns tile (ti, tj) of every nv x nv block
+  const int ti = wave >> 1, tj = wave & 1, l15 = lane & 15, l4 = lane >> 4;
+  agx_v4d acc_lqq = {0.0, 0.0, 0.0, 0.0};
+  if (DIFF) {
+    for (int ks = 0; 4 * ks < nJ_total; ++ks) {
+      const int k = 4 * ks + l4;
+      const double a = L.w.c.J[k][16 * ti + l15];
+      const double bq = L.w.c.wJ[k] * L.w.c.J[k][16 * tj + l15];
+      acc_lqq = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bq, acc_lqq, 0, 0, 0);
+    }
+    if (ti == tj) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (l4 + 4 * r == l15) acc_lqq[r] += L.dqq[16 * ti + l15];
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc_lqq[r] *= sc;
+  }
+  // node cost: fixed summation order
+  double cost_tot = 0.0;
+  for (int e = 0; e < NV; ++e) cost_tot += L.cpart[e];
+  cost_tot *= sc;
+
+  if (!TERM) {
+    // ---- bias forces and joint-space inertia
+    for (int it = tid; it < NV * 6; it += NT) {  // v_i = sum over the path root..i of S_j qd_j
+      const int i = it / 6, e = it % 6;
+      double s = 0.0;
+      for (unsigned mk = L.anc[i]; mk; mk &= mk - 1) { const int j = __builtin_ctz(mk); s += L.S[j][e] * L.x[NV + j]; }
+      L.v[i][e] = s;
+    }
+    __syncthreads();
+    if (tid < NV) {
+      double Sd[6];
+      mcross(L.v[tid], L.S[tid], Sd);
+#pragma unroll
+      for (int e = 0; e < 6; ++e) L.Sd[tid][e] = Sd[e];
+    }
+    __syncthreads();
+    for (int it = tid; it < NV * 6; it += NT) {  // bias acceleration (qdd = 0), gravity as a base acceleration
+      const int i = it / 6, e = it % 6;
+      double s = (e < 3) ? -m.gravity[e] : 0.0;
+      for (unsigned mk = L.anc[i]; mk; mk &= mk - 1) { const int j = __builtin_ctz(mk); s += L.Sd[j][e] * L.x[NV + j]; }
+      L.w.d1.a[i][e] = s;
+    }
+    __syncthreads();
+    if (tid < NV) {
+      double h6[6], g6[6], x6[6];
+      iapply(L.Ib[tid], L.v[tid], h6);
+      iapply(L.Ib[tid], L.w.d1.a[tid], g6);
+      fcross(L.v[tid], h6, x6);
+#pragma unroll
+      for (int e = 0; e < 6; ++e) { L.h[tid][e] = h6[e]; L.w.d1.f[tid][e] = g6[e] + x6[e]; }
+    }
+    __syncthreads();
+    for (int it = tid; it < NV * 16; it += NT) {  // subtree sums: composite force (6) and composite inertia (10)
+      const int i = it >> 4, e = it & 15;
+      double s = 0.0;
+      if (e < 6) {
+        for (unsigned mk = L.desc[i]; mk; mk &= mk - 1) s += L.w.d1.f[__builtin_ctz(mk)][e];
+        L.w.d1.fc[i][e] = s;
+      } else {
+        for (unsigned mk = L.desc[i]; mk; mk &= mk - 1) s += L.Ib[__builtin_ctz(mk)][e - 6];
+        L.Ic[i][e - 6] = s;
+      }
+    }
+    __syncthreads();
+    if (tid < NV) {
+      double m6[6];
+      iapply(L.Ic[tid], L.S[tid], m6);
+#pragma unroll
+      for (int e = 0; e < 6; ++e) L.m6[tid][e] = m6[e];
+      const double nle = dot6(L.S[tid], L.w.d1.fc[tid]);
+      L.nle[tid] = nle;
+      L.rhs[tid] = L.u[tid] - nle;
+    }
+    __syncthreads();
+    // CRBA, one thread per entry: M[r][c] = S_c . (Ic_r S_r) for c on the path to r (and its mirror image)
+    double (*Mx)[32] = L.M;
+    for (int it = tid; it < NV * NV; it += NT) {
+      const int r = it / NV, c = it % NV;
+      double val = 0.0;
+      if ((L.anc[r] >> c) & 1u) val = dot6(L.S[c], L.m6[r]);
+      else if ((L.anc[c] >> r) & 1u) val = dot6(L.S[r], L.m6[c]);
+      if (r == c) val += m.armature[r];
+      Mx[r][c] = val;
+    }
+    __syncthreads();
+    if (wave == 0) {
+      const double qdd = wave_spd_solve<NV>(Mx, L.rhs, lane);
+      if (lane < NV) {
+        L.qdd[lane] = qdd;
+        const double qj = L.x[lane], vj = L.x[NV + lane];
+        L.fq[lane] = qj + dt * vj + dt * dt * qdd - L.xn[lane];
+        L.fv[lane] = vj + dt * qdd - L.xn[NV + lane];
+      }
+    }
+    __syncthreads();
+  }
+  if (!DIFF) {
+    double g = 0.0;
+    if (!TERM)
+      for (int e = 0; e < NV; ++e) g += fabs(L.fq[e]) + fabs(L.fv[e]);
+    return cost_tot + in.mu_dyn * g;
+  }
+
+  if (DIFF && !TERM) {
+    // ---- RNEA derivatives (derivation: agx_device.hpp, rnea_derivatives)
+    for (int it = tid; it < NV * 6; it += NT) {
+      const int i = it / 6, e = it % 6;
+      double s = (e < 3) ? -m.gravity[e] : 0.0;
+      for (unsigned mk = L.anc[i]; mk; mk &= mk - 1) {
+        const int j = __builtin_ctz(mk);
+        s += L.S[j][e] * L.qdd[j] + L.Sd[j][e] * L.x[NV + j];
+      }
+      L.w.d3.a[i][e] = s;
+    }
+    __syncthreads();
+    if (tid < NV) {
+      const int i = tid;
+      const double *vi = L.v[i], *Si = L.S[i], *Sdi = L.Sd[i], *ai = L.w.d3.a[i], *I = L.Ib[i], *h6 = L.h[i];
+      double t1[6], t2[6];
+      mcross(ai, Si, t1);
+      mcross(vi, Sdi, t2);
+#pragma unroll
+      for (int e = 0; e < 6; ++e) L.w.d3.psi[i][e] = t1[e] + t2[e];
+      double gg[6], xx[6];
+      iapply(I, ai, gg);
+      fcross(vi, h6, xx);
+      double *pre = L.w.d3.pre[i];
+#pragma unroll
+      for (int e = 0; e < 6; ++e) pre[e] = gg[e] + xx[e];
+      pre[6] = h6[0]; pre[7] = h6[1]; pre[8] = h6[2];
+      // E = W Io + (W Io)' - v hh' - hh v' + 2 (v.hh) 1 - [n0]x
+      const double *vl = vi, *w = vi + 3, *hh = I + 1;
+      const double Io[9] = {I[4], I[5], I[6], I[5], I[7], I[8], I[6], I[8], I[9]};
+      double WI[9], E[9];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        WI[0 + c] = w[1] * Io[6 + c] - w[2] * Io[3 + c];
+        WI[3 + c] = w[2] * Io[0 + c] - w[0] * Io[6 + c];
+        WI[6 + c] = w[0] * Io[3 + c] - w[1] * Io[0 + c];
+      }
+      const double vh = dot3(vl, hh);
+#pragma unroll
+      for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) E[3 * r + c] = WI[3 * r + c] + WI[3 * c + r] - vl[r] * hh[c] - hh[r] * vl[c] + (r == c ? 2.0 * vh : 0.0);
+      const double *n0 = h6 + 3;
+      E[1] += n0[2]; E[2] -= n0[1];
+      E[3] -= n0[2]; E[5] += n0[0];
+      E[6] += n0[1]; E[7] -= n0[0];
+#pragma unroll
+      for (int e = 0; e < 9; ++e) pre[9 + e] = E[e];
+    }
+    __syncthreads();
+    for (int it = tid; it < NV * 18; it += NT) {  // subtree sums of fC | f0 | E
+      const int i = it / 18, e = it % 18;
+      double s = 0.0;
+      for (unsigned mk = L.desc[i]; mk; mk &= mk - 1) s += L.w.d3.pre[__builtin_ctz(mk)][e];
+      L.w.d3.cmp[i][e] = s;
+    }
+    __syncthreads();
+    if (tid < NV) {
+      const int i = tid;
+      const double *Si = L.S[i], *Sdi = L.Sd[i], *psi = L.w.d3.psi[i], *Ic = L.Ic[i];
+      const double *fC = L.w.d3.cmp[i], *f0C = fC + 6, *EC = fC + 9;
+      double tt[3], Dt[3];
+      cross3(f0C, Si, tt);
+      const double *sa = Si + 3;
+      Dt[0] = 2.0 * tt[0] + EC[0] * sa[0] + EC[3] * sa[1] + EC[6] * sa[2];
+      Dt[1] = 2.0 * tt[1] + EC[1] * sa[0] + EC[4] * sa[1] + EC[7] * sa[2];
+      Dt[2] = 2.0 * tt[2] + EC[2] * sa[0] + EC[5] * sa[1] + EC[8] * sa[2];
+      double IcSd[6], IcPs[6], sxf[6], u1[3], u2[3], e1[3], e2[3];
+      iapply(Ic, Sdi, IcSd);
+      iapply(Ic, psi, IcPs);
+      fcross(Si, fC, sxf);
+      cross3(f0C, Si + 3, u1);
+      cross3(f0C, Sdi + 3, u2);
+      mv3(EC, Si + 3, e1);
+      mv3(EC, Sdi + 3, e2);
+#pragma unroll
+      for (int e = 0; e < 3; ++e) {
+        L.w.d3.col.Dt[i][e] = Dt[e];
+        L.w.d3.col.colv[i][e] = 2.0 * IcSd[e] - 2.0 * u1[e];
+        L.w.d3.col.colv[i][3 + e] = 2.0 * IcSd[3 + e] + e1[e];
+        L.w.d3.col.colq[i][e] = sxf[e] - 2.0 * u2[e] + IcPs[e];
+        L.w.d3.col.colq[i][3 + e] = sxf[3 + e] + e2[e] + IcPs[3 + e];
+      }
+    }
+    __syncthreads();
+    for (int it = tid; it < NV * NV; it += NT) {  // dtau/dq, dtau/dqdot: one thread per entry
+      const int r = it / NV, c = it % NV;
+      double dvv = 0.0, dqq = 0.0;
+      if ((L.anc[r] >> c) & 1u) {  // c on the path root..r
+        const double *mr = L.m6[r], *Dr = L.w.d3.col.Dt[r];
+        dvv = 2.0 * dot6(mr, L.Sd[c]) + dot3(Dr, L.S[c] + 3);
+        dqq = dot3(Dr, L.Sd[c] + 3) + dot6(mr, L.w.d3.psi[c]);
+      } else if ((L.anc[c] >> r) & 1u) {  // r a strict ancestor of c
+        dvv = dot6(L.S[r], L.w.d3.col.colv[c]);
+        dqq = dot6(L.S[r], L.w.d3.col.colq[c]);
+      }
+      L.tv[r][c] = dvv;
+      L.tq[r][c] = dqq;
+    }
+    __syncthreads();
+  }
+
+  // ---- acceleration-input transformation on the matrix cores and the stores
+  agx_v4d hww = {0.0, 0.0, 0.0, 0.0}, hqw = hww, hvw = hww, hqq = acc_lqq, hqv = hww, hvv = hww;
+  if (ti == tj) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      if (l4 + 4 * r == l15) hvv[r] = L.Lvv[16 * ti + l15];
+  }
+  wg_store_tile(ax + A::Lqq, acc_lqq, ti, tj, lane, NV);
+  if (!TERM) {
+    const int ca = 16 * ti + l15, cb = 16 * tj + l15;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      const int k = 4 * ks + l4;
+      const double d = L.D[k];
+      const double aM = wg_op<NV>(L.M, k, ca), aq = wg_op<NV>(L.tq, k, ca), av = wg_op<NV>(L.tv, k, ca);
+      const double bM = d * wg_op<NV>(L.M, k, cb), bq = d * wg_op<NV>(L.tq, k, cb), bv = d * wg_op<NV>(L.tv, k, cb);
+      hww = __builtin_amdgcn_mfma_f64_16x16x4f64(aM, bM, hww, 0, 0, 0);
+      hqw = __builtin_amdgcn_mfma_f64_16x16x4f64(aq, bM, hqw, 0, 0, 0);
+      hvw = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bM, hvw, 0, 0, 0);
+      hqq = __builtin_amdgcn_mfma_f64_16x16x4f64(aq, bq, hqq, 0, 0, 0);
+      hqv = __builtin_amdgcn_mfma_f64_16x16x4f64(aq, bv, hqv, 0, 0, 0);
+      hvv = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, hvv, 0, 0, 0);
+    }
+  }
+  wg_store_tile(qt + Q::Hww, hww, ti, tj, lane, NV);
+  wg_store_tile(qt + Q::Hqw, hqw, ti, tj, lane, NV);
+  wg_store_tile(qt + Q::Hvw, hvw, ti, tj, lane, NV);
+  wg_store_tile(qt + Q::Hqq, hqq, ti, tj, lane, NV);
+  wg_store_tile(qt + Q::Hqv, hqv, ti, tj, lane, NV);
+  wg_store_tile(qt + Q::Hvv, hvv, ti, tj, lane, NV);
+  // aux blocks M | tq | tv straight from LDS (zeros at the terminal node), whole rows
+  for (int e = tid; e < NV * LDM; e += NT) {
+    ax[A::M + e] = (&L.M[0][0])[e];
+    ax[A::tq + e] = (&L.tq[0][0])[e];
+    ax[A::tv + e] = (&L.tv[0][0])[e];
+  }
+  // gradients: gw = M lu, gx = Lx + taux' lu
+  if (tid < 3 * NV) {
+    const int which = tid / NV, i = tid % NV;
+    double s = which == 0 ? 0.0 : (which == 1 ? L.Lq[i] : L.Lv[i]);
+    if (!TERM) {
+      if (which == 0) for (int l = 0; l < NV; ++l) s += L.M[i][l] * L.lu[l];
+      else if (which == 1) for (int l = 0; l < NV; ++l) s += L.tq[l][i] * L.lu[l];
+      else for (int l = 0; l < NV; ++l) s += L.tv[l][i] * L.lu[l];
+    }
+    qt[(which == 0 ? Q::gw : (which == 1 ? Q::gx : Q::gx + NV)) + i] = s;
+  } else if (tid >= 128 && tid < 128 + NV) {
+    const int i = tid - 128;
+    qt[Q::f + i] = L.fq[i];
+    qt[Q::f + NV + i] = L.fv[i];
+    ax[A::Lvv + i] = L.Lvv[i];
+    ax[A::Luu + i] = L.Luu[i];
+    ax[A::Lu + i] = L.lu[i];
+  } else if (tid == 255) {
+    qt[Q::cost] = cost_tot;
+  }
+  return cost_tot;
+}
+
+// K1 for large models: running nodes first (unit = b T + t), then the terminal nodes, one workgroup each.
+template <int NV>
+__global__ void __launch_bounds__(256, AGX_WG_MINWAVES) k_calc_qp_wg(const DevModel *__restrict__ mp, const DevOcp *__restrict__ op,
+                                                    const double *__restrict__ dts, const double *__restrict__ xs,
+                                                    const double *__restrict__ us, RefView rv, double *__restrict__ qts,
+                                                    double *__restrict__ auxs, const DevState *__restrict__ st) {
+  constexpr int NX = 2 * NV;
+  __shared__ WgNode<NV> L;
+  const DevOcp &o = *op;
+  const int T = o.T;
+  const long long unit = blockIdx.x, n_run = (long long)o.B * T;
+  const bool term = unit >= n_run;
+  const int b = term ? (int)(unit - n_run) : (int)(unit / T), t = term ? T : (int)(unit % T);
+  if (st[b].done) return;
+  const long long node = (long long)b * (T + 1) + t;
+  WgIn in;
+  in.x = xs + node * NX; in.dx = nullptr; in.xn = in.x + NX; in.dxn = nullptr;
+  in.u = us + ((long long)b * T + t) * NV; in.du = nullptr;
+  in.alpha = 0.0; in.preg = st[b].preg; in.mu_dyn = o.mu_dyn;
+  in.ref = ref_at(rv, b, t, T); in.stride = o.stride; in.frames = frames_at(rv, b, t, T);
+  double *qt = qts + node * QT<NV>::SIZE, *ax = auxs + node * AUX<NV>::SIZE;
+  if (term) { in.dt = 0.0; wg_node<NV, true, true>(L, *mp, o.rows[1], in, qt, ax); }
+  else { in.dt = dts[t]; wg_node<NV, false, true>(L, *mp, o.rows[0], in, qt, ax); }
+}
+
+// Line-search trial for large models: merit share of every node at (xs + alpha dx, us + alpha du).
+template <int NV>
+__global__ void __launch_bounds__(256) k_ls_trial_wg(const DevModel *__restrict__ mp, const DevOcp *__restrict__ op,
+                                                     const double *__restrict__ dts, const double *__restrict__ xs,
+                                                     const double *__restrict__ us, RefView rv, const double *__restrict__ dxs,
+                                                     const double *__restrict__ dus, double *__restrict__ trial,
+                                                     const DevState *__restrict__ st, double alpha) {
+  constexpr int NX = 2 * NV;
+  __shared__ WgNode<NV> L;
+  const DevOcp &o = *op;
+  const int T = o.T;
+  const long long node = blockIdx.x;
+  const int b = (int)(node / (T + 1)), t = (int)(node % (T + 1));
+  const DevState &S = st[b];
+  if (S.done || S.ls_acc) return;
+  WgIn in;
+  in.x = xs + node * NX; in.dx = dxs + node * NX; in.xn = in.x + NX; in.dxn = in.dx + NX;
+  in.u = us + ((long long)b * T + t) * NV; in.du = dus + ((long long)b * T + t) * NV;
+  in.alpha = alpha; in.preg = 0.0; in.mu_dyn = o.mu_dyn;
+  in.ref = ref_at(rv, b, t, T); in.stride = o.stride; in.frames = frames_at(rv, b, t, T);
+  double part;
+  if (t == T) { in.dt = 0.0; part = wg_node<NV, true, false>(L, *mp, o.rows[1], in, nullptr, nullptr); }
+  else { in.dt = dts[t]; part = wg_node<NV, false, false>(L, *mp, o.rows[0], in, nullptr, nullptr); }
+  if (threadIdx.x == 0) trial[node] = part;
+}
+
+// One semi-implicit Euler step (OCPBaseCroco.integrate, ocp_base_croco.py:184-189): forward dynamics only, one
+// workgroup per state, no cost rows.  tlist == null: n packed states x [n][nx], u [n][nu] -> xnext [n][nx].
+// tlist != null (warm-start shift, warm_start_shift_previous_solution.py:98-104: nodes with dt_i > dt_0 are
+// integrated over dt_0): workgroup (b, k) takes node t = tlist[k] of the horizon buffers and writes the staging copy.
+template <int NV>
+__global__ void __launch_bounds__(256) k_integrate_wg(const DevModel *__restrict__ mp, double dt, const double *__restrict__ x,
+                                                      const double *__restrict__ u, double *__restrict__ xnext,
+                                                      const int *__restrict__ tlist, int nlist, int T) {
+  constexpr int NX = 2 * NV;
+  __shared__ WgNode<NV> L;
+  __shared__ DevRows none;
+  long long ix = blockIdx.x, iu = blockIdx.x;
+  if (tlist) {
+    const int b = blockIdx.x / nlist, t = tlist[blockIdx.x % nlist];
+    ix = (long long)b * (T + 1) + t;
+    iu = (long long)b * T + t;
+  }
+  if (threadIdx.x == 0) none.n = 0;
+  __syncthreads();
+  WgIn in;
+  in.x = x + ix * NX; in.dx = nullptr; in.xn = in.x; in.dxn = nullptr;  // "gap" against x itself: fq = dt v + dt^2 a, fv = dt a
+  in.u = u + iu * NV; in.du = nullptr; in.alpha = 0.0; in.preg = 0.0; in.mu_dyn = 0.0; in.dt = dt;
+  in.ref = nullptr; in.stride = 0; in.frames = nullptr;
+  wg_node<NV, false, false>(L, *mp, none, in, nullptr, nullptr);
+  if (threadIdx.x < NV) {
+    const int j = threadIdx.x;
+    xnext[ix * NX + j] = L.x[j] + L.fq[j];
+    xnext[ix * NX + NV + j] = L.x[NV + j] + L.fv[j];
+  }
+}
+
+// Warm-start shift without dynamics (the nodes with dt_i == dt_0; warm_start_shift_previous_solution.py:93-97):
+// xs[i] <- xs[i+1], us[i] <- us[i+1] (the last control is kept) into the staging halves of the buffers; nodes with
+// dt_i != dt_0 keep their control, their state comes from k_integrate_wg.  k_shift_commit copies the staging back.
+__global__ void k_shift_copy(const double *__restrict__ dts, double *__restrict__ xs, double *__restrict__ us, int B, int T, int NX, int NU) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long nxs = (long long)B * (T + 1) * NX, nus = (long long)B * T * NU;
+  const double dt0 = dts[0];
+  if (i < nxs) {
+    const int t = (int)((i / NX) % (T + 1));
+    if (t < T && dts[t] == dt0) xs[nxs + i] = xs[i + NX];
+  }
+  if (i < nus) {
+    const int t = (int)((i / NU) % T);
+    us[nus + i] = (dts[t] == dt0 && t < T - 1) ? us[i + NU] : us[i];
+  }
+}
+
+}  // namespace agx

@@ -22,6 +22,7 @@ struct DevModel {
   int nv, nframes, is_chain, pad;
   int parent[AGX_MAX_NV];
   unsigned anc[AGX_MAX_NV];  // bit j: joint j is i itself or an ancestor of i
+  unsigned desc[AGX_MAX_NV]; // bit j: joint j is i itself or a descendant of i (subtree of i)
   double placement[AGX_MAX_NV][12];
   double axis[AGX_MAX_NV][3];
   double mass[AGX_MAX_NV];
@@ -730,6 +731,7 @@ AGX_DEV void closest_seg_seg(const double *a0, const double *a1, const double *b
 AGX_HD double seg_box_param(const double *c, const double *d, double h, const double *b) {
   auto fp = [&](double s) {
     double g = 0.0;
+#pragma unroll
     for (int i = 0; i < 3; ++i) {
       const double x = c[i] + s * d[i], e = fabs(x) - b[i];
       if (e > 0.0) g += (x > 0.0 ? e : -e) * d[i];
@@ -755,12 +757,9 @@ AGX_HD bool frame_has_geometry(const DevModel &m, int f) { return m.frame_radius
 // Capsule / sphere pairs: segment-segment closest points.  Box against capsule / sphere: closest
 // point of the segment to the box; when that point lies inside the box (sgn = -1) the box witness is
 // its projection on the nearest face (a simple penetration model, not coal's EPA depth).
-template <int NV>
-AGX_DEV double collision_distance(const DevModel &m, const Kin<NV> &k, int fa, int fb, double *ca, double *cb, double *n,
-                                  int *ja, int *jb) {
-  double Ra[9], pa[3], Rb[9], pb[3];
-  frame_world<NV>(m, k, fa, Ra, pa, ja);
-  frame_world<NV>(m, k, fb, Rb, pb, jb);
+// core: world placements (Ra, pa), (Rb, pb) of the two geometry frames given
+AGX_DEV double collision_distance_placed(const DevModel &m, int fa, int fb, const double *Ra, const double *pa, const double *Rb,
+                                         const double *pb, double *ca, double *cb, double *n) {
   const double ha = m.frame_halflen[fa], hb = m.frame_halflen[fb];
   double sgn = 1.0;
   if (frame_is_box(m, fa) || frame_is_box(m, fb)) {
@@ -788,14 +787,19 @@ AGX_DEV double collision_distance(const DevModel &m, const Kin<NV> &k, int fa, i
 #pragma unroll
       for (int e = 1; e < 3; ++e)
         if (half[e] - fabs(x[e]) < depth) { depth = half[e] - fabs(x[e]); best = e; }
-      y[best] = x[best] < 0.0 ? -half[best] : half[best];
+#pragma unroll
+      for (int e = 0; e < 3; ++e)  // (no dynamic index: the witness arrays stay in registers)
+        if (e == best) y[e] = x[e] < 0.0 ? -half[e] : half[e];
       sgn = -1.0;
     }
     double wy[3];
     mv3(Rx, y, wy);
-    double *cc = bb ? ca : cb, *cx = bb ? cb : ca;
 #pragma unroll
-    for (int e = 0; e < 3; ++e) { cc[e] = pc[e] + s * zc[e]; cx[e] = px[e] + wy[e]; }
+    for (int e = 0; e < 3; ++e) {  // (selects, not pointers into the witness arrays: those would live in scratch)
+      const double seg = pc[e] + s * zc[e], box = px[e] + wy[e];
+      ca[e] = bb ? seg : box;
+      cb[e] = bb ? box : seg;
+    }
   } else {
     double a0[3], a1[3], b0[3], b1[3];
 #pragma unroll
@@ -822,6 +826,14 @@ AGX_DEV double collision_distance(const DevModel &m, const Kin<NV> &k, int fa, i
   for (int e = 0; e < 3; ++e) n[e] *= inv;
   return sgn * dn - (m.frame_radius[fa] + m.frame_radius[fb]);
 }
+template <int NV>
+AGX_DEV double collision_distance(const DevModel &m, const Kin<NV> &k, int fa, int fb, double *ca, double *cb, double *n,
+                                  int *ja, int *jb) {
+  double Ra[9], pa[3], Rb[9], pb[3];
+  frame_world<NV>(m, k, fa, Ra, pa, ja);
+  frame_world<NV>(m, k, fb, Rb, pb, jb);
+  return collision_distance_placed(m, fa, fb, Ra, pa, Rb, pb, ca, cb, n);
+}
 
 template <int NV>
 struct CostAcc {
@@ -829,11 +841,6 @@ struct CostAcc {
   double Lq[NV], Lv[NV], Lu[NV];
   double Lqq[NV][NV];
   double Lvv[NV], Luu[NV];
-  // Large models only: when set, frame rows do not accumulate J' W J here (an O(6 nv^2) chain of
-  // scratch read-modify-writes on one lane) but park [weights (6) | J (6 x nv)] of up to two rows at
-  // jt + 1 (jt[0] = number of rows); the cooperative k_transform_big adds the products.
-  double *jt = nullptr;
-  int njt = 0;
 };
 
 // Evaluates the cost rows of one node.  DIFF = false: value only (line search).
@@ -841,7 +848,6 @@ template <int NV, bool CHAIN, bool TERM, bool DIFF>
 AGX_DEV void node_costs(const DevModel &m, const DevRows &rows, const Kin<NV> &k, const double *x, const double *u,
                         const double *ref, const int *frames, CostAcc<NV> &c) {
   c.cost = 0.0;
-  c.njt = 0;
   if (DIFF) {
 AGX_UNROLL_NV
     for (int i = 0; i < NV; ++i) {
@@ -973,7 +979,6 @@ AGX_UNROLL_NV
 #pragma unroll
           for (int e = 0; e < 6; ++e) { wj[e] = we[e] * J[e][i]; gi += wj[e] * res[e]; }
           c.Lq[i] += gi;
-          if (NV > 8 && c.jt && c.njt < 2) continue;  // the Hessian part is deferred (see CostAcc::jt)
 AGX_UNROLL_NV
           for (int j = 0; j <= i; ++j) {
             double acc = 0.0;
@@ -981,14 +986,6 @@ AGX_UNROLL_NV
             for (int e = 0; e < 6; ++e) acc += wj[e] * J[e][j];
             c.Lqq[i][j] += acc;
           }
-        }
-        if (NV > 8 && c.jt && c.njt < 2) {
-          double *slot = c.jt + 1 + c.njt * (6 + 6 * NV);
-          for (int e = 0; e < 6; ++e) {
-            slot[e] = we[e];
-            for (int i = 0; i < NV; ++i) slot[6 + e * NV + i] = J[e][i];
-          }
-          c.njt += 1;
         }
       }
     } else if (kind == AGX_RES_COLLISION) {

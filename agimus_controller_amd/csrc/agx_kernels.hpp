@@ -238,7 +238,7 @@ __device__ __forceinline__ void calc_qp_body(const long long unit, const DevMode
                                              const double *__restrict__ dts, const double *__restrict__ xs,
                                              const double *__restrict__ us, const RefView &rv, double *__restrict__ qts,
                                              double *__restrict__ auxs, const DevState *__restrict__ st,
-                                             double *__restrict__ auxg = nullptr, double *__restrict__ jtbuf = nullptr) {
+                                             double *__restrict__ auxg = nullptr) {
   constexpr int NX = 2 * NV, NU = NV;
   typedef QT<NV> Q;
   typedef AUX<NV> A;
@@ -269,18 +269,14 @@ AGX_UNROLL_NV
   for (int i = 0; i < NV; ++i)
 #pragma unroll
     for (int j = 0; j < NV; ++j) { L[i][j] = M[i][j]; ax[A::M + i * A::LD + j] = M[i][j]; }
-  if constexpr (NV > 8) {
-    for (int i = 0; i < NV; ++i) qdd[i] = u[i] - nle[i];
-    spd_solve<NV>(L, qdd);
-  } else {
-    spd_inverse<NV>(L, Minv);
+  static_assert(NV <= 8, "large models use the workgroup-per-node kernel (agx_big_k1.hpp)");
+  spd_inverse<NV>(L, Minv);
 AGX_UNROLL_NV
-    for (int i = 0; i < NV; ++i) {
-      double a = 0.0;
+  for (int i = 0; i < NV; ++i) {
+    double a = 0.0;
 #pragma unroll
-      for (int j = 0; j < NV; ++j) a += Minv[i][j] * (u[j] - nle[j]);
-      qdd[i] = a;
-    }
+    for (int j = 0; j < NV; ++j) a += Minv[i][j] * (u[j] - nle[j]);
+    qdd[i] = a;
   }
   {
     const double *xn = xp + NX;
@@ -293,13 +289,7 @@ AGX_UNROLL_NV
   double tq[NV][NV], tv[NV][NV];
   rnea_derivatives<NV, CHAIN>(m, k, d, x + NV, qdd, tq, tv);
   CostAcc<NV> c;
-  if constexpr (NV > 8) c.jt = jtbuf ? jtbuf + unit * (1 + 2 * (6 + 6 * NV)) : nullptr;
   node_costs<NV, CHAIN, false, true>(m, o.rows[0], k, x, u, ref_at(rv, b, t, T), frames_at(rv, b, t, T), c);
-  if constexpr (NV > 8) if (c.jt) {
-    c.jt[0] = (double)c.njt;
-    for (int s2 = 0; s2 < c.njt; ++s2)
-      for (int e = 0; e < 6; ++e) c.jt[1 + s2 * (6 + 6 * NV) + e] *= dt;  // running cost = dt * l
-  }
   CostGen<NV> g;
   if constexpr (GEN) node_costs_general<NV, CHAIN, false, true>(m, o.rows[0], k, x, u, ref_at(rv, b, t, T), frames_at(rv, b, t, T), c, g);
   qt[Q::cost] = dt * c.cost;
@@ -311,21 +301,6 @@ AGX_UNROLL_NV
     ax[A::Lvv + i] = dt * c.Lvv[i];
     ax[A::Luu + i] = dt * c.Luu[i];
     ax[A::Lu + i] = lu[i];
-  }
-  if constexpr (NV > 8) {
-    // large models: the O(nv^3) transformation into acceleration-input form is done cooperatively by
-    // k_transform_big (agx_big.hpp) from the aux tile; here only the raw pieces are written
-    (void)D;
-    for (int i = 0; i < NV; ++i) {
-      qt[Q::gx + i] = dt * c.Lq[i];
-      qt[Q::gx + NV + i] = dt * c.Lv[i];
-      for (int j = 0; j < NV; ++j) {
-        ax[A::tq + i * A::LD + j] = tq[i][j];
-        ax[A::tv + i * A::LD + j] = tv[i][j];
-        ax[A::Lqq + i * A::LD + j] = dt * c.Lqq[i][j];
-      }
-    }
-    return;
   }
   // DM = D M (row scaling), then the five transformed blocks
 AGX_UNROLL_NV
@@ -460,20 +435,6 @@ __global__ void __launch_bounds__(64) k_calc_qp_term(const DevModel *__restrict_
                                                      double *__restrict__ auxs, const DevState *__restrict__ st,
                                                      double *__restrict__ auxg = nullptr) {
   calc_qp_term_body<NV, CHAIN, GEN>(blockIdx.x * blockDim.x + threadIdx.x, mp, op, xs, rv, qts, auxs, st, auxg);
-}
-
-// one-lane derivative pass of both node types in one launch (large models: the terminal nodes would
-// otherwise be a latency-bound launch of B lanes on their own)
-template <int NV, bool CHAIN>
-__global__ void __launch_bounds__(64) k_calc_qp_all(const DevModel *__restrict__ mp, const DevOcp *__restrict__ op,
-                                                    const double *__restrict__ dts, const double *__restrict__ xs,
-                                                    const double *__restrict__ us, RefView rv, double *__restrict__ qts,
-                                                    double *__restrict__ auxs, const DevState *__restrict__ st,
-                                                    double *__restrict__ jtbuf) {
-  const long long unit = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  const long long n_run = (long long)op->B * op->T;
-  if (unit < n_run) calc_qp_body<NV, CHAIN>(unit, mp, op, dts, xs, us, rv, qts, auxs, st, nullptr, jtbuf);
-  else calc_qp_term_body<NV, CHAIN>((int)(unit - n_run), mp, op, xs, rv, qts, auxs, st);
 }
 
 __device__ __forceinline__ double wave_max(double v) {
@@ -984,7 +945,10 @@ __global__ void __launch_bounds__(128) k_step(const DevModel *__restrict__ mp, c
     red[6] = S.merit;
   }
   __syncthreads();
-  if (flag || !(mode & 1) || (mode & 8)) return;  // bit3: the line search runs in k_ls_trial / k_ls_accept
+  if (flag || !(mode & 1) || (mode & 8)) return;  // bit3: the line search runs in k_ls_trial_wg / k_ls_accept
+  // large models never search here (a per-lane node evaluation needs tens of KB of private arrays: its mere
+  // presence in the kernel would reserve that scratch at every launch)
+  if constexpr (NV <= 8) {
   const double merit = red[6];
   __syncthreads();
   // ---- line search
@@ -1113,6 +1077,7 @@ AGX_UNROLL_NV
       S.iter = max_iter;
     }
   }
+  }  // NV <= 8
 }
 
 // ---------------------------------------------------------------------------
@@ -1132,8 +1097,9 @@ __global__ void k_reset_state(DevState *st, int B, int *n_done) {
 }
 
 // stream -> host hand-off through mapped pinned memory: value first, then the sequence stamp
-__global__ void k_publish(const int *__restrict__ d_value, int *host_value, int *host_seq, int seq) {
-  __hip_atomic_store(host_value, *d_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+__global__ void k_publish(const int *__restrict__ d_value, unsigned long long *host_value, unsigned long long *host_seq,
+                          unsigned long long seq) {
+  __hip_atomic_store(host_value, (unsigned long long)(unsigned)*d_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   __threadfence_system();
   __hip_atomic_store(host_seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
@@ -1648,3 +1614,4 @@ __global__ void k_ws_from_ref(double *xs, double *us, double *x0, const double *
 #include "agx_k1_lanes.hpp"
 #include "agx_admm.hpp"
 #include "agx_big.hpp"
+#include "agx_big_k1.hpp"

@@ -10,9 +10,12 @@ importable, so reference users keep their URDF workflow.
 
 The Panda table uses the public Franka kinematics (URDF joint origins) and the
 dynamic parameters identified by Gaz et al. (RA-L 2019) as commonly distributed
-with franka_description; they are NOT example-robot-data's inertials (SURVEY.md
-section 8c): results on this table are not comparable digit-for-digit with the
-reference's golden pickle.
+with franka_description, hand and locked fingers lumped into link 7.  SURVEY.md
+section 8c expected these to differ from example-robot-data's inertials; they do
+not: the table satisfies the dynamics of the reference's golden trajectory
+(tests/resources/simple_ocp_croco_results.pkl) to 1e-11 relative and the golden
+xs / us / K are reproduced on it to 1e-9 (tests/test_oracle_golden.py,
+tests/test_hip_parity.py::test_golden_fixture_through_the_c_abi).
 """
 
 from __future__ import annotations

@@ -200,10 +200,6 @@ def cpu_baseline(args, table, tcp, po, n_steps=24):
 
 def main():
     args = parse()
-    if args.workload == "humanoid":
-        # large-model kernels use big per-lane scratch: keep it allocated between dispatches (see backend.py);
-        # must be in the environment before the HIP runtime initialises
-        os.environ.setdefault("HSA_NO_SCRATCH_RECLAIM", "1")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -369,7 +365,7 @@ def main():
             result["roofline"]["kernel"] = "k_calc_qp<7> (one lane per node: problems with a collision cost row do not use the 8-lane kernel yet)"
         if args.workload == "humanoid":
             result["metric"] = f"MPC steps/sec (horizon={T}, 30-DoF humanoid)"
-            result["roofline"]["kernel"] = "k_calc_qp<30> (one lane per node, per-lane arrays in scratch: correctness-first path)"
+            result["roofline"]["kernel"] = "k_calc_qp_wg<30> (one workgroup per node: LDS-resident dynamics, fp64 MFMA contractions)"
         if world == 1 and not args.no_batch1 and args.workload == "sine":
             # BASELINE.json configs[1]: the same workload at batch = 1 (latency of one controller)
             h1 = backend.HipOcp(table, po, 1, device=local_rank)

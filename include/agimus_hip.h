@@ -258,6 +258,12 @@ int agx_ocp_calc_diff(agx_ocp *ocp, double *tiles);
  * Riccati backward + linear forward, KKT, reported gains): K [B][T][nu][ndx], k = acceleration-space
  * feed-forward [B][T][nu], dx [B][T+1][ndx], du [B][T][nu], kkt [B].                                */
 int agx_ocp_direction(agx_ocp *ocp, double *K, double *k, double *dx, double *du, double *kkt);
+/* The QP tiles of the node-parallel derivative pass at the resident (xs, us) exactly as the solver's sweep reads
+ * them (acceleration-input form): qt [B][T+1][*qt_size], aux [B][T+1][*aux_size] (either may be
+ * NULL; the sizes are always returned).  Layout per node, blocks nv x LD row major with LD = 8 (nv <= 8) or 32:
+ *   qt  = Hqq | Hqv | Hvv | Hqw | Hvw | Hww | gx (2 nv of 2 LD) | gw (nv of LD) | f (2 nv of 2 LD) | cost (1 of 8)
+ *   aux = M | dtau/dq | dtau/dqdot | Lqq | Lvv (LD) | Luu (LD) | Lu (LD)                                   */
+int agx_ocp_qp_tiles(agx_ocp *ocp, double *qt, double *aux, int *qt_size, int *aux_size);
 /* Average device time in milliseconds of `reps` launches of one kernel,
  * measured with hipEvents on the problem's stream.
  * which: 0 = derivative pass (running + terminal launches), 1 = Riccati backward + forward,

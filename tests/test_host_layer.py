@@ -288,8 +288,13 @@ def test_two_rank_scatter_solve_gather_gloo(tmp_path):
     script = tmp_path / "worker.py"
     script.write_text(WORKER.format(root=str(ROOT)))
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    import socket
+
+    with socket.socket() as sk:  # a free port chosen by the kernel (a fixed one collides with leftovers of an earlier run)
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
-           "--master-port", "29731", str(script)]
+           "--master-port", str(port), str(script)]
     res = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env)
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
     assert "SHARD_OK" in res.stdout
