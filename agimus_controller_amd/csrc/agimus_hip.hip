@@ -1250,6 +1250,17 @@ int agx_ocp_qp_tiles(agx_ocp *o, double *qt, double *aux, int *qt_size, int *aux
   return 0;
 }
 
+#ifdef AGX_WG_PROFILE
+// development only: cycle stamps of one workgroup of the large-model derivative pass (not part of the ABI)
+int agx_dev_wg_stamps(long long *out, int *n) {
+  int zero = 0;
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(agx::g_wg_ts), sizeof(long long) * 64) != hipSuccess) return -1;
+  if (hipMemcpyFromSymbol(n, HIP_SYMBOL(agx::g_wg_n), sizeof(int)) != hipSuccess) return -1;
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(agx::g_wg_n), &zero, sizeof(int));
+  return 0;
+}
+#endif
+
 int agx_ocp_time_kernel(agx_ocp *o, int which, int reps, double *avg_ms) {
   if (!o || !avg_ms || reps < 1) return fail("agx_ocp_time_kernel: bad argument");
   if (set_device(o)) return -1;

@@ -31,26 +31,47 @@ constexpr int kWgJ = 16;     // scalar residual rows with a dense gradient in q 
 
 typedef double agx_v4d __attribute__((ext_vector_type(4)));
 
-// workgroups (= waves per SIMD) of the derivative pass a CU is asked to hold: 2 leaves the kernel its ~200 VGPRs,
-// 3 (what the 52 KB of LDS allow) caps them at 168 and spills a few values
+// Development builds (-DAGX_WG_PROFILE): thread 0 of workgroup 777 leaves a cycle stamp at every phase boundary of
+// wg_node (scripts/time_wg_phases.py prints the differences).
+#ifdef AGX_WG_PROFILE
+__device__ long long g_wg_ts[64];
+__device__ int g_wg_n;
+#define AGX_WG_STAMP()                                                                       \
+  do {                                                                                       \
+    if (threadIdx.x == 0 && blockIdx.x == 777 && DIFF && !TERM) { g_wg_ts[g_wg_n] = wall_clock64(); g_wg_n += 1; } \
+  } while (0)
+#else
+#define AGX_WG_STAMP() do { } while (0)
+#endif
+
+// workgroups (= waves per SIMD) of the derivative pass a CU is asked to hold: 2 leaves the kernel its ~200 VGPRs (1.48 ms
+// per launch at B = 512, T = 50), 3 (what the 52 KB of LDS allow) caps them at 168 and spills ~30 values that live
+// across the solve / cost-row region (268 B per lane, no arrays): 1.24 ms
 #ifndef AGX_WG_MINWAVES
-#define AGX_WG_MINWAVES 2
+#define AGX_WG_MINWAVES 3
 #endif
 
 template <int NV>
 struct WgNode {
   static constexpr int LDM = 32;
   double M[NV][LDM], tq[NV][LDM], tv[NV][LDM];  // columns >= NV stay zero (MFMA operands)
-  double S[NV][6], Sd[NV][6], v[NV][6], m6[NV][6], h[NV][6];
+  double S[NV][6], Sd[NV][6], v[NV][6], m6[NV][6];
   double Ib[NV][10], Ic[NV][10];
   double x[2 * NV], u[NV], xn[2 * NV];
   double nle[32], rhs[32], qdd[32], D[32], lu[32], Lq[32], Lv[32], Lvv[32], Luu[32], dqq[32], cpart[32], fq[32], fv[32];
+  // Working storage, reused phase by phase (doubles, offsets in comments):
+  //   kinematics   Rl [0, 360)                     | Rw [540, 810) pw [810, 900) ref [900, 1156) J [1156, 1668) wJ [1668, 1684)
+  //   bias forces  a0 f fc [0, 540)                |  ... cost rows and M qdd = rhs run side by side on Rw .. wJ ...
+  //   derivatives  a psi [0, 360)  pre [360, 900)  (-> Dt colv colq)      cmp [900, 1440)   (ref, J are dead by then)
   union {
-    struct {  // kinematics + cost rows
-      double Rl[NV][12], Rw[NV][9], pw[NV][3], ref[kWgRef], J[kWgJ][LDM], wJ[kWgJ];
+    struct {
+      union {
+        double Rl[NV][12];                                     // local placements (dead once the world placements exist)
+        struct { double a[NV][6], f[NV][6], fc[NV][6]; } d1;   // bias forces
+      };
+      double Rw[NV][9], pw[NV][3], ref[kWgRef], J[kWgJ][LDM], wJ[kWgJ];
     } c;
-    struct { double a[NV][6], f[NV][6], fc[NV][6]; } d1;  // bias forces
-    struct {                                              // RNEA derivatives
+    struct {
       double a[NV][6], psi[NV][6];
       union {
         double pre[NV][18];  // fC (6) | f0 (3) | E (9) of the body; dead once the subtree sums exist
@@ -72,17 +93,16 @@ __device__ __forceinline__ double wave_spd_solve(const double (*M)[32], const do
 #pragma unroll
   for (int j = 0; j < NV; ++j) a[j] = M[i][j];
   a[NV] = rhs[i];
+  double d = 1.0;  // the row's own pivot (final once column i has been eliminated everywhere else)
 #pragma unroll
   for (int k = 0; k < NV; ++k) {
-    const double rp = fast_rcp(readlane_f64(a[k], k));
+    const double piv = readlane_f64(a[k], k);
+    const double rp = fast_rcp(piv);
     const double f = (lane == k) ? 0.0 : a[k] * rp;  // the pivot row itself stays
+    if (i == k) d = piv;
 #pragma unroll
     for (int j = k + 1; j <= NV; ++j) a[j] -= f * readlane_f64(a[j], k);
   }
-  double d = 1.0;
-#pragma unroll
-  for (int j = 0; j < NV; ++j)
-    if (j == i) d = a[j];
   return a[NV] / d;
 }
 
@@ -105,9 +125,35 @@ __device__ __forceinline__ void wg_frame_world(const WgNode<NV> &L, const DevMod
   }
 }
 
-// one MFMA k-step operand pair from an LDS matrix X[NV][32]:  A[m][k] = X[k][col_a],  B[k][n] = s_k X[k][col_b]
+// ---- fp64 matrix-core helpers: wave w of the 4-wave workgroup owns tile (ti, tj) = (w >> 1, w & 1) of a 32 x 32
+// result.  v_mfma_f64_16x16x4_f64 operand maps (cdna_hip_programming.md): lane l supplies A[m = l & 15][k = l >> 4] and
+// B[k = l >> 4][n = l & 15]; result register q holds D[m = (l >> 4) + 4 q][n = l & 15].
 template <int NV>
 __device__ __forceinline__ double wg_op(const double (*X)[32], int k, int col) { return k < NV ? X[k][col] : 0.0; }
+
+// acc[m][n] += sum_k fa(m, k) fb(k, n) over KSTEPS k-steps of 4
+template <int KSTEPS, class FA, class FB>
+__device__ __forceinline__ agx_v4d wg_mma(int ti, int tj, int lane, FA fa, FB fb, agx_v4d acc) {
+  const int m = 16 * ti + (lane & 15), n = 16 * tj + (lane & 15), l4 = lane >> 4;
+#pragma unroll
+  for (int ks = 0; ks < KSTEPS; ++ks) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(fa(m, 4 * ks + l4), fb(4 * ks + l4, n), acc, 0, 0, 0);
+  return acc;
+}
+// Masked sums over the tree on the matrix cores: out[i][n] = sum_{k in set(i)} fb(k, n), set(i) = bits of mask[i]
+// (ancestors: recursions root -> leaf such as v_i = sum S_k qd_k; descendants: subtree sums such as composite
+// inertias / forces).  The 0 / 1 operand is exact; no level synchronisation, no data-dependent loops.
+template <class FB>
+__device__ __forceinline__ agx_v4d wg_mask_mma(const unsigned *mask, int ti, int tj, int lane, FB fb) {
+  const unsigned mrow = mask[16 * ti + (lane & 15)];
+  const agx_v4d zero = {0.0, 0.0, 0.0, 0.0};
+  return wg_mma<8>(ti, tj, lane, [&](int, int k) { return ((mrow >> k) & 1u) ? 1.0 : 0.0; }, fb, zero);
+}
+// rows (lane >> 4) + 4 q, column lane & 15 of tile (ti, tj) -> f(row, col, value)
+template <class F>
+__device__ __forceinline__ void wg_scatter(const agx_v4d &acc, int ti, int tj, int lane, F f) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) f(16 * ti + (lane >> 4) + 4 * q, 16 * tj + (lane & 15), acc[q]);
+}
 
 __device__ __forceinline__ void wg_store_tile(double *__restrict__ blk, const agx_v4d &acc, int ti, int tj, int lane, int nv) {
   const int l15 = lane & 15, l4 = lane >> 4, col = 16 * tj + l15;
@@ -127,6 +173,128 @@ struct WgIn {
   const int *frames;
 };
 
+// Cost rows of one node, evaluated by ONE wave (lane j: component j of the state / control rows, column j of every
+// dense row; lanes >= nv shadow the last joint and store nothing).  Runs next to the wave that solves M qdd = rhs.
+template <int NV, bool TERM, bool DIFF>
+__device__ __forceinline__ void wg_costs(WgNode<NV> &L, const DevModel &m, const DevRows &rows, const WgIn &in, int lane, double sc) {
+  int nJ = 0;
+  const int j = lane < NV ? lane : NV - 1;
+  const bool jl = lane < NV;
+  const double qj = L.x[j], vj = L.x[NV + j], uj = TERM ? 0.0 : L.u[j];
+  double cost = 0.0, Lq = 0.0, Lv = 0.0, Lu = 0.0, Lvv = 0.0, Luu = 0.0, dqq = 0.0;
+  for (int r = 0; r < rows.n; ++r) {
+    if (!rows.active[r]) continue;
+    const double *tile = L.w.c.ref + rows.off[r];
+    const double wi = tile[0];
+    const double *rr = tile + 1;
+    const double *aw = rr + rows.nref[r];
+    const int kind = rows.kind[r];
+    if (kind == AGX_RES_STATE) {
+      const double rq = qj - rr[j], rvv = vj - rr[NV + j];
+      const double wq = wi * aw[j], wv = wi * aw[NV + j];
+      cost += 0.5 * (wq * rq * rq + wv * rvv * rvv);
+      Lq += wq * rq; Lv += wv * rvv; Lvv += wv; dqq += wq;
+    } else if (kind == AGX_RES_CONTROL) {
+      if (!TERM) {
+        const double ru = uj - rr[j], wu = wi * aw[j];
+        cost += 0.5 * wu * ru * ru;
+        Lu += wu * ru; Luu += wu;
+      }
+    } else if (kind == AGX_RES_FRAME_PLACEMENT || kind == AGX_RES_FRAME_TRANSLATION || kind == AGX_RES_FRAME_ROTATION) {
+      int frame = in.frames ? in.frames[r] : -1;
+      if (frame < 0) frame = rows.frame[r];
+      double RF[9], pF[3];
+      int jf;
+      wg_frame_world<NV>(L, m, frame, RF, pF, &jf);
+      const bool on = (jf >= 0) && ((L.anc[jf >= 0 ? jf : 0] >> j) & 1u);
+      const double *Sj = L.S[j], *pj = L.w.c.pw[j];
+      double res[6], Jc[6], dl[3], tz[3], lin[3], ang[3];
+      int nr;
+      dl[0] = pF[0] - pj[0]; dl[1] = pF[1] - pj[1]; dl[2] = pF[2] - pj[2];
+      cross3(Sj + 3, dl, tz);  // z x (pF - pj)
+      if (kind == AGX_RES_FRAME_PLACEMENT) {
+        nr = 6;
+        double Rrel[9], d3[3], prel[3], TL[9], TR[9];
+        mtm3(rr, RF, Rrel);
+        d3[0] = pF[0] - rr[9]; d3[1] = pF[1] - rr[10]; d3[2] = pF[2] - rr[11];
+        mtv3(rr, d3, prel);
+        log6<DIFF>(Rrel, prel, res, TL, TR);
+        if (DIFF) {
+          mtv3(RF, tz, lin);
+          mtv3(RF, Sj + 3, ang);
+#pragma unroll
+          for (int e = 0; e < 3; ++e) {
+            Jc[e] = TL[3 * e] * lin[0] + TL[3 * e + 1] * lin[1] + TL[3 * e + 2] * lin[2] + TR[3 * e] * ang[0] + TR[3 * e + 1] * ang[1] + TR[3 * e + 2] * ang[2];
+            Jc[3 + e] = TL[3 * e] * ang[0] + TL[3 * e + 1] * ang[1] + TL[3 * e + 2] * ang[2];
+          }
+        }
+      } else if (kind == AGX_RES_FRAME_TRANSLATION) {
+        nr = 3;
+        res[0] = pF[0] - rr[0]; res[1] = pF[1] - rr[1]; res[2] = pF[2] - rr[2];
+        res[3] = res[4] = res[5] = 0.0;
+        Jc[0] = tz[0]; Jc[1] = tz[1]; Jc[2] = tz[2];
+        Jc[3] = Jc[4] = Jc[5] = 0.0;
+      } else {
+        nr = 3;
+        double Rrel[9], TL[9];
+        mtm3(rr, RF, Rrel);
+        log3(Rrel, res);
+        res[3] = res[4] = res[5] = 0.0;
+        Jc[3] = Jc[4] = Jc[5] = 0.0;
+        if (DIFF) {
+          jlog3(res, TL);
+          mtv3(RF, Sj + 3, ang);
+#pragma unroll
+          for (int e = 0; e < 3; ++e) Jc[e] = TL[3 * e] * ang[0] + TL[3 * e + 1] * ang[1] + TL[3 * e + 2] * ang[2];
+        }
+      }
+      double a = 0.0;
+#pragma unroll
+      for (int e = 0; e < 6; ++e) {
+        const double we = (e < nr) ? wi * aw[e] : 0.0;
+        a += 0.5 * we * res[e] * res[e];
+        if (DIFF && e < nr) {
+          const double jc = on ? Jc[e] : 0.0;
+          Lq += we * res[e] * jc;
+          if (jl) L.w.c.J[nJ + e][j] = jc;
+          if (lane == 0) L.w.c.wJ[nJ + e] = we;
+        }
+      }
+      if (lane == 0) cost += a;
+      nJ += nr;
+    } else if (kind == AGX_RES_COLLISION) {
+      // colmpc.ResidualDistanceCollision (ocp_croco_generic.py:524-533) with a scalar activation
+      double Ra[9], pa[3], Rb[9], pb[3], ca[3], cb[3], n[3];
+      int ja, jb;
+      wg_frame_world<NV>(L, m, rows.frame[r], Ra, pa, &ja);
+      wg_frame_world<NV>(L, m, rows.frame_b[r], Rb, pb, &jb);
+      const double d = collision_distance_placed(m, rows.frame[r], rows.frame_b[r], Ra, pa, Rb, pb, ca, cb, n);
+      double a, ar, arr;
+      activation1(rows.act[r], rows.alpha[r], aw[0], d, a, ar, arr);
+      if (lane == 0) cost += wi * a;
+      if (DIFF) {
+        const bool ona = (ja >= 0) && ((L.anc[ja >= 0 ? ja : 0] >> j) & 1u);
+        const bool onb = (jb >= 0) && ((L.anc[jb >= 0 ? jb : 0] >> j) & 1u);
+        const double *Sj = L.S[j], *pj = L.w.c.pw[j];
+        double da[3], db[3], ta[3], tb[3];
+#pragma unroll
+        for (int e = 0; e < 3; ++e) { da[e] = ca[e] - pj[e]; db[e] = cb[e] - pj[e]; }
+        cross3(Sj + 3, da, ta);
+        cross3(Sj + 3, db, tb);
+        const double g = (ona ? dot3(n, ta) : 0.0) - (onb ? dot3(n, tb) : 0.0);
+        Lq += wi * ar * g;
+        if (jl) L.w.c.J[nJ][j] = g;
+        if (lane == 0) L.w.c.wJ[nJ] = wi * arr;
+      }
+      nJ += 1;
+    }
+  }
+  if (jl) {
+    L.cpart[j] = cost;
+    if (DIFF) { L.Lq[j] = sc * Lq; L.Lv[j] = sc * Lv; L.Lvv[j] = sc * Lvv; L.Luu[j] = sc * Luu; L.lu[j] = sc * Lu; L.dqq[j] = dqq; L.D[j] = sc * Luu + in.preg; }
+  }
+}
+
 // DIFF = true: QP tile + aux tile (K1).  DIFF = false: returns cost + mu_dyn |gap|_1 on every thread (line search).
 template <int NV, bool TERM, bool DIFF>
 __device__ __forceinline__ double wg_node(WgNode<NV> &L, const DevModel &m, const DevRows &rows, const WgIn &in, double *__restrict__ qt,
@@ -135,9 +303,13 @@ __device__ __forceinline__ double wg_node(WgNode<NV> &L, const DevModel &m, cons
   typedef QT<NV> Q;
   typedef AUX<NV> A;
   static_assert(Q::LD == LDM && A::LD == LDM, "tile row stride of large models");
+  static_assert(sizeof(WgNode<NV>) <= 54608, "three workgroups per CU (160 KiB of LDS)");
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int ti = wave >> 1, tj = wave & 1, l15 = lane & 15, l4 = lane >> 4;
   const double dt = in.dt, sc = TERM ? 1.0 : dt;
+  const agx_v4d zero4 = {0.0, 0.0, 0.0, 0.0};
 
+  AGX_WG_STAMP();
   // ---- phase 0: inputs and model index sets into LDS, accumulators cleared
   for (int e = tid; e < NX; e += NT) {
     L.x[e] = in.x[e] + (in.dx ? in.alpha * in.dx[e] : 0.0);
@@ -158,9 +330,16 @@ __device__ __forceinline__ double wg_node(WgNode<NV> &L, const DevModel &m, cons
     for (int e = tid; e < kWgJ * LDM; e += NT) (&L.w.c.J[0][0])[e] = 0.0;
     if (tid < kWgJ) L.w.c.wJ[tid] = 0.0;
   }
+  int nJ_total = 0;  // dense residual rows of the node (uniform: a function of the row table)
+  for (int r = 0; r < rows.n; ++r) {
+    if (!rows.active[r]) continue;
+    const int kind = rows.kind[r];
+    nJ_total += kind == AGX_RES_FRAME_PLACEMENT ? 6 : ((kind == AGX_RES_FRAME_TRANSLATION || kind == AGX_RES_FRAME_ROTATION) ? 3 : (kind == AGX_RES_COLLISION ? 1 : 0));
+  }
   __syncthreads();
+  AGX_WG_STAMP();
 
-  // ---- kinematics: local placements, then every joint composes its own path to the root
+  // ---- kinematics: local placements ...
   if (tid < NV) {
     const int i = tid;
     const double *ax3 = m.axis[i];
@@ -184,24 +363,27 @@ __device__ __forceinline__ double wg_node(WgNode<NV> &L, const DevModel &m, cons
     for (int e = 0; e < 3; ++e) L.w.c.Rl[i][9 + e] = m.placement[i][9 + e];
   }
   __syncthreads();
+  AGX_WG_STAMP();
+  // ... then every (joint, column) composes its own path to the root: thread 4 i + c carries column c of the
+  // rotation (c < 3) or the translation (c = 3) of joint i:  y <- R_j y (+ p_j) for j = parent, grandparent, ...
+  if (tid < 4 * NV) {
+    const int i = tid >> 2, c = tid & 3;
+    double y0, y1, y2;
+    if (c < 3) { y0 = L.w.c.Rl[i][c]; y1 = L.w.c.Rl[i][3 + c]; y2 = L.w.c.Rl[i][6 + c]; }
+    else { y0 = L.w.c.Rl[i][9]; y1 = L.w.c.Rl[i][10]; y2 = L.w.c.Rl[i][11]; }
+    for (int j = L.par[i]; j >= 0; j = L.par[j]) {
+      const double *Tj = L.w.c.Rl[j];
+      const double z0 = Tj[0] * y0 + Tj[1] * y1 + Tj[2] * y2, z1 = Tj[3] * y0 + Tj[4] * y1 + Tj[5] * y2, z2 = Tj[6] * y0 + Tj[7] * y1 + Tj[8] * y2;
+      y0 = z0 + (c == 3 ? Tj[9] : 0.0); y1 = z1 + (c == 3 ? Tj[10] : 0.0); y2 = z2 + (c == 3 ? Tj[11] : 0.0);
+    }
+    if (c < 3) { L.w.c.Rw[i][c] = y0; L.w.c.Rw[i][3 + c] = y1; L.w.c.Rw[i][6 + c] = y2; }
+    else { L.w.c.pw[i][0] = y0; L.w.c.pw[i][1] = y1; L.w.c.pw[i][2] = y2; }
+  }
+  __syncthreads();
+  AGX_WG_STAMP();
   if (tid < NV) {
     const int i = tid;
-    double R[9], p[3];
-#pragma unroll
-    for (int e = 0; e < 9; ++e) R[e] = L.w.c.Rl[i][e];
-#pragma unroll
-    for (int e = 0; e < 3; ++e) p[e] = L.w.c.Rl[i][9 + e];
-    for (int j = L.par[i]; j >= 0; j = L.par[j]) {  // X <- Rl[j] o X
-      const double *Tj = L.w.c.Rl[j];
-      double t3[3];
-      mv3(Tj, p, t3);
-      p[0] = Tj[9] + t3[0]; p[1] = Tj[10] + t3[1]; p[2] = Tj[11] + t3[2];
-      mm3(Tj, R, R);
-    }
-#pragma unroll
-    for (int e = 0; e < 9; ++e) L.w.c.Rw[i][e] = R[e];
-#pragma unroll
-    for (int e = 0; e < 3; ++e) L.w.c.pw[i][e] = p[e];
+    const double *R = L.w.c.Rw[i], *p = L.w.c.pw[i];
     double z[3], S[6];
     mv3(R, m.axis[i], z);
     cross3(p, z, S);
@@ -232,166 +414,19 @@ __device__ __forceinline__ double wg_node(WgNode<NV> &L, const DevModel &m, cons
     }
   }
   __syncthreads();
+  AGX_WG_STAMP();
 
-  // ---- cost rows: thread j owns component j of the state / control terms and column j of every dense row
-  // (wave 0 only: lanes >= NV shadow the last joint and store nothing)
-  int nJ_total = 0;  // dense rows in use (uniform: a function of the row table)
-  for (int r = 0; r < rows.n; ++r) {
-    if (!rows.active[r]) continue;
-    const int kind = rows.kind[r];
-    nJ_total += kind == AGX_RES_FRAME_PLACEMENT ? 6 : ((kind == AGX_RES_FRAME_TRANSLATION || kind == AGX_RES_FRAME_ROTATION) ? 3 : (kind == AGX_RES_COLLISION ? 1 : 0));
-  }
-  if (wave == 0) {
-    int nJ = 0;
-    const int j = tid < NV ? tid : NV - 1;
-    const bool jl = tid < NV;
-    const double qj = L.x[j], vj = L.x[NV + j], uj = TERM ? 0.0 : L.u[j];
-    double cost = 0.0, Lq = 0.0, Lv = 0.0, Lu = 0.0, Lvv = 0.0, Luu = 0.0, dqq = 0.0;
-    for (int r = 0; r < rows.n; ++r) {
-      if (!rows.active[r]) continue;
-      const double *tile = L.w.c.ref + rows.off[r];
-      const double wi = tile[0];
-      const double *rr = tile + 1;
-      const double *aw = rr + rows.nref[r];
-      const int kind = rows.kind[r];
-      if (kind == AGX_RES_STATE) {
-        const double rq = qj - rr[j], rvv = vj - rr[NV + j];
-        const double wq = wi * aw[j], wv = wi * aw[NV + j];
-        cost += 0.5 * (wq * rq * rq + wv * rvv * rvv);
-        Lq += wq * rq; Lv += wv * rvv; Lvv += wv; dqq += wq;
-      } else if (kind == AGX_RES_CONTROL) {
-        if (!TERM) {
-          const double ru = uj - rr[j], wu = wi * aw[j];
-          cost += 0.5 * wu * ru * ru;
-          Lu += wu * ru; Luu += wu;
-        }
-      } else if (kind == AGX_RES_FRAME_PLACEMENT || kind == AGX_RES_FRAME_TRANSLATION || kind == AGX_RES_FRAME_ROTATION) {
-        int frame = in.frames ? in.frames[r] : -1;
-        if (frame < 0) frame = rows.frame[r];
-        double RF[9], pF[3];
-        int jf;
-        wg_frame_world<NV>(L, m, frame, RF, pF, &jf);
-        const bool on = (jf >= 0) && ((L.anc[jf >= 0 ? jf : 0] >> j) & 1u);
-        const double *Sj = L.S[j], *pj = L.w.c.pw[j];
-        double res[6], Jc[6], dl[3], tz[3], lin[3], ang[3];
-        int nr;
-        dl[0] = pF[0] - pj[0]; dl[1] = pF[1] - pj[1]; dl[2] = pF[2] - pj[2];
-        cross3(Sj + 3, dl, tz);  // z x (pF - pj)
-        if (kind == AGX_RES_FRAME_PLACEMENT) {
-          nr = 6;
-          double Rrel[9], d3[3], prel[3], TL[9], TR[9];
-          mtm3(rr, RF, Rrel);
-          d3[0] = pF[0] - rr[9]; d3[1] = pF[1] - rr[10]; d3[2] = pF[2] - rr[11];
-          mtv3(rr, d3, prel);
-          log6<DIFF>(Rrel, prel, res, TL, TR);
-          if (DIFF) {
-            mtv3(RF, tz, lin);
-            mtv3(RF, Sj + 3, ang);
-#pragma unroll
-            for (int e = 0; e < 3; ++e) {
-              Jc[e] = TL[3 * e] * lin[0] + TL[3 * e + 1] * lin[1] + TL[3 * e + 2] * lin[2] + TR[3 * e] * ang[0] + TR[3 * e + 1] * ang[1] + TR[3 * e + 2] * ang[2];
-              Jc[3 + e] = TL[3 * e] * ang[0] + TL[3 * e + 1] * ang[1] + TL[3 * e + 2] * ang[2];
-            }
-          }
-        } else if (kind == AGX_RES_FRAME_TRANSLATION) {
-          nr = 3;
-          res[0] = pF[0] - rr[0]; res[1] = pF[1] - rr[1]; res[2] = pF[2] - rr[2];
-          res[3] = res[4] = res[5] = 0.0;
-          Jc[0] = tz[0]; Jc[1] = tz[1]; Jc[2] = tz[2];
-          Jc[3] = Jc[4] = Jc[5] = 0.0;
-        } else {
-          nr = 3;
-          double Rrel[9], TL[9];
-          mtm3(rr, RF, Rrel);
-          log3(Rrel, res);
-          res[3] = res[4] = res[5] = 0.0;
-          Jc[3] = Jc[4] = Jc[5] = 0.0;
-          if (DIFF) {
-            jlog3(res, TL);
-            mtv3(RF, Sj + 3, ang);
-#pragma unroll
-            for (int e = 0; e < 3; ++e) Jc[e] = TL[3 * e] * ang[0] + TL[3 * e + 1] * ang[1] + TL[3 * e + 2] * ang[2];
-          }
-        }
-        double a = 0.0;
-#pragma unroll
-        for (int e = 0; e < 6; ++e) {
-          const double we = (e < nr) ? wi * aw[e] : 0.0;
-          a += 0.5 * we * res[e] * res[e];
-          if (DIFF && e < nr) {
-            const double jc = on ? Jc[e] : 0.0;
-            Lq += we * res[e] * jc;
-            if (jl) L.w.c.J[nJ + e][j] = jc;
-            if (tid == 0) { L.w.c.wJ[nJ + e] = we; }
-          }
-        }
-        if (tid == 0) cost += a;
-        nJ += nr;
-      } else if (kind == AGX_RES_COLLISION) {
-        // colmpc.ResidualDistanceCollision (ocp_croco_generic.py:524-533) with a scalar activation
-        double Ra[9], pa[3], Rb[9], pb[3], ca[3], cb[3], n[3];
-        int ja, jb;
-        wg_frame_world<NV>(L, m, rows.frame[r], Ra, pa, &ja);
-        wg_frame_world<NV>(L, m, rows.frame_b[r], Rb, pb, &jb);
-        const double d = collision_distance_placed(m, rows.frame[r], rows.frame_b[r], Ra, pa, Rb, pb, ca, cb, n);
-        double a, ar, arr;
-        activation1(rows.act[r], rows.alpha[r], aw[0], d, a, ar, arr);
-        if (tid == 0) cost += wi * a;
-        if (DIFF) {
-          const bool ona = (ja >= 0) && ((L.anc[ja >= 0 ? ja : 0] >> j) & 1u);
-          const bool onb = (jb >= 0) && ((L.anc[jb >= 0 ? jb : 0] >> j) & 1u);
-          const double *Sj = L.S[j], *pj = L.w.c.pw[j];
-          double da[3], db[3], ta[3], tb[3];
-#pragma unroll
-          for (int e = 0; e < 3; ++e) { da[e] = ca[e] - pj[e]; db[e] = cb[e] - pj[e]; }
-          cross3(Sj + 3, da, ta);
-          cross3(Sj + 3, db, tb);
-          const double g = (ona ? dot3(n, ta) : 0.0) - (onb ? dot3(n, tb) : 0.0);
-          Lq += wi * ar * g;
-          if (jl) L.w.c.J[nJ][j] = g;
-          if (tid == 0) L.w.c.wJ[nJ] = wi * arr;
-        }
-        nJ += 1;
-      }
-    }
-    if (jl) {
-      L.cpart[j] = cost;
-      if (DIFF) { L.Lq[j] = sc * Lq; L.Lv[j] = sc * Lv; L.Lvv[j] = sc * Lvv; L.Luu[j] = sc * Luu; L.lu[j] = sc * Lu; L.dqq[j] = dqq; L.D[j] = sc * Luu + in.preg; }
-    }
-  }
-  __syncthreads();
-  // Lqq = J' W J + diag(state weights) on the matrix cores: wave w owns tile (ti, tj) of every nv x nv block
-  const int ti = wave >> 1, tj = wave & 1, l15 = lane & 15, l4 = lane >> 4;
-  agx_v4d acc_lqq = {0.0, 0.0, 0.0, 0.0};
-  if (DIFF) {
-    for (int ks = 0; 4 * ks < nJ_total; ++ks) {
-      const int k = 4 * ks + l4;
-      const double a = L.w.c.J[k][16 * ti + l15];
-      const double bq = L.w.c.wJ[k] * L.w.c.J[k][16 * tj + l15];
-      acc_lqq = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bq, acc_lqq, 0, 0, 0);
-    }
-    if (ti == tj) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-        if (l4 + 4 * r == l15) acc_lqq[r] += L.dqq[16 * ti + l15];
-    }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) acc_lqq[r] *= sc;
-  }
-  // node cost: fixed summation order
-  double cost_tot = 0.0;
-  for (int e = 0; e < NV; ++e) cost_tot += L.cpart[e];
-  cost_tot *= sc;
-
-  if (!TERM) {
-    // ---- bias forces and joint-space inertia
-    for (int it = tid; it < NV * 6; it += NT) {  // v_i = sum over the path root..i of S_j qd_j
-      const int i = it / 6, e = it % 6;
-      double s = 0.0;
-      for (unsigned mk = L.anc[i]; mk; mk &= mk - 1) { const int j = __builtin_ctz(mk); s += L.S[j][e] * L.x[NV + j]; }
-      L.v[i][e] = s;
+  if (TERM) {
+    if (wave == 1) wg_costs<NV, TERM, DIFF>(L, m, rows, in, lane, sc);
+    __syncthreads();
+  } else {
+    // ---- bias forces and joint-space inertia; sums along the tree on the matrix cores (tiles (0, 0) and (1, 0): 6 columns)
+    if (tj == 0) {  // v_i = sum over the path root..i of S_k qd_k
+      const agx_v4d acc = wg_mask_mma(L.anc, ti, 0, lane, [&](int k, int n) { return (k < NV && n < 6) ? L.S[k][n] * L.x[NV + k] : 0.0; });
+      wg_scatter(acc, ti, 0, lane, [&](int r, int n, double val) { if (r < NV && n < 6) L.v[r][n] = val; });
     }
     __syncthreads();
+    AGX_WG_STAMP();
     if (tid < NV) {
       double Sd[6];
       mcross(L.v[tid], L.S[tid], Sd);
@@ -399,66 +434,80 @@ __device__ __forceinline__ double wg_node(WgNode<NV> &L, const DevModel &m, cons
       for (int e = 0; e < 6; ++e) L.Sd[tid][e] = Sd[e];
     }
     __syncthreads();
-    for (int it = tid; it < NV * 6; it += NT) {  // bias acceleration (qdd = 0), gravity as a base acceleration
-      const int i = it / 6, e = it % 6;
-      double s = (e < 3) ? -m.gravity[e] : 0.0;
-      for (unsigned mk = L.anc[i]; mk; mk &= mk - 1) { const int j = __builtin_ctz(mk); s += L.Sd[j][e] * L.x[NV + j]; }
-      L.w.d1.a[i][e] = s;
+    AGX_WG_STAMP();
+    if (tj == 0) {  // bias acceleration (qdd = 0), gravity as a base acceleration
+      const agx_v4d acc = wg_mask_mma(L.anc, ti, 0, lane, [&](int k, int n) { return (k < NV && n < 6) ? L.Sd[k][n] * L.x[NV + k] : 0.0; });
+      wg_scatter(acc, ti, 0, lane, [&](int r, int n, double val) { if (r < NV && n < 6) L.w.c.d1.a[r][n] = val - (n < 3 ? m.gravity[n] : 0.0); });
     }
     __syncthreads();
+    AGX_WG_STAMP();
     if (tid < NV) {
       double h6[6], g6[6], x6[6];
       iapply(L.Ib[tid], L.v[tid], h6);
-      iapply(L.Ib[tid], L.w.d1.a[tid], g6);
+      iapply(L.Ib[tid], L.w.c.d1.a[tid], g6);
       fcross(L.v[tid], h6, x6);
 #pragma unroll
-      for (int e = 0; e < 6; ++e) { L.h[tid][e] = h6[e]; L.w.d1.f[tid][e] = g6[e] + x6[e]; }
+      for (int e = 0; e < 6; ++e) L.w.c.d1.f[tid][e] = g6[e] + x6[e];
     }
     __syncthreads();
-    for (int it = tid; it < NV * 16; it += NT) {  // subtree sums: composite force (6) and composite inertia (10)
-      const int i = it >> 4, e = it & 15;
-      double s = 0.0;
-      if (e < 6) {
-        for (unsigned mk = L.desc[i]; mk; mk &= mk - 1) s += L.w.d1.f[__builtin_ctz(mk)][e];
-        L.w.d1.fc[i][e] = s;
-      } else {
-        for (unsigned mk = L.desc[i]; mk; mk &= mk - 1) s += L.Ib[__builtin_ctz(mk)][e - 6];
-        L.Ic[i][e - 6] = s;
-      }
+    AGX_WG_STAMP();
+    if (tj == 0) {  // subtree sums: composite force (columns 0..5) and composite inertia (6..15)
+      const agx_v4d acc = wg_mask_mma(L.desc, ti, 0, lane, [&](int k, int n) { return k < NV ? (n < 6 ? L.w.c.d1.f[k][n] : L.Ib[k][n - 6]) : 0.0; });
+      wg_scatter(acc, ti, 0, lane, [&](int r, int n, double val) {
+        if (r < NV) { if (n < 6) L.w.c.d1.fc[r][n] = val; else L.Ic[r][n - 6] = val; }
+      });
     }
     __syncthreads();
+    AGX_WG_STAMP();
     if (tid < NV) {
       double m6[6];
       iapply(L.Ic[tid], L.S[tid], m6);
 #pragma unroll
       for (int e = 0; e < 6; ++e) L.m6[tid][e] = m6[e];
-      const double nle = dot6(L.S[tid], L.w.d1.fc[tid]);
+      const double nle = dot6(L.S[tid], L.w.c.d1.fc[tid]);
       L.nle[tid] = nle;
       L.rhs[tid] = L.u[tid] - nle;
     }
     __syncthreads();
-    // CRBA, one thread per entry: M[r][c] = S_c . (Ic_r S_r) for c on the path to r (and its mirror image)
-    double (*Mx)[32] = L.M;
-    for (int it = tid; it < NV * NV; it += NT) {
-      const int r = it / NV, c = it % NV;
-      double val = 0.0;
-      if ((L.anc[r] >> c) & 1u) val = dot6(L.S[c], L.m6[r]);
-      else if ((L.anc[c] >> r) & 1u) val = dot6(L.S[r], L.m6[c]);
-      if (r == c) val += m.armature[r];
-      Mx[r][c] = val;
+    AGX_WG_STAMP();
+    {
+      // CRBA on the matrix cores: G = m6 S' (G[r][c] = (Ic_r S_r) . S_c) and its transpose;
+      // M[r][c] = G[r][c] for c on the path to r, G[c][r] for r on the path to c, 0 on different branches
+      const agx_v4d g1 = wg_mma<2>(ti, tj, lane, [&](int r, int k) { return (r < NV && k < 6) ? L.m6[r][k] : 0.0; },
+                                   [&](int k, int c) { return (c < NV && k < 6) ? L.S[c][k] : 0.0; }, zero4);
+      const agx_v4d g2 = wg_mma<2>(ti, tj, lane, [&](int r, int k) { return (r < NV && k < 6) ? L.S[r][k] : 0.0; },
+                                   [&](int k, int c) { return (c < NV && k < 6) ? L.m6[c][k] : 0.0; }, zero4);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int r = 16 * ti + l4 + 4 * q, c = 16 * tj + l15;
+        if (r < NV && c < NV) {
+          double val = ((L.anc[r] >> c) & 1u) ? g1[q] : (((L.anc[c] >> r) & 1u) ? g2[q] : 0.0);
+          if (r == c) val += m.armature[r];
+          L.M[r][c] = val;
+        }
+      }
     }
     __syncthreads();
+    AGX_WG_STAMP();
+    // ---- wave 0 solves M qdd = u - nle, wave 1 evaluates the cost rows meanwhile
     if (wave == 0) {
-      const double qdd = wave_spd_solve<NV>(Mx, L.rhs, lane);
+      const double qdd = wave_spd_solve<NV>(L.M, L.rhs, lane);
       if (lane < NV) {
         L.qdd[lane] = qdd;
         const double qj = L.x[lane], vj = L.x[NV + lane];
         L.fq[lane] = qj + dt * vj + dt * dt * qdd - L.xn[lane];
         L.fv[lane] = vj + dt * qdd - L.xn[NV + lane];
       }
+    } else if (wave == 1) {
+      wg_costs<NV, TERM, DIFF>(L, m, rows, in, lane, sc);
     }
     __syncthreads();
   }
+  AGX_WG_STAMP();
+  // node cost: fixed summation order
+  double cost_tot = 0.0;
+  for (int e = 0; e < NV; ++e) cost_tot += L.cpart[e];
+  cost_tot *= sc;
   if (!DIFF) {
     double g = 0.0;
     if (!TERM)
@@ -466,27 +515,38 @@ __device__ __forceinline__ double wg_node(WgNode<NV> &L, const DevModel &m, cons
     return cost_tot + in.mu_dyn * g;
   }
 
-  if (DIFF && !TERM) {
+  // Lqq = J' W J + diag(state weights) on the matrix cores (J of the frame / collision rows)
+  agx_v4d acc_lqq = zero4;
+  for (int ks = 0; 4 * ks < nJ_total; ++ks) {
+    const int k = 4 * ks + l4;
+    acc_lqq = __builtin_amdgcn_mfma_f64_16x16x4f64(L.w.c.J[k][16 * ti + l15], L.w.c.wJ[k] * L.w.c.J[k][16 * tj + l15], acc_lqq, 0, 0, 0);
+  }
+  if (ti == tj) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      if (l4 + 4 * r == l15) acc_lqq[r] += L.dqq[16 * ti + l15];
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) acc_lqq[r] *= sc;
+
+  if (!TERM) {
     // ---- RNEA derivatives (derivation: agx_device.hpp, rnea_derivatives)
-    for (int it = tid; it < NV * 6; it += NT) {
-      const int i = it / 6, e = it % 6;
-      double s = (e < 3) ? -m.gravity[e] : 0.0;
-      for (unsigned mk = L.anc[i]; mk; mk &= mk - 1) {
-        const int j = __builtin_ctz(mk);
-        s += L.S[j][e] * L.qdd[j] + L.Sd[j][e] * L.x[NV + j];
-      }
-      L.w.d3.a[i][e] = s;
+    if (tj == 0) {  // accelerations with qdd
+      const agx_v4d acc = wg_mask_mma(L.anc, ti, 0, lane, [&](int k, int n) { return (k < NV && n < 6) ? L.S[k][n] * L.qdd[k] + L.Sd[k][n] * L.x[NV + k] : 0.0; });
+      wg_scatter(acc, ti, 0, lane, [&](int r, int n, double val) { if (r < NV && n < 6) L.w.d3.a[r][n] = val - (n < 3 ? m.gravity[n] : 0.0); });
     }
     __syncthreads();
+    AGX_WG_STAMP();
     if (tid < NV) {
       const int i = tid;
-      const double *vi = L.v[i], *Si = L.S[i], *Sdi = L.Sd[i], *ai = L.w.d3.a[i], *I = L.Ib[i], *h6 = L.h[i];
-      double t1[6], t2[6];
+      const double *vi = L.v[i], *Si = L.S[i], *Sdi = L.Sd[i], *ai = L.w.d3.a[i], *I = L.Ib[i];
+      double t1[6], t2[6], h6[6];
       mcross(ai, Si, t1);
       mcross(vi, Sdi, t2);
 #pragma unroll
       for (int e = 0; e < 6; ++e) L.w.d3.psi[i][e] = t1[e] + t2[e];
       double gg[6], xx[6];
+      iapply(I, vi, h6);
       iapply(I, ai, gg);
       fcross(vi, h6, xx);
       double *pre = L.w.d3.pre[i];
@@ -516,13 +576,13 @@ __device__ __forceinline__ double wg_node(WgNode<NV> &L, const DevModel &m, cons
       for (int e = 0; e < 9; ++e) pre[9 + e] = E[e];
     }
     __syncthreads();
-    for (int it = tid; it < NV * 18; it += NT) {  // subtree sums of fC | f0 | E
-      const int i = it / 18, e = it % 18;
-      double s = 0.0;
-      for (unsigned mk = L.desc[i]; mk; mk &= mk - 1) s += L.w.d3.pre[__builtin_ctz(mk)][e];
-      L.w.d3.cmp[i][e] = s;
+    AGX_WG_STAMP();
+    {  // subtree sums of fC | f0 | E: 18 columns, all four tiles
+      const agx_v4d acc = wg_mask_mma(L.desc, ti, tj, lane, [&](int k, int n) { return (k < NV && n < 18) ? L.w.d3.pre[k][n] : 0.0; });
+      wg_scatter(acc, ti, tj, lane, [&](int r, int n, double val) { if (r < NV && n < 18) L.w.d3.cmp[r][n] = val; });
     }
     __syncthreads();
+    AGX_WG_STAMP();
     if (tid < NV) {
       const int i = tid;
       const double *Si = L.S[i], *Sdi = L.Sd[i], *psi = L.w.d3.psi[i], *Ic = L.Ic[i];
@@ -551,25 +611,33 @@ __device__ __forceinline__ double wg_node(WgNode<NV> &L, const DevModel &m, cons
       }
     }
     __syncthreads();
-    for (int it = tid; it < NV * NV; it += NT) {  // dtau/dq, dtau/dqdot: one thread per entry
-      const int r = it / NV, c = it % NV;
-      double dvv = 0.0, dqq = 0.0;
-      if ((L.anc[r] >> c) & 1u) {  // c on the path root..r
-        const double *mr = L.m6[r], *Dr = L.w.d3.col.Dt[r];
-        dvv = 2.0 * dot6(mr, L.Sd[c]) + dot3(Dr, L.S[c] + 3);
-        dqq = dot3(Dr, L.Sd[c] + 3) + dot6(mr, L.w.d3.psi[c]);
-      } else if ((L.anc[c] >> r) & 1u) {  // r a strict ancestor of c
-        dvv = dot6(L.S[r], L.w.d3.col.colv[c]);
-        dqq = dot6(L.S[r], L.w.d3.col.colq[c]);
+    AGX_WG_STAMP();
+    {
+      // dtau/dq, dtau/dqdot on the matrix cores.  Entry (r, c):
+      //   c on the path root..r:      dv = [m6_r | Dt_r] . [2 Sd_c | S_c,ang],  dq = [m6_r | Dt_r] . [psi_c | Sd_c,ang]   (k = 9)
+      //   r a strict ancestor of c:   dv = S_r . colv_c,                        dq = S_r . colq_c                        (k = 6)
+      auto fa1 = [&](int r, int k) { return r < NV ? (k < 6 ? L.m6[r][k] : (k < 9 ? L.w.d3.col.Dt[r][k - 6] : 0.0)) : 0.0; };
+      auto fa2 = [&](int r, int k) { return (r < NV && k < 6) ? L.S[r][k] : 0.0; };
+      const agx_v4d v1 = wg_mma<3>(ti, tj, lane, fa1, [&](int k, int c) { return c < NV ? (k < 6 ? 2.0 * L.Sd[c][k] : (k < 9 ? L.S[c][k - 3] : 0.0)) : 0.0; }, zero4);
+      const agx_v4d q1 = wg_mma<3>(ti, tj, lane, fa1, [&](int k, int c) { return c < NV ? (k < 6 ? L.w.d3.psi[c][k] : (k < 9 ? L.Sd[c][k - 3] : 0.0)) : 0.0; }, zero4);
+      const agx_v4d v2 = wg_mma<2>(ti, tj, lane, fa2, [&](int k, int c) { return (c < NV && k < 6) ? L.w.d3.col.colv[c][k] : 0.0; }, zero4);
+      const agx_v4d q2 = wg_mma<2>(ti, tj, lane, fa2, [&](int k, int c) { return (c < NV && k < 6) ? L.w.d3.col.colq[c][k] : 0.0; }, zero4);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int r = 16 * ti + l4 + 4 * q, c = 16 * tj + l15;
+        if (r < NV && c < NV) {
+          const bool path = (L.anc[r] >> c) & 1u, above = (L.anc[c] >> r) & 1u;
+          L.tv[r][c] = path ? v1[q] : (above ? v2[q] : 0.0);
+          L.tq[r][c] = path ? q1[q] : (above ? q2[q] : 0.0);
+        }
       }
-      L.tv[r][c] = dvv;
-      L.tq[r][c] = dqq;
     }
     __syncthreads();
+    AGX_WG_STAMP();
   }
 
   // ---- acceleration-input transformation on the matrix cores and the stores
-  agx_v4d hww = {0.0, 0.0, 0.0, 0.0}, hqw = hww, hvw = hww, hqq = acc_lqq, hqv = hww, hvv = hww;
+  agx_v4d hww = zero4, hqw = zero4, hvw = zero4, hqq = acc_lqq, hqv = zero4, hvv = zero4;
   if (ti == tj) {
 #pragma unroll
     for (int r = 0; r < 4; ++r)
@@ -592,6 +660,7 @@ __device__ __forceinline__ double wg_node(WgNode<NV> &L, const DevModel &m, cons
       hvv = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, hvv, 0, 0, 0);
     }
   }
+  AGX_WG_STAMP();
   wg_store_tile(qt + Q::Hww, hww, ti, tj, lane, NV);
   wg_store_tile(qt + Q::Hqw, hqw, ti, tj, lane, NV);
   wg_store_tile(qt + Q::Hvw, hvw, ti, tj, lane, NV);
@@ -624,6 +693,7 @@ __device__ __forceinline__ double wg_node(WgNode<NV> &L, const DevModel &m, cons
   } else if (tid == 255) {
     qt[Q::cost] = cost_tot;
   }
+  AGX_WG_STAMP();
   return cost_tot;
 }
 
