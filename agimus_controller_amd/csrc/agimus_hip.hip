@@ -582,8 +582,10 @@ int solve_resident(agx_ocp *o, int max_iter, double max_time, bool prologue_done
     prev_done = n_done;
     if (n_done >= o->B) break;
     if (max_time > 0.0) {
+      // SolverCSQP max_solve_time (ocp_base_croco.py:70-71): checked once per SQP iteration; unfinished instances
+      // report the iterations that really ran
       const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-      if (el > max_time) { need_fixup = need_fixup || !pair; break; }
+      if (el > max_time) { need_fixup = need_fixup || !pair; o->last_max_iter = it + 1; break; }
     }
   }
   if (!o->has_con && need_fixup && launch_gains(o, 2)) return -1;  // instances whose last direction has no gains sweep yet

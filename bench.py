@@ -2,16 +2,18 @@
 """bench.py -- MPC steps/s of the MI355X-native OCP solve path.
 
 One "step" = one receding-horizon MPC step (MPC.run, agimus_controller/agimus_controller/mpc.py:32-66)
-of every instance of the batch, fully device resident: horizon window of the resident sine-wave
-reference, x0 <- previous xs[1], warm-start shift, SQP solve (CSQP semantics,
-max_iter / tol of the ROS defaults), then the download of what the controller publishes
-(us[0], K[0], x1 and the solver status).  Inputs sit in HBM before the timed region starts.
+of every instance of the batch, fully device resident: horizon window of the resident reference trajectory
+(SURVEY 8(d)), x0 <- previous xs[1], warm-start shift, SQP solve (CSQP semantics, max_iter / tol of the ROS
+defaults), then the download of what the controller publishes (us[0], K[0], x1 and the solver status).
+Inputs sit in HBM before the timed region starts.
 
-  python bench.py [--gpus N --steps K --warmup W --batch B --horizon T --max-iter I]
+  python bench.py [--gpus N --steps K --warmup W --batch B --horizon T --max-iter I --workload W --scaling weak|strong]
 
-N > 1 is launched by the driver through torch.distributed.run (one rank per GPU).  Instances are
-independent, so ranks share nothing on the data path: the only collectives are the barriers and
-the MAX over ranks of the timed region.  Per-GPU work is fixed: scaling = "weak".
+N > 1 is launched by the driver through torch.distributed.run (one rank per GPU, RCCL).  Instances are
+independent, so ranks share nothing while they solve: the collectives are the barriers, the MAX over ranks of the
+timed region and, after it, one all_gather of the per-instance status words (plus, in the host_refs leg, the
+scatter of the reference tiles from rank 0 and the gather of the first-node results).
+--scaling weak (default): --batch instances PER GPU.  --scaling strong: --batch instances in total, B / N per rank.
 """
 from __future__ import annotations
 
@@ -27,34 +29,55 @@ import numpy as np
 ROOT = pathlib.Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
-from agimus_controller_amd import _abi, backend, workloads  # noqa: E402
+from agimus_controller_amd import _abi, backend, batched, workloads  # noqa: E402
 from agimus_controller_amd.factory import robot_tables as rt  # noqa: E402
 
 HBM_PEAK = 8.0e12  # B/s, /opt/skills/guides/MI355X_MICROARCH.md "HBM3E peak BW"
 # Algorithmic doubles per node and launch (nv = 7): K1 read x,u + reference tile and
 # write the 673-double derivative tile; K2+K3 one Riccati backward + one linear forward; K4 one trial.
 ALGO_DOUBLES = {"calc_qp": 775, "riccati": 778 + 448, "step": 138}
+PARITY = {
+    "sine": "pinned: golden file of the reference reproduced to 1e-9 (tests/test_oracle_golden.py, tests/test_hip_parity.py)",
+    "generic": "pinned: golden file of the reference reproduced to 1e-9 (same kernels as the sine workload)",
+    "humanoid": "pinned for the arithmetic (same algorithm as the golden case); the 30-DoF tree is synthetic, HIP == checker",
+    "collision": "UNPINNED: colmpc distance / QuadExp and the ADMM loop are recalled forms, HIP == this repository's checker only",
+    "cartesian": "UNPINNED: colmpc distance / QuadExp and the ADMM loop are recalled forms, HIP == this repository's checker only",
+}
+K1_NAME = {
+    "sine": "k_calc_qp_lj", "generic": "k_calc_qp_lj", "humanoid": "k_calc_qp_wg", "collision": "k_calc_qp", "cartesian": "k_calc_qp",
+}
+K1_TEXT = {
+    "k_calc_qp_lj": "k_calc_qp_lj (node-parallel derivative pass, running nodes, 8 lanes per node)",
+    "k_calc_qp_wg": "k_calc_qp_wg<30> (one workgroup per node: LDS-resident dynamics, tree sums and contractions on the fp64 matrix cores)",
+    "k_calc_qp": "k_calc_qp<7> (one lane per node: problems with a collision cost row do not use the 8-lane kernel yet)",
+}
+
+
+def ncores():
+    return len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=None, help="MPC instances per GPU (default: the BASELINE.json shape of the workload: "
-                                                            "1024; collision / cartesian 256; humanoid 512)")
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=None, help="MPC instances per GPU (weak scaling) or in total (strong scaling); default: the "
+                                                            "BASELINE.json shape of the workload: 1024; collision / cartesian 256; humanoid 512")
     ap.add_argument("--horizon", type=int, default=None, help="default: 100; collision / cartesian 200; humanoid 50")
     ap.add_argument("--max-iter", type=int, default=10, help="SQP iteration cap (ROS default 10)")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-batch1", action="store_true", help="skip the batch = 1 latency leg (profiling runs)")
-    ap.add_argument("--cpu-instances", type=int, default=0, help="instances of the CPU sample (0 = 2 per core)")
+    ap.add_argument("--no-batch1", action="store_true", help="skip the extra legs (batch 1 latency, max_iter 3, full download, host refs): profiling runs")
+    ap.add_argument("--cpu-instances", type=int, default=0, help="instances of the CPU sample (0 = 2 per core, at most 256)")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU work the baseline sample is sized for")
     ap.add_argument("--loop", choices=("prediction", "feedback"), default="prediction",
                     help="how the next measured state is produced: previous xs[1] (the reference's dummy_mpc_test) or the Riccati "
                          "feedback law rolled out on the model at 1 kHz (SURVEY 8(f-3))")
     ap.add_argument("--workload", choices=("sine", "generic", "humanoid", "collision", "cartesian"), default="sine",
-                    help="sine: BASELINE configs[1] (the headline); generic: configs[3] generic_trajectory + pick-and-place costs; "
-                         "humanoid: configs[4] synthetic 30-DoF tree (use --horizon 50 --batch 512); "
-                         "collision: configs[2] shape, collision-avoidance cost + distance constraint (use --horizon 200 --batch 256)")
+                    help="sine: BASELINE configs[1] at batch 1024 (the headline); generic: configs[3] generic_trajectory + pick-and-place costs; "
+                         "humanoid: configs[4] synthetic 30-DoF tree (T 50, B 512); collision / cartesian: configs[2], collision-avoidance cost "
+                         "+ distance constraint (T 200, B 256) with configuration-space / cartesian sine references")
     args = ap.parse_args()
     shape = {"collision": (256, 200), "cartesian": (256, 200), "humanoid": (512, 50)}.get(args.workload, (1024, 100))
     if args.batch is None:
@@ -103,87 +126,96 @@ def make_problem(T, workload="sine"):
     return table, tcp, po
 
 
-def cpu_baseline(args, table, tcp, po, n_steps=24):
-    """The same MPC steps on the host cores with the CPU restatement under oracle/ ("port", OpenMP
-    over the instances): a bounded sample of the workload (first instances, first steps)."""
+class HostRefs:
+    """The reference tiles of the resident trajectory rebuilt on the host, sample by sample, from what
+    agx_traj_get_point returns (q, dq, ddq, feed-forward effort, end-effector pose): what a caller without the
+    device-side generators hands to agx_ocp_set_refs (OCPCrocoGeneric.set_reference_weighted_trajectory,
+    ocp_croco_generic.py:855-892).  Mirrors k_sine_fill row by row."""
+
+    def __init__(self, hip, po, w, n_samples, n_inst):
+        self.po, self.T, self.nv = po, po.horizon, po.nv
+        nv = self.nv
+        self.run = np.zeros((n_inst, n_samples, po.stride))
+        self.term = np.zeros((n_inst, n_samples, po.stride))
+        self.x = np.zeros((n_inst, n_samples, 2 * nv))
+        self.u = np.zeros((n_inst, n_samples, nv))
+        bc = lambda v, n: np.broadcast_to(np.asarray(v, dtype=float), (n,))  # noqa: E731
+        for k in range(n_samples):
+            q, v, a, u, pose = (z[:n_inst] for z in hip.traj_point(k))
+            self.x[:, k], self.u[:, k] = np.concatenate([q, v], 1), u
+            for rows, offs, dst in ((po.running, po.running_offsets, self.run), (po.terminal, po.terminal_offsets, self.term)):
+                for r, off in zip(rows, offs):
+                    seg = dst[:, k, off:]
+                    seg[:, 0] = r.weight
+                    if r.kind == _abi.RES_STATE:
+                        seg[:, 1:1 + 2 * nv] = self.x[:, k]
+                        seg[:, 1 + 2 * nv:1 + 3 * nv], seg[:, 1 + 3 * nv:1 + 4 * nv] = bc(w["w_q"], nv), bc(w["w_qdot"], nv)
+                    elif r.kind == _abi.RES_CONTROL:
+                        seg[:, 1:1 + nv], seg[:, 1 + nv:1 + 2 * nv] = u, bc(w["w_effort"], nv)
+                    elif r.kind == _abi.RES_FRAME_PLACEMENT:
+                        seg[:, 1:13], seg[:, 13:19] = pose, bc(w["w_pose"], 6)
+
+    def first(self, n):
+        sub = HostRefs.__new__(HostRefs)
+        sub.po, sub.T, sub.nv = self.po, self.T, self.nv
+        sub.run, sub.term, sub.x, sub.u = self.run[:n], self.term[:n], self.x[:n], self.u[:n]
+        return sub
+
+    def window(self, k0, out=None):
+        T = self.T
+        out = np.empty((self.run.shape[0], T + 1, self.po.stride)) if out is None else out
+        out[:, :T] = self.run[:, k0:k0 + T]
+        out[:, T] = self.term[:, k0 + T]
+        return out
+
+
+def cpu_baseline(args, table, po, refs: HostRefs, seconds):
+    """The same MPC steps on the host cores with the CPU restatement under oracle/ ("port", OpenMP over the
+    instances): a bounded sample of the workload (first instances, first steps), sized for ~`seconds` of CPU work."""
     from oracle.oracle import Oracle  # test infrastructure: only this leg of bench.py uses it
 
-    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    cores = avail
-    B = args.cpu_instances or min(2 * avail, 256)
-    T, dt = args.horizon, 0.01
-    q0, amp, puls, scale, t0 = workloads.sine_batch_params(B, lower=table.lower_position_limit, upper=table.upper_position_limit)
+    avail = ncores()
+    B, T = refs.run.shape[0], args.horizon
     o = Oracle(table, po, B)
-    w = workloads.SINE_WEIGHTS
-    running, terminal = po.running, po.terminal
-
-    def sample(k):
-        t = t0 + k * dt
-        s = np.clip(t[:, None] / scale, 0.0, 1.0)
-        ramp = 10 * s**3 - 15 * s**4 + 6 * s**5
-        dramp = np.where((s > 0) & (s < 1), (30 * s**2 - 60 * s**3 + 30 * s**4) / scale, 0.0)
-        ddramp = np.where((s > 0) & (s < 1), (60 * s - 180 * s**2 + 120 * s**3) / scale**2, 0.0)
-        sw, cw = np.sin(puls * t[:, None]), np.cos(puls * t[:, None])
-        q = q0 + amp * ramp * sw
-        dq = amp * (dramp * sw + ramp * puls * cw)
-        ddq = amp * (ddramp * sw + 2 * dramp * puls * cw - ramp * puls**2 * sw)
-        return q, dq, o.rnea(q, dq, ddq).reshape(B, 7), o.frame_placement(tcp, q)
-
-    pts = [sample(k) for k in range(T + 1 + n_steps)]
-
-    def window(k0):
-        ref = po.new_ref_tile(B)
-        for t in range(T + 1):
-            q, dq, u, pose = pts[k0 + t]
-            rows, offs = (terminal, po.terminal_offsets) if t == T else (running, po.running_offsets)
-            for r, off in zip(rows, offs):
-                seg = ref[:, t, off:]
-                seg[:, 0] = 1.0
-                if r.kind == _abi.RES_STATE:
-                    seg[:, 1:15] = np.concatenate([q, dq], 1)
-                    seg[:, 15:22], seg[:, 22:29] = w["w_q"], w["w_qdot"]
-                elif r.kind == _abi.RES_CONTROL:
-                    seg[:, 1:8], seg[:, 8:15] = u, w["w_effort"]
-                else:
-                    seg[:, 1:13], seg[:, 13:19] = pose, w["w_pose"]
-        return ref
-
-    refs = [window(k) for k in range(n_steps)]
-    xs = np.stack([np.concatenate([p[0], p[1]], 1) for p in pts[: T + 1]], 1)
-    us = np.stack([p[2] for p in pts[:T]], 1)
-    x0 = xs[:, 0].copy()
-    # thread count: the best of a few candidates on one untimed iteration (big hosts oversubscribe easily)
+    xs0, us0 = refs.x[:, : T + 1].copy(), refs.u[:, :T].copy()
+    x0 = xs0[:, 0].copy()
+    ref0 = refs.window(0)
+    # thread count: the best of a few candidates on one untimed SQP iteration (big hosts oversubscribe easily)
     best = None
     for nt in sorted({min(avail, c) for c in (16, 32, 64, avail)}):
-        o.solve(refs[0], None, x0, xs, us, 1, nthreads=nt)  # thread pool / page warm-up
+        o.solve(ref0, None, x0, xs0, us0, 1, nthreads=nt)  # thread pool / page warm-up
         t0 = time.perf_counter()
-        o.solve(refs[0], None, x0, xs, us, 1, nthreads=nt)
+        o.solve(ref0, None, x0, xs0, us0, 1, nthreads=nt)
         el = time.perf_counter() - t0
         if best is None or el < best[0]:
             best = (el, nt)
     cores = best[1]
+    o.reset_duals()
+    n_max = refs.run.shape[1] - T - 1
+    xs, us = xs0, us0
+    iters, n_steps = [], 0
     t_start = time.perf_counter()
-    iters = []
-    for k in range(n_steps):
-        if k > 0:
+    while n_steps < n_max and (n_steps < 2 or time.perf_counter() - t_start < seconds):
+        if n_steps > 0:
             x0 = xs[:, 1].copy()
             xs, us = o.shift_warmstart(xs, us)
-        xs, us, K, st = o.solve(refs[k], None, x0, xs, us, args.max_iter, nthreads=cores)
+        xs, us, K, st = o.solve(refs.window(n_steps), None, x0, xs, us, args.max_iter, nthreads=cores)
         iters.append(float(st["iter"].mean()))
+        n_steps += 1
     el = time.perf_counter() - t_start
     # the reference's default n_threads = 1 (ocp_param_base.py:65): one instance on one thread, same MPC loop
     o1 = Oracle(table, po, 1)
-    xs1 = np.stack([np.concatenate([p[0][:1], p[1][:1]], 1) for p in pts[: T + 1]], 1)
-    us1 = np.stack([p[2][:1] for p in pts[:T]], 1)
+    xs1, us1 = xs0[:1].copy(), us0[:1].copy()
     x01 = xs1[:, 0].copy()
-    o1.solve(refs[0][:1], None, x01, xs1, us1, 1, nthreads=1)
+    o1.solve(ref0[:1], None, x01, xs1, us1, 1, nthreads=1)
+    o1.reset_duals()
     t1 = time.perf_counter()
     n1 = 0
-    for k in range(min(n_steps, 12)):
-        if k > 0:
+    while n1 < n_max and (n1 < 2 or time.perf_counter() - t1 < seconds / 3.0):
+        if n1 > 0:
             x01 = xs1[:, 1].copy()
             xs1, us1 = o1.shift_warmstart(xs1, us1)
-        xs1, us1, _, _ = o1.solve(refs[k][:1], None, x01, xs1, us1, args.max_iter, nthreads=1)
+        xs1, us1, _, _ = o1.solve(refs.window(n1)[:1], None, x01, xs1, us1, args.max_iter, nthreads=1)
         n1 += 1
     el1 = time.perf_counter() - t1
     return {
@@ -193,7 +225,8 @@ def cpu_baseline(args, table, tcp, po, n_steps=24):
         "cores": cores,
         "kind": "port",
         "sample": f"{B} instances x {n_steps} steps of the same workload (T={T}), OpenMP over instances; "
-                  f"CPU restatement (oracle/), not the Crocoddyl/mim_solvers binaries; mean SQP iters {np.mean(iters):.2f}",
+                  f"CPU restatement with automatic differentiation (oracle/), not the Crocoddyl/mim_solvers binaries; "
+                  f"mean SQP iters {np.mean(iters):.2f}",
         "seconds": el,
     }
 
@@ -203,13 +236,14 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    dist = None
+    dist = torch = None
+    rehearsal = False
     if world > 1:
         import torch
         import torch.distributed as dist
 
         # AGX_BENCH_REHEARSAL=1: every rank on cuda:0 with the gloo backend -- lets the N > 1 code path (seeding by
-        # global instance index, barriers, MAX of the timed region, rank-0 report) run on a one-GPU box
+        # global instance index, barriers, MAX of the timed region, status gather, rank-0 report) run on a one-GPU box
         rehearsal = os.environ.get("AGX_BENCH_REHEARSAL", "0") == "1"
         if rehearsal:
             local_rank = 0
@@ -218,16 +252,24 @@ def main():
         else:
             torch.cuda.set_device(local_rank)
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    coll_dev = "cpu" if (rehearsal or world == 1) else "cuda"  # tensors of the collectives: RCCL moves device memory
 
-    B, T, dt = args.batch, args.horizon, 0.01
+    T, dt = args.horizon, 0.01
+    if args.scaling == "strong":
+        lo, hi = batched.shard_bounds(args.batch, rank, world)
+        B, first_instance, global_batch = hi - lo, lo, args.batch
+    else:
+        B, first_instance, global_batch = args.batch, rank * args.batch, world * args.batch
     table, tcp, po = make_problem(T, args.workload)
     hip = backend.HipOcp(table, po, B, device=local_rank)
-    n_points = args.warmup + max(args.steps, 200) + T + 2 + 32  # + in-situ profile steps + full-download steps
+    n_extra = 0 if args.no_batch1 else 40
+    n_points = args.warmup + args.steps + T + 2 + min(10, T // 2) + n_extra  # + in-situ profile steps + the extra legs
     # per-instance seeds follow the GLOBAL instance index so every rank works on different instances
     nv = table.nv
-    q0, amp, puls, scale, t0 = workloads.sine_batch_params(B, nv=nv, seed0=1234 + rank * B, q0=(None if nv == 7 else np.zeros(nv)),
+    seed0 = 1234 + first_instance
+    q0, amp, puls, scale, t0 = workloads.sine_batch_params(B, nv=nv, seed0=seed0, q0=(None if nv == 7 else np.zeros(nv)),
                                                            lower=table.lower_position_limit, upper=table.upper_position_limit)
-    w = workloads.SINE_WEIGHTS
+    w = dict(workloads.SINE_WEIGHTS)
     if args.workload == "humanoid":
         hip.sine_trajectory(n_points, dt, q0, amp, puls, scale, t0, w["w_q"], w["w_qdot"], w["w_effort"], w["w_pose"], tcp)
         workload_name = "synthetic 30-DoF humanoid tree (seed 7) sine_wave_configuration_space, goal-reaching costs"
@@ -238,7 +280,7 @@ def main():
     elif args.workload == "cartesian":
         # BASELINE configs[2] as written: sine_wave_cartesian_space references (lockstep inverse kinematics of the batch,
         # outside the timed region) resident in HBM as q/dq/ddq arrays, collision-avoidance costs + constraint
-        cq0, camp, cpuls = workloads.cartesian_sine_batch_params(B, seed0=1234 + rank * B, lower=table.lower_position_limit,
+        cq0, camp, cpuls = workloads.cartesian_sine_batch_params(B, seed0=seed0, lower=table.lower_position_limit,
                                                                  upper=table.upper_position_limit)
         gq, gdq, gddq = workloads.cartesian_sine_batch_arrays(hip, tcp, n_points, dt, cq0, camp, cpuls)
         hip.generic_trajectory(gq, gdq, gddq, w["w_q"], w["w_qdot"], w["w_effort"], w["w_pose"], tcp)
@@ -252,7 +294,7 @@ def main():
         # BASELINE configs[3]: q/dq/ddq arrays from seeded smooth random accelerations (tests/test_generic_trajectory.py:147-160
         # upstream), pick-and-place cost set and weights (trajectory_weigths_params.yaml:4-9)
         w = dict(w_q=3.0, w_qdot=0.12, w_effort=8e-4, w_pose=0.0)
-        gq, gdq, gddq = workloads.generic_batch_arrays(B, n_points, dt, seed0=1234 + rank * B, q0=q0)
+        gq, gdq, gddq = workloads.generic_batch_arrays(B, n_points, dt, seed0=seed0, q0=q0)
         hip.generic_trajectory(gq, gdq, gddq, w["w_q"], w["w_qdot"], w["w_effort"], w["w_pose"], tcp)
         workload_name = "Panda 7-DoF generic_trajectory (seeded smooth random accelerations), pick-and-place costs (control_reg + state_reg)"
 
@@ -266,8 +308,6 @@ def main():
 
     def sync_all():
         if dist is not None:
-            import torch
-
             dist.barrier()
             torch.cuda.synchronize()
         hip.sync()
@@ -283,52 +323,75 @@ def main():
         iters_max.append(int(st["iter"].max()))
     sync_all()
     elapsed = time.perf_counter() - t_start
-    solved_frac = float(st["solved"].mean())
+    solved_local = np.asarray(st["solved"], dtype=np.float64).copy()
+    iter_local = np.asarray(st["iter"], dtype=np.float64).copy()
+    solved_frac, status_ranks = float(solved_local.mean()), 1
     if dist is not None:
-        import torch
-
-        tt = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        tt = torch.tensor([elapsed], device=coll_dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
+        # the step closes with ONE all_gather of the per-instance status words; ranks may hold B or B +- 1
+        # instances under strong scaling: padded to the largest shard
+        bmax = -(-global_batch // world) if args.scaling == "strong" else B
+        mine = torch.full((bmax, 2), -1.0, dtype=torch.float64, device=coll_dev)
+        mine[:B, 0] = torch.from_numpy(solved_local).to(coll_dev)
+        mine[:B, 1] = torch.from_numpy(iter_local).to(coll_dev)
+        every = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        allst = torch.cat(every).cpu().numpy()
+        valid = allst[:, 0] >= 0
+        solved_frac, status_ranks = float(allst[valid, 0].mean()), world
+        assert int(valid.sum()) == global_batch, (int(valid.sum()), global_batch)
 
     # per-kernel device time, measured live and in situ: a few more MPC steps of the same loop with
     # HIP events around every launch on the solver's stream (outside the timed region above)
     kernels = {}
+    k_next = args.warmup + args.steps
+    n_prof = min(10, T // 2)
     if rank == 0:
         nodes = {"calc_qp": B * T, "riccati": B * (T + 1), "step": B * (T + 1)}
         ALGO = algo_doubles(nv)
         hip.profile(True)
-        k0 = args.warmup + args.steps
-        for k in range(k0, k0 + min(10, T // 2)):
-            if k + T + 1 <= n_points:
-                step(k)
+        for k in range(k_next, k_next + n_prof):
+            step(k)
         ms_sum, cnt = hip.profile(False)
         for i, name in enumerate(("calc_qp", "riccati", "step")):
             ms = ms_sum[i] / max(cnt[i], 1)
             algo = ALGO[name] * 8 * nodes[name]
             kernels[name] = {"ms": ms, "launches": cnt[i], "algorithmic_bytes": algo, "GBps": algo / (ms * 1e-3) / 1e9,
                              "frac_hbm": algo / (ms * 1e-3) / HBM_PEAK}
+    else:
+        for k in range(k_next, k_next + n_prof):
+            step(k)
+    k_next += n_prof
 
     result = None
+    extra = world == 1 and not args.no_batch1
     if rank == 0:
         k1 = kernels["calc_qp"]
-        traffic = None
-        tfile = ROOT / "profiles" / "pmc_traffic.json"  # HBM bytes per launch from separate rocprofv3 --pmc passes
+        # HBM bytes from separate rocprofv3 --pmc passes (scripts/collect_profiles.sh), committed under profiles/:
+        # never measured by this run
+        traffic, step_traffic, tsrc = None, None, None
+        tfile = ROOT / "profiles" / "pmc_traffic.json"
         if tfile.exists():
             try:
-                traffic = json.loads(tfile.read_text()).get(f"k_calc_qp_lj,B={B},T={T}")
+                doc = json.loads(tfile.read_text())
+                traffic = doc.get(f"{K1_NAME[args.workload]},B={B},T={T}")
+                step_traffic = doc.get(f"step:{args.workload},B={B},T={T}")
+                tsrc = doc.get("_source")
             except Exception:
                 traffic = None
+        ms_step = elapsed / args.steps * 1e3
         result = {
             "metric": "MPC steps/sec (horizon=100, Panda 7-DoF)",
-            "value": world * B * args.steps / elapsed,
+            "value": global_batch * args.steps / elapsed,
             "unit": "MPC steps/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3,
+            "ms_per_step": ms_step,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
@@ -338,40 +401,47 @@ def main():
                             + ("closed loop on own prediction" if args.loop == "prediction" else "closed loop through the Riccati feedback rollout at 1 kHz"),
                 "horizon": T,
                 "batch_per_gpu": B,
-                "global_batch": world * B,
+                "global_batch": global_batch,
                 "max_iter": args.max_iter,
                 "termination_tolerance": 1e-3,
-                "parallelism": f"batch-sharded x{world}, no data-path collective",
+                "parallelism": f"batch-sharded x{world} ({args.scaling} scaling), no collective while solving; "
+                               f"status words of {status_ranks} rank(s) all_gathered after the timed region",
+                "parity": PARITY[args.workload],
                 "mean_sqp_iters_per_step": float(np.mean(iters)),
                 "mean_sqp_iters_of_slowest_instance": float(np.mean(iters_max)),  # what a batch step costs
                 "solved_fraction_last_step": solved_frac,
                 "step_includes": "window select, x0<-xs[1], warm-start shift, SQP solve, D2H of us[0],K[0],x1,status",
             },
             "roofline": {
-                "kernel": "k_calc_qp_lj (node-parallel derivative pass, running nodes, 8 lanes per node)",
+                "kernel": K1_TEXT[K1_NAME[args.workload]],
                 "bound": "hbm",
                 "achieved": k1["GBps"],
                 "peak": HBM_PEAK / 1e9,
                 "unit": "GB/s",
                 "frac": k1["frac_hbm"],
                 "traffic": traffic,
+                "traffic_source": ((tsrc or "profiles/pmc_traffic.json") + " (separate rocprofv3 --pmc passes, not measured by this run)") if traffic else None,
                 "avg_launch_ms": k1["ms"],
                 "algorithmic_bytes_per_launch": k1["algorithmic_bytes"],
             },
             "kernels": kernels,
         }
+        if step_traffic:
+            # all kernels of one MPC step: counter bytes (profiles/) over the step time of THIS run
+            result["roofline_step"] = {"traffic_per_step": step_traffic, "GBps": step_traffic / (ms_step * 1e-3) / 1e9,
+                                       "frac": step_traffic / (ms_step * 1e-3) / HBM_PEAK,
+                                       "note": "HBM bytes of every kernel of one MPC step (profiles/, WRITE_SIZE + 2 FETCH_SIZE) / ms_per_step of this run"}
         if args.workload in ("collision", "cartesian"):
             result["metric"] = f"MPC steps/sec (horizon={T}, Panda 7-DoF, collision avoidance)"
-            result["roofline"]["kernel"] = "k_calc_qp<7> (one lane per node: problems with a collision cost row do not use the 8-lane kernel yet)"
         if args.workload == "humanoid":
             result["metric"] = f"MPC steps/sec (horizon={T}, 30-DoF humanoid)"
-            result["roofline"]["kernel"] = "k_calc_qp_wg<30> (one workgroup per node: LDS-resident dynamics, fp64 MFMA contractions)"
-        if world == 1 and not args.no_batch1 and args.workload == "sine":
+        if extra and args.workload == "sine":
             # BASELINE.json configs[1]: the same workload at batch = 1 (latency of one controller)
             h1 = backend.HipOcp(table, po, 1, device=local_rank)
             p1 = workloads.sine_batch_params(1, lower=table.lower_position_limit, upper=table.upper_position_limit)
-            h1.sine_trajectory(n_points, dt, *p1, w["w_q"], w["w_qdot"], w["w_effort"], w["w_pose"], tcp)
-            n1 = min(200, n_points - T - 2 - args.warmup)
+            n1 = 200
+            np1 = args.warmup + n1 + T + 2
+            h1.sine_trajectory(np1, dt, *p1, w["w_q"], w["w_qdot"], w["w_effort"], w["w_pose"], tcp)
             for k in range(args.warmup):
                 h1.mpc_step(k, args.max_iter, first=(k == 0))
                 h1.download_first(copy=False)
@@ -388,34 +458,72 @@ def main():
                                 "steps": int(len(lat)), "value": 1e3 / ms1, "unit": "MPC steps/s",
                                 "workload": "same, batch = 1 (BASELINE.json configs[1]); per-step host wall time incl. D2H"}
             h1.close()
-        if world == 1 and not args.no_batch1 and args.max_iter != 3:
+        if extra and args.max_iter != 3:
             # also the pick-and-place iteration cap (max_iter 3) on the same workload
-            ka = args.warmup + args.steps + min(10, T // 2)
             na = 8
             hip.sync()
             t1 = time.perf_counter()
-            for k in range(ka, ka + na):
+            for k in range(k_next, k_next + na):
                 hip.mpc_step(k, 3, first=False)
                 hip.download_first(copy=False)
             hip.sync()
             msa = (time.perf_counter() - t1) / na * 1e3
+            k_next += na
             result["max_iter_3"] = {"ms_per_step": msa, "value": B / (msa * 1e-3), "unit": "MPC steps/s",
                                     "note": "same workload with the pick-and-place cap max_iter = 3"}
-        if world == 1 and not args.no_batch1:
+        if extra:
             # the same step with the FULL result download (xs, us, K of every node) into pageable memory
-            kf = args.warmup + args.steps + min(10, T // 2) + 8
             t1 = time.perf_counter()
             nfull = 3
-            for k in range(kf, kf + nfull):
+            for k in range(k_next, k_next + nfull):
                 hip.mpc_step(k, args.max_iter, first=False)
                 hip.download()
             msf = (time.perf_counter() - t1) / nfull * 1e3
+            k_next += nfull
             result["full_download"] = {"ms_per_step": msf, "value": B / (msf * 1e-3), "unit": "MPC steps/s",
                                        "bytes_per_step": int(8 * B * ((T + 1) * 2 * nv + T * nv + T * 2 * nv * nv)),
                                        "note": "PCIe-inclusive: xs, us, K of all nodes copied to host every step"}
-        if not args.no_cpu_baseline and world == 1 and args.workload == "sine":
+    # ---- host_refs leg (the step as the reference's caller sees it): the reference tiles of every step come
+    # from the host (agx_ocp_set_refs: H2D of [B][T+1][stride]), then shift + solve + download of the first-node results.
+    # With N > 1 ranks the tiles of the whole job originate on rank 0 and travel through batched.scatter_rows (RCCL
+    # point-to-point), the first-node results go back through gather_rows: the data-path payload of SURVEY 8(e).
+    host_leg = not args.no_batch1
+    n_cpu = args.cpu_instances or min(2 * ncores(), 256, B)
+    want_cpu = rank == 0 and world == 1 and not args.no_cpu_baseline
+    refs = None
+    if host_leg:
+        refs = HostRefs(hip, po, w, min(n_points, max(k_next + T + 8, T + 1 + 64)), B)
+    elif want_cpu:
+        refs = HostRefs(hip, po, w, T + 1 + 64, n_cpu)
+    if host_leg:
+        nh, n_glob = 5, (global_batch if args.scaling == "strong" else world * B)
+        tile = np.empty((B, T + 1, po.stride))
+        sync_all()
+        t1 = time.perf_counter()
+        for k in range(k_next, k_next + nh):
+            mine = refs.window(k, tile)
+            if world > 1:
+                full = batched.gather_rows(mine, n_glob, device=coll_dev)   # (stands in for rank 0 owning the generator)
+                mine = batched.scatter_rows(full, n_glob, device=coll_dev)  # the scatter of the step's inputs
+            hip.set_refs(mine)
+            hip.x0_from_prediction()
+            hip.shift_warmstart()
+            hip.solve_resident(args.max_iter)
+            us0, K0, x1, _ = hip.download_first(copy=True)
+            if world > 1:
+                batched.gather_rows(np.concatenate([us0, K0.reshape(B, -1), x1], 1), n_glob, device=coll_dev)
+        sync_all()
+        msh = (time.perf_counter() - t1) / nh * 1e3
+        if rank == 0:
+            result["host_refs"] = {"ms_per_step": msh, "value": global_batch / (msh * 1e-3), "unit": "MPC steps/s",
+                                   "h2d_bytes_per_step_per_gpu": int(tile.nbytes),
+                                   "note": "PCIe-inclusive: reference tiles [B][T+1][stride] built on the host and uploaded every step "
+                                           "(agx_ocp_set_refs), shift, solve, first-node download"
+                                           + ("; tiles scattered from / results gathered to rank 0 over RCCL" if world > 1 else "")}
+    if rank == 0:
+        if want_cpu:
             try:
-                result["cpu_baseline"] = cpu_baseline(args, table, tcp, po)
+                result["cpu_baseline"] = cpu_baseline(args, table, po, refs.first(n_cpu), args.cpu_seconds)
             except Exception as e:  # the GPU numbers stand on their own
                 result["cpu_baseline"] = {"value": None, "unit": "MPC steps/s", "cores": os.cpu_count(), "kind": "port",
                                           "sample": f"failed: {e!r}"}
