@@ -29,7 +29,7 @@ EXPORTED_SYMBOLS = [
     "agx_ocp_shift_warmstart", "agx_ocp_x0_from_prediction", "agx_ocp_integrate", "agx_model_rnea",
     "agx_model_frame_placement", "agx_ocp_get_residuals", "agx_ocp_calc_diff", "agx_ocp_direction",
     "agx_ocp_time_kernel", "agx_ocp_profile", "agx_traj_sine_create", "agx_traj_set_window",
-    "agx_traj_get_point", "agx_traj_warmstart_from_reference", "agx_ocp_mpc_step", "agx_ocp_qp_tiles",
+    "agx_traj_get_point", "agx_traj_warmstart_from_reference", "agx_ocp_mpc_step", "agx_ocp_qp_tiles", "agx_ocp_set_quorum",
 ]  # fmt: skip
 
 
@@ -242,6 +242,10 @@ class HipOcp:
     def set_geom_placement(self, frame: int, se3_12):
         """OCPBaseCroco.update_geometry_placement (ocp_base_croco.py:110-132) for a geometry frame."""
         _chk(lib().agx_ocp_set_geom_placement(self._h, int(frame), _p(_f8(se3_12).reshape(12))))
+
+    def set_quorum(self, sqp_fraction: float = 1.0, qp_fraction: float = 1.0):
+        """Batch policy: end the SQP / ADMM loops once this fraction of the instances has finished (see agimus_hip.h)."""
+        _chk(lib().agx_ocp_set_quorum(self._h, C.c_double(sqp_fraction), C.c_double(qp_fraction)))
 
     def reset_duals(self):
         _chk(lib().agx_ocp_reset_duals(self._h))

@@ -65,7 +65,13 @@ struct agx_ocp {
   bool lanes_ok = true;  // problem fits the LDS staging of the 8-lanes-per-node kernel
   bool speculate = true;  // AGX_SPECULATE_GAINS=0: gains sweep only on exit
   bool gains_mfma = true; // AGX_GAINS_MFMA=0: scalar K = M Kw - taux for large models
+  bool riccati_mfma = true;  // AGX_RICCATI_MFMA=0: large models sweep with the LDS Gauss-Jordan kernel (k_riccati_big)
   bool k1_fused = true;     // AGX_K1_FUSED=0: running and terminal nodes of the derivative pass as two launches (profiling)
+  // Batch policy (agx_ocp_set_quorum): the SQP loop of a batch step ends once this fraction of the instances has
+  // finished, the ADMM loop of an SQP iteration once this fraction of the QPs has converged; the others keep their
+  // iterate (solved = 0 / qp_iters = max_qp_iters) and continue from it at the next MPC step, as a lone controller
+  // that ran into max_solve_time would.  1.0 = wait for everyone (the default).
+  double quorum_sqp = 1.0, quorum_qp = 1.0;
   bool queue_ahead = true;  // AGX_QUEUE_AHEAD=0: next derivative pass only after the host saw the finished count (profiling: no empty launches)
   double *d_ref = nullptr;  // owned tile [B][T+1][stride]
   int *d_frames = nullptr;  // owned [B][T+1][AGX_MAX_ROWS]
@@ -309,6 +315,12 @@ int launch_riccati(agx_ocp *o, int forward, bool pair = false, int iter = 0, con
                            o->d_Kws, o->d_kws, o->d_dx, o->d_w, o->d_du, o->d_Kout, o->d_state, forward, 0);
     } else {
       (void)pair; (void)iter;
+      if constexpr (NV > 16) if (o->riccati_mfma) {
+        hipLaunchKernelGGL((agx::k_riccati_mfma<NV>), dim3(o->B), dim3(256), 0, o->stream, o->d_ocp, o->d_dt, qt, o->d_Kws, o->d_kws, o->d_dx,
+                           o->d_w, o->d_state, forward, 0);
+        HIPCHK(hipGetLastError());
+        return 0;
+      }
       hipLaunchKernelGGL((agx::k_riccati_big<NV>), dim3(o->B), dim3(256), 0, o->stream, o->d_ocp, o->d_dt, qt, o->d_Kws, o->d_kws, o->d_dx,
                          o->d_w, o->d_state, forward, 0);
     }
@@ -385,6 +397,13 @@ int launch_gains(agx_ocp *o, int gmode = 0) {
       // large models: sigma-augmented tiles, LDS sweep, gains to u-space -- for every instance
       const long long nodes = (long long)o->B * (o->T + 1);
       hipLaunchKernelGGL((agx::k_sigma_tile_big<NV>), dim3((int)nodes), dim3(256), 0, o->stream, o->d_ocp, o->d_qt, o->d_qt2, o->d_aux);
+      bool swept = false;
+      if constexpr (NV > 16) if (o->riccati_mfma) {
+        hipLaunchKernelGGL((agx::k_riccati_mfma<NV>), dim3(o->B), dim3(256), 0, o->stream, o->d_ocp, o->d_dt, o->d_qt2, o->d_Kws, o->d_kws,
+                           o->d_dx, o->d_w, o->d_state, 0, 1);
+        swept = true;
+      }
+      if (!swept)
       hipLaunchKernelGGL((agx::k_riccati_big<NV>), dim3(o->B), dim3(256), 0, o->stream, o->d_ocp, o->d_dt, o->d_qt2, o->d_Kws, o->d_kws,
                          o->d_dx, o->d_w, o->d_state, 0, 1);
       if constexpr (NV > 16) {
@@ -474,6 +493,12 @@ int read_int(agx_ocp *o, const int *d_value, int slot_value, int slot_seq, int *
   return 0;
 }
 
+int quorum_count(int B, double q) {
+  if (!(q < 1.0)) return B;
+  const int n = (int)std::ceil(q * B - 1e-9);
+  return n < 1 ? 1 : (n > B ? B : n);
+}
+
 // Constrained direction of one SQP iteration (SolverCSQP::computeDirection): the plain LQR pass has
 // run (equality-QP initial guess: dx, w); now du, the constraint data and the ADMM loop.
 int admm_direction(agx_ocp *o) {
@@ -508,7 +533,13 @@ int admm_direction(agx_ocp *o) {
       if (iter % 4 == 0 || iter == max_qp) {
         int n_conv = 0;
         if (read_int(o, o->d_ndone + 1, 4, 5, &n_conv)) return -1;
-        if (n_conv >= o->B) break;
+        if (n_conv >= quorum_count(o->B, o->quorum_qp)) {
+          if (n_conv < o->B && iter < max_qp) {  // quorum reached: the others stop here with the iterations they ran
+            hipLaunchKernelGGL(agx::k_admm_cap, dim3((o->B + 255) / 256), dim3(256), 0, o->stream, o->d_state, o->B, iter);
+            HIPCHK(hipGetLastError());
+          }
+          break;
+        }
       }
     }
     // the gains the solver reports: those of the last ADMM backward pass, in u-space
@@ -580,7 +611,10 @@ int solve_resident(agx_ocp *o, int max_iter, double max_time, bool prologue_done
     const int n_done = (int)__atomic_load_n(o->h_ndone, __ATOMIC_ACQUIRE);
     if (!pair && n_done > prev_done) need_fixup = true;
     prev_done = n_done;
-    if (n_done >= o->B) break;
+    if (n_done >= quorum_count(o->B, o->quorum_sqp)) {
+      if (n_done < o->B) o->last_max_iter = it + 1;  // the stragglers stop here: iterations that really ran
+      break;
+    }
     if (max_time > 0.0) {
       // SolverCSQP max_solve_time (ocp_base_croco.py:70-71): checked once per SQP iteration; unfinished instances
       // report the iterations that really ran
@@ -723,6 +757,7 @@ int agx_ocp_create(const agx_model *m, const agx_ocp_desc *d, int batch, int dev
   if (const char *e = getenv("AGX_K1_LANES")) o->k1_lanes = (e[0] != '0');
   if (const char *e = getenv("AGX_SPECULATE_GAINS")) o->speculate = (e[0] != '0');
   if (const char *e = getenv("AGX_GAINS_MFMA")) o->gains_mfma = (e[0] != '0');
+  if (const char *e = getenv("AGX_RICCATI_MFMA")) o->riccati_mfma = (e[0] != '0');
   if (const char *e = getenv("AGX_QUEUE_AHEAD")) o->queue_ahead = (e[0] != '0');
   if (const char *e = getenv("AGX_K1_FUSED")) o->k1_fused = (e[0] != '0');
   o->T = d->horizon; o->B = batch; o->device = device;
@@ -897,6 +932,15 @@ int agx_ocp_sync(agx_ocp *o) {
   if (!o) return fail("null handle");
   if (set_device(o)) return -1;
   HIPCHK(hipStreamSynchronize(o->stream));
+  return 0;
+}
+
+int agx_ocp_set_quorum(agx_ocp *o, double sqp_fraction, double qp_fraction) {
+  if (!o) return fail("null handle");
+  if (!(sqp_fraction > 0.0 && sqp_fraction <= 1.0) || !(qp_fraction > 0.0 && qp_fraction <= 1.0))
+    return fail("agx_ocp_set_quorum: fractions must be in (0, 1]");
+  o->quorum_sqp = sqp_fraction;
+  o->quorum_qp = qp_fraction;
   return 0;
 }
 

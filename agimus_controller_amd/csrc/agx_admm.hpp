@@ -522,6 +522,15 @@ __global__ void __launch_bounds__(128) k_admm_reduce(const DevOcp *__restrict__ 
   }
 }
 
+// The host left the ADMM loop at iteration `iter` with a quorum of converged QPs (agx_ocp_set_quorum): the others
+// go on with the iterate they have, and report the iterations they ran.
+__global__ void k_admm_cap(DevState *__restrict__ st, int B, int iter) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  DevState &S = st[b];
+  if (!S.done && !S.admm_conv) S.admm_iter = iter;
+}
+
 // K = M Kw - taux: one lane per (node, column of K); the gains of the last ADMM backward pass
 template <int NV>
 __global__ void __launch_bounds__(256) k_gains_to_u(const DevOcp *__restrict__ op, const double *__restrict__ auxs,

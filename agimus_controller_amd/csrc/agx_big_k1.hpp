@@ -797,3 +797,234 @@ __global__ void k_shift_copy(const double *__restrict__ dts, double *__restrict_
 }
 
 }  // namespace agx
+
+namespace agx {
+
+// ---------------------------------------------------------------------------
+// K2 for large models, matrix-core version.  One 256-thread workgroup per instance; per node
+//   * Qww, Qxw = Qwx', qw, qx from the QP tile and the value function of node t+1: element-wise thanks to the
+//     (Phi, G) structure of the acceleration-input QP (as in the register kernel), coalesced tile reads;
+//   * Kw = Qww^-1 Qwx, kw = Qww^-1 qw: every wave keeps the rows of [Qww | a quarter of the right-hand sides] in
+//     registers, a row per lane, 30 Gauss-Jordan pivots with v_readlane broadcasts: no barrier inside the elimination;
+//   * V = Qxx - Qxw Kw  (60 x 30 x 60) on v_mfma_f64_16x16x4_f64, wave w owns row band w of the 4 x 4 tiles;
+//     the accumulators start at Qxx, built in the result layout.
+// (k_riccati_big above: Gauss-Jordan on the whole 90 x 91 matrix in LDS, two barriers per pivot, kept as AGX_RICCATI_MFMA=0.)
+// ---------------------------------------------------------------------------
+template <int NV>
+__global__ void __launch_bounds__(256) k_riccati_mfma(const DevOcp *__restrict__ op, const double *__restrict__ dts,
+                                                      const double *__restrict__ qts, double *__restrict__ Kws,
+                                                      double *__restrict__ kws, double *__restrict__ dxs,
+                                                      double *__restrict__ wss, const DevState *__restrict__ st, int forward,
+                                                      int gains_pass) {
+  static_assert(NV > 16 && NV <= 32 && NV % 2 == 0, "tiling below: 2 nv <= 64 result rows, nv / 2 right-hand sides per wave");
+  constexpr int NX = 2 * NV, LV = NX + 1, LQ = NV + 1, NR = NV / 2 + 1;  // right-hand sides per wave: NV / 2 columns of Qwx (+ qw on wave 3)
+  typedef QT<NV> Q;
+  __shared__ double V[NX][LV], Qxw[NX][LQ], Qww[NV][LQ], Kl[NV][LV];
+  __shared__ double vx[NX], vp[NX], fl[NX], qx[NX], qw[NV], kl[NV], dxl[NX], wl[NV];
+  const DevOcp &o = *op;
+  const int T = o.T, b = blockIdx.x, tid = threadIdx.x, nt = 256, lane = tid & 63, wave = tid >> 6;
+  const int l15 = lane & 15, l4 = lane >> 4;
+  const DevState &S = st[b];
+  if (!gains_pass && (S.done || S.admm_conv)) return;
+  const double dreg = gains_pass ? (S.solved ? S.dreg : S.gains_dreg) : S.dreg;
+  const double *qb = qts + (long long)b * (T + 1) * Q::SIZE;
+  double *Kw = Kws + (long long)b * T * NV * NX, *kw = kws + (long long)b * T * NV;
+  {  // value function of the terminal node
+    const double *tt = qb + (long long)T * Q::SIZE;
+    for (int e = tid; e < NV * NV; e += nt) {
+      const int r = e / NV, c = e % NV;
+      const double hqq = tt[Q::Hqq + r * Q::LD + c], hqv = tt[Q::Hqv + r * Q::LD + c], hvv = tt[Q::Hvv + r * Q::LD + c];
+      V[r][c] = hqq + (r == c ? dreg : 0.0);
+      V[r][NV + c] = hqv;
+      V[NV + c][r] = hqv;
+      V[NV + r][NV + c] = hvv + (r == c ? dreg : 0.0);
+    }
+    for (int i = tid; i < NX; i += nt) vx[i] = gains_pass ? 0.0 : tt[Q::gx + i];
+  }
+  __syncthreads();
+  // Tile entries travel global -> registers one node ahead (the sweep is a dependent chain of ~10 us steps: an
+  // un-prefetched HBM read per phase would sit on it): this thread's entries of Hww | Hqw | Hvw for the element-wise
+  // build (coalesced rows) and of Hqq | Hqv | Hvv in the MFMA result layout for the start value of the accumulators.
+  constexpr int NE = (NV * NV + 255) / 256;
+  double pw[NE], pq[NE], pv[NE], px[4][4], pf = 0.0, pgw = 0.0, pgq = 0.0, pgv = 0.0;
+  // result-layout bookkeeping of this lane: entry (i, j) = (16 wave + l4 + 4 q, 16 tj + l15) of the 2nv x 2nv matrix
+  auto fetch = [&](int t) {
+    const double *tl = qb + (long long)t * Q::SIZE;
+#pragma unroll
+    for (int n = 0; n < NE; ++n) {
+      const int e = tid + 256 * n, r = e / NV, c = e % NV, rc = r * Q::LD + c;
+      const bool in = e < NV * NV;
+      pw[n] = in ? tl[Q::Hww + rc] : 0.0; pq[n] = in ? tl[Q::Hqw + rc] : 0.0; pv[n] = in ? tl[Q::Hvw + rc] : 0.0;
+    }
+#pragma unroll
+    for (int tj = 0; tj < 4; ++tj)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int i = 16 * wave + l4 + 4 * q, j = 16 * tj + l15;
+        const int bi = i >= NV, bj = j >= NV, r = i - bi * NV, c = j - bj * NV;
+        // (q, q): Hqq[r][c]   (q, v): Hqv[r][c]   (v, q): Hqv[c][r]   (v, v): Hvv[r][c]
+        const int off = (bi && !bj) ? Q::Hqv + c * Q::LD + r : ((bi ? Q::Hvv : (bj ? Q::Hqv : Q::Hqq)) + r * Q::LD + c);
+        px[tj][q] = (i < NX && j < NX) ? tl[off] : 0.0;
+      }
+    if (!gains_pass) {
+      if (tid < NX) pf = tl[Q::f + tid];
+      if (tid < NV) { pgw = tl[Q::gw + tid]; pgq = tl[Q::gx + tid]; pgv = tl[Q::gx + NV + tid]; }
+    }
+  };
+  fetch(T - 1);
+  for (int t = T - 1; t >= 0; --t) {
+    const double h = dts[t], h2 = h * h;
+    if (tid < NX) fl[tid] = gains_pass ? 0.0 : pf;
+    const double gw_t = pgw, gq_t = pgq, gv_t = pgv;
+    __syncthreads();
+    if (tid < NX) {  // vp = vx + V f
+      double s = vx[tid];
+      for (int j = 0; j < NX; ++j) s += V[tid][j] * fl[j];
+      vp[tid] = s;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int n = 0; n < NE; ++n) {
+      const int e = tid + 256 * n, r = e / NV, c = e % NV;
+      if (e < NV * NV) {
+        const double Vqq = V[r][c], Vqv = V[r][NV + c], Vvq = V[NV + r][c], Vvv = V[NV + r][NV + c];
+        const double Yq = h2 * Vqq + h * Vvq, Yv = h2 * Vqv + h * Vvv;    // (G' V) blocks, rows = acceleration index
+        const double YqT = h2 * Vqq + h * Vqv, YvT = h2 * Vvq + h * Vvv;  // their transposes at [r][c]
+        Qww[r][c] = pw[n] + h2 * Yq + h * Yv;
+        Qxw[r][c] = pq[n] + YqT;
+        Qxw[NV + r][c] = pv[n] + h * YqT + YvT;
+      }
+    }
+    if (tid < NV) {
+      const double vpq = vp[tid], vpv = vp[NV + tid];
+      qw[tid] = gains_pass ? 0.0 : gw_t + h2 * vpq + h * vpv;
+      qx[tid] = gains_pass ? 0.0 : gq_t + vpq;
+      qx[NV + tid] = gains_pass ? 0.0 : gv_t + h * vpq + vpv;
+    }
+    // start value of the accumulators: Qxx = Hxx + Phi' V Phi in the result layout, branch free:
+    //   value = H + a0 V[r][c] + a1 V[r][nv + c] + a2 V[nv + r][c] + a3 V[nv + r][nv + c],
+    //   (a0..a3) = (1, 0, 0, 0) on (q, q), (h, 1, 0, 0) on (q, v), (h, 0, 1, 0) on (v, q), (h^2, h, h, 1) on (v, v)
+    agx_v4d acc[4];
+#pragma unroll
+    for (int tj = 0; tj < 4; ++tj) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int i = 16 * wave + l4 + 4 * q, j = 16 * tj + l15;
+        const bool in = i < NX && j < NX;
+        const int bi = i >= NV, bj = j >= NV, r = in ? i - bi * NV : 0, c = in ? j - bj * NV : 0;
+        const double a0 = bi ? (bj ? h2 : h) : (bj ? h : 1.0), a1 = bj ? (bi ? h : 1.0) : 0.0, a2 = bi ? (bj ? h : 1.0) : 0.0, a3 = (bi && bj) ? 1.0 : 0.0;
+        const double val = px[tj][q] + a0 * V[r][c] + a1 * V[r][NV + c] + a2 * V[NV + r][c] + a3 * V[NV + r][NV + c];
+        acc[tj][q] = in ? val : 0.0;
+      }
+    }
+    if (t > 0) fetch(t - 1);  // next node's tile entries are on their way during the elimination
+    __syncthreads();
+    {
+      // ---- Kw = Qww^-1 Qwx, kw = Qww^-1 qw: lane r = row r of [Qww | right-hand sides of this wave]
+      const int r = lane < NV ? lane : NV - 1;
+      double a[NV], y[NR];
+#pragma unroll
+      for (int j = 0; j < NV; ++j) a[j] = Qww[r][j];
+      const int c0 = (NV / 2) * wave;  // x columns c0 .. c0 + NV / 2 - 1
+#pragma unroll
+      for (int j = 0; j < NV / 2; ++j) y[j] = Qxw[c0 + j][r];
+      y[NV / 2] = qw[r];  // every wave carries it (only wave 3 stores it)
+      double d = 1.0;
+#pragma unroll
+      for (int k = 0; k < NV; ++k) {
+        const double piv = readlane_f64(a[k], k);
+        const double rp = fast_rcp(piv);
+        const double f = (lane == k) ? 0.0 : a[k] * rp;
+        if (r == k) d = rp;
+#pragma unroll
+        for (int j = k + 1; j < NV; ++j) a[j] -= f * readlane_f64(a[j], k);
+#pragma unroll
+        for (int j = 0; j < NR; ++j) y[j] -= f * readlane_f64(y[j], k);
+      }
+      if (lane < NV) {
+#pragma unroll
+        for (int j = 0; j < NV / 2; ++j) Kl[r][c0 + j] = y[j] * d;
+        if (wave == 3) kl[r] = y[NV / 2] * d;
+      }
+    }
+    __syncthreads();
+    // ---- V <- Qxx - Qxw Kw: wave w owns rows 16 w .. 16 w + 15 of the 64 x 64 result
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      const int k = 4 * ks + l4, i = 16 * wave + l15;
+      const double av = (k < NV && i < NX) ? -Qxw[i][k] : 0.0;
+#pragma unroll
+      for (int tj = 0; tj < 4; ++tj) {
+        const int j = 16 * tj + l15;
+        const double bv = (k < NV && j < NX) ? Kl[k][j] : 0.0;
+        acc[tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc[tj], 0, 0, 0);
+      }
+    }
+    double vxn = 0.0;
+    if (tid < NX) {  // gradient of the value function of node t
+      double s = qx[tid];
+      for (int k = 0; k < NV; ++k) s -= Qxw[tid][k] * kl[k];
+      vxn = s;
+    }
+    __syncthreads();  // every read of the old V / Qxw is done
+#pragma unroll
+    for (int tj = 0; tj < 4; ++tj)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int i = 16 * wave + l4 + 4 * q, j = 16 * tj + l15;
+        if (i < NX && j < NX) V[i][j] = acc[tj][q];
+      }
+    if (tid < NX) vx[tid] = vxn;
+    // gains of this node to HBM, whole rows
+    for (int e = tid; e < NV * NX; e += nt) Kw[(long long)t * NV * NX + e] = Kl[e / NX][e % NX];
+    if (tid < NV) kw[(long long)t * NV + tid] = kl[tid];
+    __syncthreads();
+    for (int e = tid; e < NX * NX; e += nt) {  // symmetrise in place: one thread per unordered pair
+      const int i = e / NX, j = e % NX;
+      if (i > j) continue;
+      const double sv = 0.5 * (V[i][j] + V[j][i]) + ((i == j) ? dreg : 0.0);
+      V[i][j] = sv;
+      V[j][i] = sv;
+    }
+    __syncthreads();
+  }
+  if (gains_pass || !forward) return;
+  // ---- forward pass: w = -kw - Kw dx (8 lanes per row, columns strided over them), then the state update
+  double *dx = dxs + (long long)b * (T + 1) * NX, *ws = wss + (long long)b * T * NV;
+  if (tid < NX) { dxl[tid] = 0.0; dx[tid] = 0.0; }
+  __threadfence_block();
+  __syncthreads();
+  for (int t = 0; t < T; ++t) {
+    const double *tl = qb + (long long)t * Q::SIZE;
+    const double h = dts[t], h2 = h * h;
+    {
+      const int r = tid >> 3, p = tid & 7;
+      double s = 0.0;
+      if (r < NV) {
+        const double *kr = Kw + ((long long)t * NV + r) * NX;
+        for (int c = p; c < NX; c += 8) s += kr[c] * dxl[c];
+      }
+      s += dpp_xor1(s); s += dpp_xor2(s); s += dpp_xor4(s);
+      if (r < NV && p == 0) {
+        const double wv = -(kw[(long long)t * NV + r] + s);
+        wl[r] = wv;
+        ws[(long long)t * NV + r] = wv;
+      }
+    }
+    __syncthreads();
+    double nq = 0.0, nv2 = 0.0;
+    if (tid < NV) {
+      nq = dxl[tid] + h * dxl[NV + tid] + h2 * wl[tid] + tl[Q::f + tid];
+      nv2 = dxl[NV + tid] + h * wl[tid] + tl[Q::f + NV + tid];
+    }
+    __syncthreads();
+    if (tid < NV) {
+      dxl[tid] = nq; dxl[NV + tid] = nv2;
+      dx[(long long)(t + 1) * NX + tid] = nq;
+      dx[(long long)(t + 1) * NX + NV + tid] = nv2;
+    }
+    __syncthreads();
+  }
+}
+
+}  // namespace agx

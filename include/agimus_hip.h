@@ -187,6 +187,14 @@ int agx_ocp_sync(agx_ocp *ocp);
  * (R row major 9 | p 3, in the parent joint frame; world for parent -1) of a geometry frame,
  * e.g. a moving obstacle.  Applies to every instance of the handle.              */
 int agx_ocp_set_geom_placement(agx_ocp *ocp, int frame, const double *se3);
+/* Batch policy -- no counterpart upstream, where every controller is its own process (mpc.py:14-19) and a slow solve
+ * delays only itself.  In a batch the SQP loop of one step runs until EVERY instance has finished; with a quorum
+ * below 1 it ends as soon as that fraction has, and the ADMM loop of an SQP iteration as soon as that fraction of
+ * the QPs has converged.  The remaining instances keep their current iterate and report solved = 0 (qp_iters =
+ * max_qp_iters): exactly what a lone controller returns when it runs into max_iter / max_solve_time
+ * (ocp_base_croco.py:160-171); the next MPC step continues from that iterate through the warm-start shift.
+ * Defaults 1.0 / 1.0: wait for everyone.                                            */
+int agx_ocp_set_quorum(agx_ocp *ocp, double sqp_fraction, double qp_fraction);
 /* Constrained problems keep the ADMM multipliers y and the penalty rho between solves, as the
  * reference's solver object does (SolverCSQP reset_y = reset_rho = false).  This forgets them:
  * the state of a freshly constructed solver.                                      */
