@@ -63,6 +63,7 @@ struct agx_ocp {
   int qt_size = 0, aux_size = 0;
   bool k1_lanes = true;  // AGX_K1_LANES=0 selects the one-lane-per-node derivative kernel
   bool lanes_ok = true;  // problem fits the LDS staging of the 8-lanes-per-node kernel
+  bool lanes_coll = false;  // ... in its variant with one collision cost row
   bool speculate = true;  // AGX_SPECULATE_GAINS=0: gains sweep only on exit
   bool gains_mfma = true; // AGX_GAINS_MFMA=0: scalar K = M Kw - taux for large models
   bool riccati_mfma = true;  // AGX_RICCATI_MFMA=0: large models sweep with the LDS Gauss-Jordan kernel (k_riccati_big)
@@ -267,21 +268,26 @@ int launch_calc_qp(agx_ocp *o, bool running_only = false, bool term_only = false
     }
     bool lanes = false;
     if constexpr (NV <= 7) lanes = CH && o->k1_lanes && o->lanes_ok;
-    if constexpr (NV <= 7) if (lanes && o->k1_fused && !term_only && !running_only) {
-      // both node types in one launch
+    if constexpr (NV <= 7) if (lanes) {
       const int n_run = (int)((units * 8 + 63) / 64), n_term = (int)(((long long)o->B * 8 + 63) / 64);
-      hipLaunchKernelGGL((agx::k_calc_qp_lj_all<NV>), dim3(n_run + n_term), dim3(64), 0, o->stream, o->d_model, o->d_ocp, o->d_dt, o->d_xs,
-                         o->d_us, o->rv, o->d_qt, o->d_aux, o->d_state, n_run);
+#define AGX_LAUNCH_LJ(COLL)                                                                                                              \
+  do {                                                                                                                                   \
+    if (o->k1_fused && !term_only && !running_only) { /* both node types in one launch */                                                \
+      hipLaunchKernelGGL((agx::k_calc_qp_lj_all<NV, COLL>), dim3(n_run + n_term), dim3(64), 0, o->stream, o->d_model, o->d_ocp, o->d_dt, \
+                         o->d_xs, o->d_us, o->rv, o->d_qt, o->d_aux, o->d_state, n_run);                                                \
+    } else {                                                                                                                             \
+      if (!term_only)                                                                                                                    \
+        hipLaunchKernelGGL((agx::k_calc_qp_lj<NV, false, COLL>), dim3(n_run), dim3(64), 0, o->stream, o->d_model, o->d_ocp, o->d_dt,     \
+                           o->d_xs, o->d_us, o->rv, o->d_qt, o->d_aux, o->d_state);                                                     \
+      if (!running_only)                                                                                                                 \
+        hipLaunchKernelGGL((agx::k_calc_qp_lj<NV, true, COLL>), dim3(n_term), dim3(64), 0, o->stream, o->d_model, o->d_ocp, o->d_dt,     \
+                           o->d_xs, o->d_us, o->rv, o->d_qt, o->d_aux, o->d_state);                                                     \
+    }                                                                                                                                    \
+  } while (0)
+      if (o->lanes_coll) AGX_LAUNCH_LJ(true); else AGX_LAUNCH_LJ(false);
+#undef AGX_LAUNCH_LJ
       HIPCHK(hipGetLastError());
       return 0;
-    }
-    if constexpr (NV <= 7) if (lanes) {
-      if (!term_only)
-      hipLaunchKernelGGL((agx::k_calc_qp_lj<NV, false>), dim3((int)((units * 8 + 63) / 64)), dim3(64), 0, o->stream, o->d_model,
-                         o->d_ocp, o->d_dt, o->d_xs, o->d_us, o->rv, o->d_qt, o->d_aux, o->d_state);
-      if (!running_only)
-        hipLaunchKernelGGL((agx::k_calc_qp_lj<NV, true>), dim3((int)(((long long)o->B * 8 + 63) / 64)), dim3(64), 0, o->stream,
-                           o->d_model, o->d_ocp, o->d_dt, o->d_xs, o->d_us, o->rv, o->d_qt, o->d_aux, o->d_state);
     }
     if constexpr (NV > 8) {
       // large models: one workgroup per node, running and terminal nodes in one launch (agx_big_k1.hpp)
@@ -799,8 +805,10 @@ int agx_ocp_create(const agx_model *m, const agx_ocp_desc *d, int batch, int dev
       for (int i = 0; i < r.n; ++i) n += (r.kind[i] == AGX_RES_COLLISION);
       return n;
     };
+    // at most one collision cost row per node type, capsule / sphere / box pair, serial chain: the COLL variant
+    o->lanes_coll = n_collision_rows(o->ho.rows[0]) + n_collision_rows(o->ho.rows[1]) > 0;
     o->lanes_ok = o->stride <= agx::kLjRef && n_frame_rows(o->ho.rows[0]) <= 2 && n_frame_rows(o->ho.rows[1]) <= 2 &&
-                  n_collision_rows(o->ho.rows[0]) + n_collision_rows(o->ho.rows[1]) == 0 && !o->general;
+                  n_collision_rows(o->ho.rows[0]) <= 1 && n_collision_rows(o->ho.rows[1]) <= 1 && !o->general;
   }
   if (o->nv > 8) {
     // the workgroup-per-node kernels stage the reference tile and the dense residual rows of a node in LDS

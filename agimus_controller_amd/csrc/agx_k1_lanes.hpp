@@ -80,21 +80,21 @@ __device__ __forceinline__ double g_sum(double x) {
 
 // per-node LDS tile (doubles).  Phase 1 (dynamics): S, m6, Sd, psi, Dt.  Phase 2 (after the
 // derivative matrices exist) reuses the same storage for tq, tv and the frame Jacobian J.
-constexpr int kLjRef = 64;  // reference-tile doubles staged in LDS per node (larger tiles use the one-lane-per-node kernel)
+constexpr int kLjRef = 72;  // reference-tile doubles staged in LDS per node (larger tiles use the one-lane-per-node kernel)
 // Per-node LDS tile.  The kernel runs in three phases that reuse the same storage:
 //   c  (costs):      the node's reference tile, the frames its cost rows use, the frame Jacobian J
 //   d1 (dynamics):   S, m6 = Ic S, Dt of every joint (the all-to-all operands of CRBA / RNEA derivatives)
 //   d2 (transform):  the full dtau/dq, dtau/dqdot matrices
 struct LjNode {
   union {
-    struct { double ref[kLjRef], frm[2][14], J[8][6]; } c;
+    struct { double ref[kLjRef], frm[4][14], J[8][6]; } c;  // frm: two frame rows, the two geometry frames of a collision row
     struct { double S[8][6], m6[8][6], Dt[8][4]; } d1;
     struct { double tq[8][8], tv[8][8]; } d2;
   } u;
   double M[8][8];
   double vec[3][8];  // rhs / lu / D
-  int fpar[4];       // parent joints of the staged frames
-  double pad[2];     // keeps the node stride an odd multiple of 2 doubles (bank spread over the 8 nodes of a wave)
+  int fpar[4];       // parent joints of the staged frames | their row indices
+  int cpar[4];       // collision row: parent joints of the two geometry frames, row index, unused
 };
 // joint constants of the model, staged once per wave: placement 12 | axis 3 | com 3 | inertia 9 | mass | armature
 struct LjModel {
@@ -104,7 +104,10 @@ struct LjModel {
 #ifndef AGX_K1_WAVES
 #define AGX_K1_WAVES 2
 #endif
-template <int NV, bool TERM>
+// COLL: the row table may hold ONE ResidualDistanceCollision cost row (closest points of the pair evaluated redundantly by
+// the 8 lanes of the node, lane j its own column of the distance gradient); a template flag because the narrow-phase code
+// would otherwise cost the collision-free kernel registers.
+template <int NV, bool TERM, bool COLL = false>
 __device__ __forceinline__ void calc_qp_lj_body(const long long blk, LjNode *lds, LjModel &lmod, const DevModel *__restrict__ mp,
                                                 const DevOcp *__restrict__ op, const double *__restrict__ dts,
                                                 const double *__restrict__ xs, const double *__restrict__ us, const RefView &rv,
@@ -165,6 +168,14 @@ __device__ __forceinline__ void calc_qp_lj_body(const long long blk, LjNode *lds
       for (int e = l8; e < 12; e += 8) L.u.c.frm[slot][e] = m.frame_placement[frame][e];
       if (l8 == 0) { L.fpar[slot] = m.frame_parent[frame]; L.fpar[2 + slot] = r; }
       ++slot;
+    }
+    if constexpr (COLL) {
+      for (int r = 0; r < rows.n; ++r) {
+        if (rows.kind[r] != AGX_RES_COLLISION) continue;
+        for (int e = l8; e < 12; e += 8) { L.u.c.frm[2][e] = m.frame_placement[rows.frame[r]][e]; L.u.c.frm[3][e] = m.frame_placement[rows.frame_b[r]][e]; }
+        if (l8 == 0) { L.cpar[0] = m.frame_parent[rows.frame[r]]; L.cpar[1] = m.frame_parent[rows.frame_b[r]]; L.cpar[2] = r; }
+        break;
+      }
     }
   }
   const double grav[3] = {m.gravity[0], m.gravity[1], m.gravity[2]};
@@ -333,6 +344,55 @@ __device__ __forceinline__ void calc_qp_lj_body(const long long blk, LjNode *lds
         for (int e = 0; e < 6; ++e) acc += we[e] * L.u.c.J[i][e] * Jc[e];
         Lqqc[i] += acc;
       }
+    }
+  }
+  if constexpr (COLL) {
+    // colmpc.ResidualDistanceCollision (ocp_croco_generic.py:524-533) with a scalar activation: one row per problem here
+    for (int r = 0; r < rows.n; ++r) {
+      if (rows.kind[r] != AGX_RES_COLLISION) continue;
+      if (!rows.active[r]) break;
+      const double *tile = L.u.c.ref + rows.off[r];
+      const double wi = tile[0], aw0 = tile[1 + rows.nref[r]];
+      double Rg[2][9], pg[2][3];
+#pragma unroll
+      for (int g = 0; g < 2; ++g) {
+        const double *fpl = L.u.c.frm[2 + g];
+        const int jf = L.cpar[g];
+        if (jf >= 0) {
+          double Rp[9], pp[3], tt[3];
+#pragma unroll
+          for (int e = 0; e < 9; ++e) Rp[e] = g_bc(R[e], jf);
+#pragma unroll
+          for (int e = 0; e < 3; ++e) pp[e] = g_bc(p[e], jf);
+          mm3(Rp, fpl, Rg[g]);
+          mv3(Rp, fpl + 9, tt);
+          pg[g][0] = pp[0] + tt[0]; pg[g][1] = pp[1] + tt[1]; pg[g][2] = pp[2] + tt[2];
+        } else {
+#pragma unroll
+          for (int e = 0; e < 9; ++e) Rg[g][e] = fpl[e];
+#pragma unroll
+          for (int e = 0; e < 3; ++e) pg[g][e] = fpl[9 + e];
+        }
+      }
+      double ca[3], cb[3], nn[3];
+      const double d = collision_distance_placed(m, rows.frame[r], rows.frame_b[r], Rg[0], pg[0], Rg[1], pg[1], ca, cb, nn);
+      double a, ar, arr;
+      activation1(rows.act[r], rows.alpha[r], aw0, d, a, ar, arr);
+      if (l8 == 0) cost += wi * a;
+      const bool ona = jl && (l8 <= L.cpar[0]), onb = jl && (l8 <= L.cpar[1]);
+      double da[3], db[3], ta[3], tb[3];
+#pragma unroll
+      for (int e = 0; e < 3; ++e) { da[e] = ca[e] - p[e]; db[e] = cb[e] - p[e]; }
+      cross3(S + 3, da, ta);
+      cross3(S + 3, db, tb);
+      const double gj = (ona ? dot3(nn, ta) : 0.0) - (onb ? dot3(nn, tb) : 0.0);
+      Lq += wi * ar * gj;
+      wave_lds_sync();  // previous users of the J tile are done
+      L.u.c.J[l8][0] = gj;
+      wave_lds_sync();
+#pragma unroll
+      for (int i = 0; i < NV; ++i) Lqqc[i] += wi * arr * L.u.c.J[i][0] * gj;
+      break;
     }
   }
   wave_lds_sync();  // the cost phase's LDS (reference tile, frames, J) is dead from here on
@@ -620,20 +680,20 @@ __device__ __forceinline__ void calc_qp_lj_body(const long long blk, LjNode *lds
 }
 
 // Separate launches (timing, terminal-only / running-only callers)
-template <int NV, bool TERM>
+template <int NV, bool TERM, bool COLL = false>
 __global__ void __launch_bounds__(64, AGX_K1_WAVES) k_calc_qp_lj(const DevModel *__restrict__ mp, const DevOcp *__restrict__ op,
                                                     const double *__restrict__ dts, const double *__restrict__ xs,
                                                     const double *__restrict__ us, RefView rv, double *__restrict__ qts,
                                                     double *__restrict__ auxs, const DevState *__restrict__ st) {
   __shared__ LjNode lds[8];  // one wave per workgroup: 8 nodes
   __shared__ LjModel lmod;
-  calc_qp_lj_body<NV, TERM>(blockIdx.x, lds, lmod, mp, op, dts, xs, us, rv, qts, auxs, st);
+  calc_qp_lj_body<NV, TERM, COLL>(blockIdx.x, lds, lmod, mp, op, dts, xs, us, rv, qts, auxs, st);
 }
 
 // The derivative pass of one SQP iteration in ONE launch: the first n_run workgroups take the running
 // nodes, the rest the terminal nodes (wave-uniform branch, shared LDS declarations): the short
 // terminal launch and its dispatch gap disappear behind the tail of the running nodes.
-template <int NV>
+template <int NV, bool COLL = false>
 __global__ void __launch_bounds__(64, AGX_K1_WAVES) k_calc_qp_lj_all(const DevModel *__restrict__ mp, const DevOcp *__restrict__ op,
                                                         const double *__restrict__ dts, const double *__restrict__ xs,
                                                         const double *__restrict__ us, RefView rv, double *__restrict__ qts,
@@ -641,9 +701,9 @@ __global__ void __launch_bounds__(64, AGX_K1_WAVES) k_calc_qp_lj_all(const DevMo
   __shared__ LjNode lds[8];
   __shared__ LjModel lmod;
   if ((int)blockIdx.x < n_run)
-    calc_qp_lj_body<NV, false>(blockIdx.x, lds, lmod, mp, op, dts, xs, us, rv, qts, auxs, st);
+    calc_qp_lj_body<NV, false, COLL>(blockIdx.x, lds, lmod, mp, op, dts, xs, us, rv, qts, auxs, st);
   else
-    calc_qp_lj_body<NV, true>((long long)blockIdx.x - n_run, lds, lmod, mp, op, dts, xs, us, rv, qts, auxs, st);
+    calc_qp_lj_body<NV, true, COLL>((long long)blockIdx.x - n_run, lds, lmod, mp, op, dts, xs, us, rv, qts, auxs, st);
 }
 
 }  // namespace agx
