@@ -54,7 +54,7 @@ __device__ int g_wg_n;
 template <int NV>
 struct WgNode {
   static constexpr int LDM = 32;
-  double M[NV][LDM], tq[NV][LDM], tv[NV][LDM];  // columns >= NV stay zero (MFMA operands)
+  alignas(16) double M[NV][LDM], tq[NV][LDM], tv[NV][LDM];  // columns >= NV stay zero (MFMA operands); copied out as double2
   double S[NV][6], Sd[NV][6], v[NV][6], m6[NV][6];
   double Ib[NV][10], Ic[NV][10];
   double x[2 * NV], u[NV], xn[2 * NV];
@@ -155,12 +155,19 @@ __device__ __forceinline__ void wg_scatter(const agx_v4d &acc, int ti, int tj, i
   for (int q = 0; q < 4; ++q) f(16 * ti + (lane >> 4) + 4 * q, 16 * tj + (lane & 15), acc[q]);
 }
 
+// Tile (ti, tj) of a 32-column block to HBM as 16-byte stores: neighbouring lanes (columns c, c + 1) swap one value so
+// that the even lane owns [row a][c .. c + 1] and the odd lane [row b][c - 1 .. c] of a pair of result rows (a, b):
+// half as many store instructions, every row segment still a whole 128-byte line (columns nv..31 carry zeros).
 __device__ __forceinline__ void wg_store_tile(double *__restrict__ blk, const agx_v4d &acc, int ti, int tj, int lane, int nv) {
-  const int l15 = lane & 15, l4 = lane >> 4, col = 16 * tj + l15;
+  const int l15 = lane & 15, l4 = lane >> 4;
+  const bool even = !(l15 & 1);
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int row = 16 * ti + l4 + 4 * r;
-    if (row < nv) blk[row * 32 + col] = acc[r];  // columns nv..31 carry zeros: whole 128-byte segments
+  for (int qp = 0; qp < 2; ++qp) {
+    const double a = acc[2 * qp], b = acc[2 * qp + 1];
+    const double y = dpp_mov<0xB1>(even ? b : a);  // quad_perm [1,0,3,2]: swap with the neighbour lane
+    const double2 v = even ? make_double2(a, y) : make_double2(y, b);
+    const int row = 16 * ti + l4 + 4 * (2 * qp + (even ? 0 : 1));
+    if (row < nv) *reinterpret_cast<double2 *>(blk + row * 32 + 16 * tj + (l15 & 14)) = v;
   }
 }
 
@@ -668,10 +675,10 @@ __device__ __forceinline__ double wg_node(WgNode<NV> &L, const DevModel &m, cons
   wg_store_tile(qt + Q::Hqv, hqv, ti, tj, lane, NV);
   wg_store_tile(qt + Q::Hvv, hvv, ti, tj, lane, NV);
   // aux blocks M | tq | tv straight from LDS (zeros at the terminal node), whole rows
-  for (int e = tid; e < NV * LDM; e += NT) {
-    ax[A::M + e] = (&L.M[0][0])[e];
-    ax[A::tq + e] = (&L.tq[0][0])[e];
-    ax[A::tv + e] = (&L.tv[0][0])[e];
+  for (int e = 2 * tid; e < NV * LDM; e += 2 * NT) {
+    *reinterpret_cast<double2 *>(ax + A::M + e) = *reinterpret_cast<const double2 *>(&L.M[0][0] + e);
+    *reinterpret_cast<double2 *>(ax + A::tq + e) = *reinterpret_cast<const double2 *>(&L.tq[0][0] + e);
+    *reinterpret_cast<double2 *>(ax + A::tv + e) = *reinterpret_cast<const double2 *>(&L.tv[0][0] + e);
   }
   // gradients: gw = M lu, gx = Lx + taux' lu
   if (tid < 3 * NV) {
