@@ -11,7 +11,16 @@
 // Spatial vectors are [linear(3); angular(3)], expressed in the WORLD frame.
 #pragma once
 
+#ifdef AGX_HOST_BUILD
+// oracle/agx_analytic.cpp (the analytic-derivative CPU leg of bench.py's cpu_baseline) compiles the per-node arithmetic
+// of this header for the host: plain C++ below, the cross-lane helpers are left out.
+#include <cmath>
+#define __device__
+#define __host__
+#define __forceinline__ inline __attribute__((always_inline))
+#else
 #include <hip/hip_runtime.h>
+#endif
 #include <stdint.h>
 
 #include "../../include/agimus_hip.h"
@@ -74,6 +83,7 @@ struct DevOcp {
 
 namespace agx {
 
+#ifndef AGX_HOST_BUILD
 // ------------------------------------------------------------------ DPP helpers (8-lane groups)
 // Cross-lane moves on the VALU (no LDS traffic).  A DPP row is 16 lanes = two 8-lane groups.
 template <int CTRL, int BANK = 0xf>
@@ -118,6 +128,8 @@ __device__ __forceinline__ double transpose_reduce8(const double *p, int l8) {
   for (int k = 0; k < 2; ++k) k2[k] = (b2 ? k4[k + 2] : k4[k]) + dpp_xor2(b2 ? k4[k] : k4[k + 2]);
   return (b1 ? k2[1] : k2[0]) + dpp_xor1(b1 ? k2[0] : k2[1]);
 }
+
+#endif  // !AGX_HOST_BUILD
 
 // ------------------------------------------------------------------ 3-vectors
 AGX_DEV void cross3(const double *a, const double *b, double *c) {

@@ -176,20 +176,22 @@ class HostRefs:
         return out
 
 
-def cpu_baseline(args, table, po, refs: HostRefs, seconds):
-    """The same MPC steps on the host cores with the CPU restatement under oracle/ ("port", OpenMP over the
-    instances): a bounded sample of the workload (first instances, first steps), sized for ~`seconds` of CPU work."""
-    from oracle.oracle import Oracle  # test infrastructure: only this leg of bench.py uses it
+def _cpu_leg(args, table, po, refs: HostRefs, seconds, analytic):
+    """One CPU leg: MPC loop of the first instances on the host cores (OpenMP over instances) + the same loop for one
+    instance on one thread (the reference's default n_threads = 1, ocp_param_base.py:65).  None if the leg does not apply."""
+    from oracle.oracle import Oracle  # test infrastructure: only the cpu_baseline leg of bench.py uses it
 
     avail = ncores()
     B, T = refs.run.shape[0], args.horizon
     o = Oracle(table, po, B)
+    if analytic and not o.set_analytic(True):
+        return None
     xs0, us0 = refs.x[:, : T + 1].copy(), refs.u[:, :T].copy()
     x0 = xs0[:, 0].copy()
     ref0 = refs.window(0)
     # thread count: the best of a few candidates on one untimed SQP iteration (big hosts oversubscribe easily)
     best = None
-    for nt in sorted({min(avail, c) for c in (16, 32, 64, avail)}):
+    for nt in sorted({min(avail, c) for c in (8, 16, 32, 64, avail)}):
         o.solve(ref0, None, x0, xs0, us0, 1, nthreads=nt)  # thread pool / page warm-up
         t0 = time.perf_counter()
         o.solve(ref0, None, x0, xs0, us0, 1, nthreads=nt)
@@ -210,8 +212,9 @@ def cpu_baseline(args, table, po, refs: HostRefs, seconds):
         iters.append(float(st["iter"].mean()))
         n_steps += 1
     el = time.perf_counter() - t_start
-    # the reference's default n_threads = 1 (ocp_param_base.py:65): one instance on one thread, same MPC loop
     o1 = Oracle(table, po, 1)
+    if analytic:
+        o1.set_analytic(True)
     xs1, us1 = xs0[:1].copy(), us0[:1].copy()
     x01 = xs1[:, 0].copy()
     o1.solve(ref0[:1], None, x01, xs1, us1, 1, nthreads=1)
@@ -225,17 +228,33 @@ def cpu_baseline(args, table, po, refs: HostRefs, seconds):
         xs1, us1, _, _ = o1.solve(refs.window(n1)[:1], None, x01, xs1, us1, args.max_iter, nthreads=1)
         n1 += 1
     el1 = time.perf_counter() - t1
+    what = ("analytic RNEA / CRBA derivatives (the kernels' node arithmetic compiled for the host, oracle/agx_analytic.cpp) behind the "
+            "checker's SQP / Riccati loop" if analytic else "CPU restatement with automatic differentiation (oracle/agx_oracle.cpp: the parity checker)")
     return {
-        "single_thread": {"value": n1 / el1, "unit": "MPC steps/s", "cores": 1, "sample": f"1 instance x {n1} MPC steps, 1 thread"},
         "value": B * n_steps / el,
         "unit": "MPC steps/s",
         "cores": cores,
-        "kind": "port",
-        "sample": f"{B} instances x {n_steps} steps of the same workload (T={T}), OpenMP over instances; "
-                  f"CPU restatement with automatic differentiation (oracle/), not the Crocoddyl/mim_solvers binaries; "
-                  f"mean SQP iters {np.mean(iters):.2f}",
+        "kind": "port-analytic" if analytic else "port-ad",
+        "sample": f"{B} instances x {n_steps} steps of the same workload (T={T}), OpenMP over instances; {what}; "
+                  f"not the Crocoddyl/mim_solvers binaries; mean SQP iters {np.mean(iters):.2f}",
         "seconds": el,
+        "single_thread": {"value": n1 / el1, "unit": "MPC steps/s", "cores": 1, "sample": f"1 instance x {n1} MPC steps, 1 thread"},
     }
+
+
+def cpu_baseline(args, table, po, refs: HostRefs, seconds):
+    """The same MPC steps on the host cores: a bounded sample of the workload (first instances, first steps) sized for
+    ~`seconds` of CPU work per leg.  Two legs: "port-analytic" (analytic derivatives, what a Pinocchio-based CPU path does;
+    unconstrained workloads) is the baseline when it applies; "port-ad" (the parity checker, dual-number automatic
+    differentiation, an order of magnitude slower per node) is always reported next to it."""
+    ad = _cpu_leg(args, table, po, refs, seconds / 2.0, False)
+    ana = _cpu_leg(args, table, po, refs, seconds, True)
+    if ana is None:
+        ad["kind"] = "port"
+        ad["note"] = "constrained workload: only the automatic-differentiation checker covers the ADMM loop"
+        return ad
+    ana["port_ad"] = ad
+    return ana
 
 
 def main():

@@ -40,6 +40,16 @@
 #include <string>
 #include <vector>
 
+// analytic-derivative node evaluation (oracle/agx_analytic.cpp): bench.py's "port-analytic" CPU leg only, never the checker
+extern "C" {
+void *ana_create(const agx_model_desc *d, const agx_ocp_desc *od);
+void ana_destroy(void *p);
+void ana_node_diff(void *p, int term, double dt, const double *x, const double *u, const double *xnext_ws, const double *ref,
+                   const int32_t *frames, double *tile);
+void ana_node_calc(void *p, int term, double dt, const double *x, const double *u, const double *ref, const int32_t *frames,
+                   double *xnext, double *cost);
+}
+
 namespace {
 
 // ---------------------------------------------------------------------------
@@ -1305,10 +1315,23 @@ struct Workspace {
 };
 
 void eval_tiles(const Model &m, const Ocp &o, const double *xs, const double *us, const double *ref,
-                const int32_t *frames, Workspace &w, double &cost, double &gap1, double *con1 = nullptr) {
+                const int32_t *frames, Workspace &w, double &cost, double &gap1, double *con1 = nullptr, void *ana = nullptr) {
   const int nv = m.nv, nx = 2 * nv, nu = nv, T = o.T, TILE = AGX_TILE_DOUBLES(nv);
   w.tiles.resize((size_t)(T + 1) * TILE);
   cost = 0.0; gap1 = 0.0;
+  if (ana) {  // analytic derivatives (bench baseline): the canonical tile straight from oracle/agx_analytic.cpp
+    const int of = nx * nx + nx * nu;
+    if (con1) *con1 = 0.0;
+    for (int t = 0; t <= T; ++t) {
+      const bool term = (t == T);
+      double *tile = &w.tiles[(size_t)t * TILE];
+      ana_node_diff(ana, term, term ? 0.0 : o.dt[t], xs + (size_t)t * nx, term ? nullptr : us + (size_t)t * nu,
+                    term ? nullptr : xs + (size_t)(t + 1) * nx, ref + (size_t)t * o.stride, frames ? frames + (size_t)t * AGX_MAX_ROWS : nullptr, tile);
+      cost += tile[TILE - 1];
+      if (!term) for (int i = 0; i < nx; ++i) gap1 += std::fabs(tile[of + i]);
+    }
+    return;
+  }
   const bool has_con = o.nc[0] + o.nc[1] > 0;
   if (has_con) w.cn.resize(T + 1);
   if (con1) *con1 = 0.0;
@@ -1329,9 +1352,10 @@ void eval_tiles(const Model &m, const Ocp &o, const double *xs, const double *us
 
 void solve_one(const Model &m, const Ocp &o, const double *ref, const int32_t *frames, const double *x0,
                const double *xs_ws, const double *us_ws, int max_iter, double max_time, double *xs, double *us,
-               double *K, agx_status *st, Workspace &w, Admm *admm = nullptr) {
+               double *K, agx_status *st, Workspace &w, Admm *admm = nullptr, void *ana = nullptr) {
   const int nv = m.nv, nx = 2 * nv, nu = nv, T = o.T;
   const bool has_con = (o.nc[0] + o.nc[1] > 0) && admm != nullptr;
+  if (has_con) ana = nullptr;  // the analytic leg covers unconstrained problems
   auto t_start = std::chrono::steady_clock::now();
   std::memcpy(xs, xs_ws, sizeof(double) * (T + 1) * nx);
   std::memcpy(us, us_ws, sizeof(double) * T * nu);
@@ -1355,7 +1379,7 @@ void solve_one(const Model &m, const Ocp &o, const double *ref, const int32_t *f
   bool have_dir = false;
   for (; it < max_iter; ++it) {
     double cost, gap1, con1 = 0.0;
-    eval_tiles(m, o, xs, us, ref, frames, w, cost, gap1, &con1);
+    eval_tiles(m, o, xs, us, ref, frames, w, cost, gap1, &con1, ana);
     const double merit = cost + o.mu_dyn * gap1 + o.mu_con * con1;
     bool ok;
     if (has_con) {
@@ -1381,6 +1405,10 @@ void solve_one(const Model &m, const Ocp &o, const double *ref, const int32_t *f
       for (int t = 0; t <= T; ++t) {
         const bool term = (t == T);
         double c;
+        if (ana)
+          ana_node_calc(ana, term, term ? 0.0 : o.dt[t], &w.xs_try[(size_t)t * nx], term ? nullptr : &w.us_try[(size_t)t * nu],
+                        ref + (size_t)t * o.stride, frames ? frames + (size_t)t * AGX_MAX_ROWS : nullptr, w.xn.data(), &c);
+        else
         node_calc(m, o, term, term ? 0.0 : o.dt[t], &w.xs_try[(size_t)t * nx], term ? nullptr : &w.us_try[(size_t)t * nu],
                   ref + (size_t)t * o.stride, frames ? frames + (size_t)t * AGX_MAX_ROWS : nullptr, w.xn.data(), c);
         cost_try += c;
@@ -1421,6 +1449,9 @@ struct OrcOcp {
   Model m;
   Ocp o;
   int B;
+  void *ana = nullptr;   // analytic-derivative leg (oracle/agx_analytic.cpp), NULL when not covered
+  bool use_ana = false;  // orc_set_analytic: bench.py's "port-analytic" baseline
+  ~OrcOcp() { if (ana) ana_destroy(ana); }
   std::vector<Admm> admm;  // per instance; duals and rho persist across solves like the solver object's
 };
 
@@ -1439,6 +1470,7 @@ int orc_ocp_create(const agx_model_desc *md, const agx_ocp_desc *od, int batch, 
   copy_ocp(od, md->nv, p->o);
   p->B = batch;
   p->admm.resize(batch);
+  p->ana = ana_create(md, od);
   *out = p;
   return 0;
 }
@@ -1548,9 +1580,19 @@ int orc_solve(void *h, const double *ref, const int32_t *frames, const double *x
     Workspace w;
     solve_one(p->m, p->o, ref + (size_t)b * (T + 1) * p->o.stride, frames ? frames + (size_t)b * (T + 1) * AGX_MAX_ROWS : nullptr,
               x0 + (size_t)b * nx, xs_ws + (size_t)b * (T + 1) * nx, us_ws + (size_t)b * T * nu, max_iter, max_time,
-              xs + (size_t)b * (T + 1) * nx, us + (size_t)b * T * nu, K + (size_t)b * T * nu * nx, st + b, w, &p->admm[b]);
+              xs + (size_t)b * (T + 1) * nx, us + (size_t)b * T * nu, K + (size_t)b * T * nu * nx, st + b, w, &p->admm[b],
+              p->use_ana ? p->ana : nullptr);
   }
   return 0;
+}
+
+// 1: the per-node derivatives come from the analytic formulas of oracle/agx_analytic.cpp (bench baseline "port-analytic");
+// returns 0 when the problem is outside what that leg covers (then nothing changes), 1 otherwise
+int orc_set_analytic(void *h, int on) {
+  OrcOcp *p = static_cast<OrcOcp *>(h);
+  if (on && !p->ana) return 0;
+  p->use_ana = on != 0;
+  return 1;
 }
 
 // forget the constraint multipliers and rho of every instance (a freshly constructed solver)

@@ -169,6 +169,11 @@ class Oracle:
         )
         return xs, us, K, st
 
+    def set_analytic(self, on: bool = True) -> bool:
+        """solve() with the analytic per-node derivatives of oracle/agx_analytic.cpp instead of automatic differentiation
+        (bench.py's "port-analytic" CPU baseline; unconstrained problems of the sizes 7 / 30).  False: not covered."""
+        return bool(lib().orc_set_analytic(self._h, 1 if on else 0))
+
     def reset_duals(self):
         lib().orc_reset_duals(self._h)
 

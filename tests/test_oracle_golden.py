@@ -12,9 +12,15 @@ from agimus_controller_amd.factory import robot_tables as rt
 from oracle.oracle import Oracle
 
 
-def test_golden_cold_start_reproduced(golden):
+@pytest.mark.parametrize("analytic", [False, True])
+def test_golden_cold_start_reproduced(golden, analytic):
+    """analytic = True: the same with the kernels' analytical derivatives on the CPU (oracle/agx_analytic.cpp) -- the
+    reference's golden file pins that derivation too, without a GPU."""
     table, po, ref, x0, xs0, us0 = workloads.golden_problem()
-    xs, us, K, st = Oracle(table, po, 1).solve(ref, None, x0, xs0, us0, 100)
+    o = Oracle(table, po, 1)
+    if analytic:
+        assert o.set_analytic(True)
+    xs, us, K, st = o.solve(ref, None, x0, xs0, us0, 100)
     assert st["solved"][0] == 1 and st["kkt"][0] <= 1e-3
     # upstream asserts 6 decimals; the restatement is good to ~1e-10
     np.testing.assert_allclose(xs[0], golden["states"], rtol=0, atol=1e-9)
@@ -188,3 +194,30 @@ def test_warm_start_shift_semantics():
     np.testing.assert_array_equal(xs[0, 2], Oracle(table, _abi.PackedOcp(3, [0.1], rows, rows), 1).integrate(states[2], controls[2]))
     np.testing.assert_array_equal(us[0, 2], controls[2])
     np.testing.assert_array_equal(xs[0, 3], states[3])
+
+
+def test_analytic_cpu_leg_agrees_with_the_automatic_differentiation_checker():
+    """oracle/agx_analytic.cpp (bench.py's "port-analytic" CPU baseline: the kernels' analytical RNEA / CRBA derivatives
+    compiled for the host) against the dual-number checker: same SQP path, same iterates -- a third derivation of the
+    tiles that runs without a GPU.  Serial chain (Panda) and tree (30 DoF), dt factors, frame and collision rows."""
+    from agimus_controller_amd import _abi, workloads
+    from agimus_controller_amd.factory import robot_tables as rt
+    from oracle.oracle import Oracle
+
+    cases = [(rt.panda_table(0.1), "goal", 12, 3, None), (rt.panda_collision_table(0.1, obstacle_xyz=(0.45, 0.1, 0.45), obstacle_radius=0.08,
+              obstacle_length=0.3), "collision", 10, 2, None), (rt.humanoid30_table(), "goal", 6, 2, [0.01, 0.01, 0.02, 0.02, 0.04, 0.04])]
+    for table, rows, T, B, ts in cases:
+        frame = table.frame_id("panda_hand_tcp") if table.nv == 7 else len(table.frame_names) - 1
+        po, ref, x0, xs, us = workloads.random_goal_problem(table, T, 0.01, B, seed=4, frame=frame, rows=rows, timesteps=ts)
+        o = Oracle(table, po, B)
+        r_ad = o.solve(ref, None, x0, xs, us, 12)
+        assert o.set_analytic(True)
+        r_an = o.solve(ref, None, x0, xs, us, 12)
+        assert np.array_equal(r_ad[3]["iter"], r_an[3]["iter"]) and np.array_equal(r_ad[3]["solved"], r_an[3]["solved"])
+        np.testing.assert_allclose(r_an[0], r_ad[0], rtol=1e-9, atol=1e-10)
+        np.testing.assert_allclose(r_an[1], r_ad[1], rtol=1e-8, atol=1e-8)
+        np.testing.assert_allclose(r_an[2], r_ad[2], rtol=1e-7, atol=1e-7)
+    # not covered: general rows / constraints keep the automatic-differentiation path
+    table = rt.panda_table(0.1)
+    rows = [_abi.RowSpec(_abi.RES_STATE), _abi.RowSpec(_abi.RES_CONTROL_GRAV)]
+    assert not Oracle(table, _abi.PackedOcp(7, [0.01] * 3, rows, rows[:1]), 1).set_analytic(True)
