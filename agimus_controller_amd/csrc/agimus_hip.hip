@@ -59,7 +59,9 @@ struct agx_ocp {
   bool general = false;       // ControlGrav / FrameVelocity cost rows: one-lane GEN kernels (agx_general.hpp)
   double *d_auxg = nullptr;   // [B][T+1][3 nv 8]: Lqv | Lvvd | Lqu of every node (general problems)
   double *d_qt2 = nullptr, *d_cg = nullptr, *d_cjac = nullptr, *d_y = nullptr, *d_z = nullptr, *d_cx = nullptr, *d_admmstat = nullptr,
-         *d_fac = nullptr;  // Riccati factors of every node for the gradient-only ADMM sweeps [B][T][192]
+         *d_fac = nullptr,  // Riccati factors of every node for the gradient-only ADMM sweeps [B][T][192]
+         *d_segP = nullptr;  // closed-loop transition products of the horizon segments [B][kSeg][4][64] (agx_admm.hpp)
+  bool admm_segments = true;  // AGX_ADMM_SEGMENTS=0: gradient-only sweeps on one wave per instance
   int qt_size = 0, aux_size = 0;
   bool k1_lanes = true;  // AGX_K1_LANES=0 selects the one-lane-per-node derivative kernel
   bool lanes_ok = true;  // problem fits the LDS staging of the 8-lanes-per-node kernel
@@ -529,8 +531,13 @@ int admm_direction(agx_ocp *o) {
       if (iter == 1 || (iter > 2 && (iter - 1) % agx::kRhoInterval == 0))
         hipLaunchKernelGGL((agx::k_admm_tile<NV>), dim3(g8b), dim3(128), 0, o->stream, o->d_ocp, o->d_qt, o->d_qt2, o->d_aux, o->d_cx,
                            o->d_du, o->d_cjac, o->d_y, o->d_z, o->d_state);
-      hipLaunchKernelGGL((agx::k_riccati_admm<NV>), dim3(o->B), dim3(64), 0, o->stream, o->d_ocp, o->d_dt, o->d_qt2, o->d_aux, o->d_Kws,
-                         o->d_kws, o->d_dx, o->d_w, o->d_du, o->d_Kout, o->d_state, o->d_fac);
+      const bool may_refactor = iter == 1 || (iter > 2 && (iter - 1) % agx::kRhoInterval == 0);
+      hipLaunchKernelGGL((agx::k_riccati_admm<NV>), dim3(o->B), dim3(64 * agx::kSeg), 0, o->stream, o->d_ocp, o->d_dt, o->d_qt2, o->d_aux,
+                         o->d_Kws, o->d_kws, o->d_dx, o->d_w, o->d_du, o->d_Kout, o->d_state, o->d_fac,
+                         o->admm_segments ? (const double *)o->d_segP : (const double *)nullptr);
+      if (may_refactor && o->admm_segments)  // new gains: the segments' closed-loop products for the gradient-only sweeps that follow
+        hipLaunchKernelGGL((agx::k_seg_products<NV>), dim3(o->B * agx::kSeg), dim3(64), 0, o->stream, o->d_ocp, o->d_dt, o->d_Kws, o->d_segP,
+                           o->d_state);
       hipLaunchKernelGGL((agx::k_admm_update<NV>), dim3(g8), dim3(256), 0, o->stream, o->d_ocp, o->d_qt, o->d_aux, o->d_dx, o->d_w,
                          o->d_du, o->d_cx, o->d_cg, o->d_cjac, o->d_y, o->d_z, o->d_nodestat, o->d_admmstat, o->d_qt2, o->d_state);
       hipLaunchKernelGGL(agx::k_admm_reduce, dim3(o->B), dim3(128), 0, o->stream, o->d_ocp, o->d_admmstat, o->d_state, iter,
@@ -869,6 +876,8 @@ int agx_ocp_create(const agx_model *m, const agx_ocp_desc *d, int batch, int dev
     ALLOC(o->d_cx, B * (T + 1) * nx);
     ALLOC(o->d_admmstat, B * (T + 1) * 4);
     ALLOC(o->d_fac, B * T * 192);
+    ALLOC(o->d_segP, B * agx::kSeg * 256);
+    if (const char *e = getenv("AGX_ADMM_SEGMENTS")) o->admm_segments = (e[0] != '0');
   }
 #undef ALLOC
   // the polled hand-off needs FINE-GRAINED host memory (the stamp must not overtake the data it guards): ask for it
@@ -908,7 +917,7 @@ void agx_ocp_destroy(agx_ocp *o) {
   if (o->stream) (void)hipStreamSynchronize(o->stream);
   void *ptrs[] = {o->d_model, o->d_ocp, o->d_dt, o->d_xs, o->d_us, o->d_x0, o->d_tiles, o->d_Kws, o->d_kws, o->d_Kout, o->d_dx,
                   o->d_du, o->d_ref, o->d_frames, o->d_state, o->d_ndone, o->d_scratch, o->d_traj, o->d_pts, o->d_sine, o->d_qt, o->d_aux, o->d_w, o->d_nodestat,
-                  o->d_qt2, o->d_cg, o->d_cjac, o->d_y, o->d_z, o->d_cx, o->d_admmstat, o->d_fac, o->d_hidx, o->d_trial, o->d_auxg, o->d_shift_nodes};
+                  o->d_qt2, o->d_cg, o->d_cjac, o->d_y, o->d_z, o->d_cx, o->d_admmstat, o->d_fac, o->d_hidx, o->d_trial, o->d_auxg, o->d_shift_nodes, o->d_segP};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
   if (o->h_ndone) (void)hipHostFree(o->h_ndone);

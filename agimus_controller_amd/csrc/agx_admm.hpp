@@ -299,20 +299,282 @@ __device__ __forceinline__ void riccati_vec_body(const int b, const DevOcp *__re
   riccati_forward<NV>(b, T, dts, qb, Kw, kw, dxs, wss);
 }
 
+// ---------------------------------------------------------------------------
+// Gradient-only sweeps, parallel in time.  Between two factorisations the backward gradient recursion and the forward
+// pass are AFFINE recursions whose linear parts are fixed: with the closed-loop transition  Abar_t = Phi - G Kw_t
+//     forward    dx_{t+1} = Abar_t dx_t + (f_t - G kw_t)
+//     backward   v_t      = Abar_t' v_{t+1} + c_t                    (c_t: what the node's gradient contributes)
+// so the horizon is cut into kSeg segments, one wave each:
+//   1. every wave sweeps its segment from a zero boundary value               -> the segment's offset
+//   2. one wave chains the boundaries: value_out = P_s(') value_in + offset   (P_s = product of the segment's Abar_t,
+//      computed once per factorisation by k_seg_products)
+//   3. every wave sweeps its segment again from its true boundary value       -> kw_t (backward), dx_t, w_t (forward)
+// Two passes over T / kSeg nodes + kSeg boundary steps instead of one pass over T nodes: the chain that bounds an ADMM
+// iteration at B = 256 (a quarter of the SIMDs hold a wave at all) shrinks ~3 x at T = 200.
+// ---------------------------------------------------------------------------
+constexpr int kSeg = 8;
+__host__ __device__ inline int seg_len(int T) { return (T + kSeg - 1) / kSeg; }
+
+// P_s = Abar_{b-1} ... Abar_a of segment s = [a, b) on the 8 x 8 lane grid (blocks qq | qv | vq | vv, element [r][c] on
+// lane 8 r + c), from the gains Kw of the last factorisation.  One wave per (instance, segment).
 template <int NV>
-__global__ void __launch_bounds__(64) k_riccati_admm(const DevOcp *__restrict__ op, const double *__restrict__ dts,
-                                                     const double *__restrict__ qts, const double *__restrict__ auxs,
-                                                     double *__restrict__ Kws, double *__restrict__ kws,
-                                                     double *__restrict__ dxs, double *__restrict__ wss,
-                                                     double *__restrict__ dus, double *__restrict__ Kout,
-                                                     DevState *__restrict__ st, double *__restrict__ facs) {
+__global__ void __launch_bounds__(64) k_seg_products(const DevOcp *__restrict__ op, const double *__restrict__ dts,
+                                                     const double *__restrict__ Kws, double *__restrict__ segP,
+                                                     const DevState *__restrict__ st) {
+  constexpr int NX = 2 * NV;
+  const DevOcp &o = *op;
+  const int T = o.T, b = blockIdx.x / kSeg, sg = blockIdx.x % kSeg, lane = threadIdx.x;
+  const DevState &S = st[b];
+  if (S.done || S.admm_conv || !S.admm_refactor) return;
+  const int L = seg_len(T), ta = sg * L, tb = min(T, ta + L);
+  const int r = lane >> 3, c = lane & 7;
+  const bool in = (r < NV) && (c < NV);
+  const double *Kw = Kws + (long long)b * T * NV * NX;
+  double Pqq = (in && r == c) ? 1.0 : 0.0, Pqv = 0.0, Pvq = 0.0, Pvv = Pqq;
+  for (int t = ta; t < tb; ++t) {
+    const double h = dts[t], h2 = h * h;
+    const double *kr = Kw + ((long long)t * NV + (r < NV ? r : 0)) * NX;
+    const double Kq = in ? kr[c] : 0.0, Kv = in ? kr[NV + c] : 0.0;
+    double Xq = 0.0, Xv = 0.0;
+    auto acc = [&](auto Kc) {
+      constexpr int k = decltype(Kc)::value;
+      if (k >= NV) return;
+      const double kq = grid_col<k>(Kq), kv = grid_col<k>(Kv);  // K[r][k]
+      const double pqq = __shfl(Pqq, 8 * k + c, 64), pqv = __shfl(Pqv, 8 * k + c, 64), pvq = __shfl(Pvq, 8 * k + c, 64), pvv = __shfl(Pvv, 8 * k + c, 64);  // P[k][c]
+      Xq += kq * pqq + kv * pvq;
+      Xv += kq * pqv + kv * pvv;
+    };
+    acc(std::integral_constant<int, 0>()); acc(std::integral_constant<int, 1>()); acc(std::integral_constant<int, 2>());
+    acc(std::integral_constant<int, 3>()); acc(std::integral_constant<int, 4>()); acc(std::integral_constant<int, 5>());
+    acc(std::integral_constant<int, 6>());
+    const double nqq = Pqq + h * Pvq - h2 * Xq, nqv = Pqv + h * Pvv - h2 * Xv;
+    Pvq = Pvq - h * Xq; Pvv = Pvv - h * Xv;
+    Pqq = nqq; Pqv = nqv;
+    if (!in) { Pqq = 0.0; Pqv = 0.0; Pvq = 0.0; Pvv = 0.0; }
+  }
+  double *P = segP + ((long long)b * kSeg + sg) * 256;
+  P[lane] = Pqq; P[64 + lane] = Pqv; P[128 + lane] = Pvq; P[192 + lane] = Pvv;
+}
+
+// backward gradient recursion over the nodes t_hi-1 .. t_lo of one segment (see riccati_vec_body); v: the value gradient
+// on the lanes c = 1 (q) and c = 2 (v) of grid row r, in: boundary value, out: value at t_lo
+template <int NV, bool STORE_KW>
+__device__ __forceinline__ double vec_backward_seg(const int t_lo, const int t_hi, double v, const double *__restrict__ dts,
+                                                   const double *__restrict__ qb, const double *__restrict__ fb, double *__restrict__ kw) {
+  constexpr int TS = QT<NV>::SIZE;
+  typedef QT<NV> Q;
+  typedef FT<NV> F;
+  const int lane = threadIdx.x & 63, r = lane >> 3, c = lane & 7;
+  const int rr = r < NV ? r : 0;
+  const int sel = c < 3 ? c : 0;
+  const int goff = sel == 0 ? Q::gw : (sel == 1 ? Q::gx : Q::gx + NV);
+  const int foff = sel == 0 ? F::FW : (sel == 1 ? F::FQ : F::FV);
+  const int poff = sel == 2 ? F::PV : F::PQ;
+  struct Node { double g, rp, p, h, f[NV]; };
+  int vzero;  // dts through the vector memory path, see riccati_forward
+  asm volatile("v_mov_b32 %0, 0" : "=v"(vzero));
+  auto load_node = [&](Node &z, int t) {
+    const double *tl = qb + (long long)t * TS;
+    const double *ft = fb + (long long)t * F::SIZE;
+    z.g = tl[goff + rr];
+    z.rp = ft[F::RP + rr]; z.p = ft[poff + rr];
+    z.h = dts[t + vzero];
+#pragma unroll
+    for (int k = 0; k < NV; ++k) z.f[k] = ft[foff + k * 8 + rr];
+  };
+  auto step = [&](Node &z, int t) {
+    const double h = z.h, h2 = h * h;
+    const double vp = v + z.p;
+    const double vpq = dpp_mov<0x55>(vp), vpv = dpp_mov<0xAA>(vp);  // quad broadcast of lanes c = 1 / c = 2
+    const double ca = sel == 0 ? h2 : (sel == 1 ? 1.0 : h), cb = sel == 0 ? h : (sel == 1 ? 0.0 : 1.0);
+    double g = z.g + ca * vpq + cb * vpv;
+    const double rp = z.rp;
+    double f[NV];
+#pragma unroll
+    for (int k = 0; k < NV; ++k) f[k] = z.f[k];
+    if (t - 4 >= t_lo) load_node(z, t - 4);
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      const double gk = readlane_f64(g, 8 * k);
+      g -= f[k] * gk;
+    }
+    if (STORE_KW && c == 0 && r < NV) kw[(long long)t * NV + r] = g * rp;
+    v = g;
+  };
+  if (t_hi <= t_lo) return v;
+  Node n0, n1, n2, n3;
+  load_node(n0, t_hi - 1);
+  if (t_hi - 2 >= t_lo) load_node(n1, t_hi - 2);
+  if (t_hi - 3 >= t_lo) load_node(n2, t_hi - 3);
+  if (t_hi - 4 >= t_lo) load_node(n3, t_hi - 4);
+  for (int t = t_hi - 1; t >= t_lo; t -= 4) {
+    step(n0, t);
+    if (t - 1 >= t_lo) step(n1, t - 1);
+    if (t - 2 >= t_lo) step(n2, t - 2);
+    if (t - 3 >= t_lo) step(n3, t - 3);
+  }
+  return v;
+}
+
+// forward pass over the nodes t_lo .. t_hi-1 of one segment (see riccati_forward); the state enters / leaves indexed by the
+// lane's grid row (dq_r, dv_r)
+template <int NV, bool STORE>
+__device__ __forceinline__ void forward_seg(const int t_lo, const int t_hi, double &dq_r, double &dv_r, const double *__restrict__ dts,
+                                            const double *__restrict__ qb, const double *__restrict__ Kw, const double *__restrict__ kw,
+                                            double *__restrict__ dx, double *__restrict__ ws) {
+  constexpr int NX = 2 * NV, TS = QT<NV>::SIZE;
+  typedef QT<NV> Q;
+  const int lane = threadIdx.x & 63, r = lane >> 3, c = lane & 7;
+  const bool in = (r < NV) && (c < NV);
+  const int rr = r < NV ? r : 0, cc = c < NV ? c : 0;
+  double dq_c = __shfl(dq_r, 8 * cc, 64), dv_c = __shfl(dv_r, 8 * cc, 64);
+  struct Gain { double kq, kv, kw, fq, fv, h; };
+  int vzero;
+  asm volatile("v_mov_b32 %0, 0" : "=v"(vzero));
+  constexpr int DEPTH = 4;
+  auto load_gain = [&](Gain &g, int t) {
+    const double *kr = Kw + ((long long)t * NV + rr) * NX;
+    g.kq = in ? kr[cc] : 0.0;
+    g.kv = in ? kr[NV + cc] : 0.0;
+    g.kw = kw[(long long)t * NV + rr];
+    g.fq = qb[(long long)t * TS + Q::f + rr];
+    g.fv = qb[(long long)t * TS + Q::f + NV + rr];
+    g.h = dts[t + vzero];
+  };
+  auto fstep = [&](Gain &g, int t) {
+    const double h = g.h, h2 = h * h;
+    double p = g.kq * dq_c + g.kv * dv_c;
+    const double kwv = g.kw, fqc = g.fq, fvc = g.fv;
+    if (t + DEPTH < t_hi) load_gain(g, t + DEPTH);
+    p += dpp_xor1(p); p += dpp_xor2(p); p += dpp_xor4(p);
+    const double wv = -(kwv + p);
+    const double nq = dq_r + h * dv_r + h2 * wv + fqc;
+    const double nv2 = dv_r + h * wv + fvc;
+    dq_r = nq; dv_r = nv2;
+    dq_c = __shfl(nq, 8 * cc, 64);
+    dv_c = __shfl(nv2, 8 * cc, 64);
+    if (STORE && c == 0 && r < NV) {
+      ws[(long long)t * NV + r] = wv;
+      dx[(long long)(t + 1) * NX + r] = nq;
+      dx[(long long)(t + 1) * NX + NV + r] = nv2;
+    }
+  };
+  Gain g[DEPTH];
+#pragma unroll
+  for (int i = 0; i < DEPTH; ++i)
+    if (t_lo + i < t_hi) load_gain(g[i], t_lo + i);
+  for (int t = t_lo; t < t_hi; t += DEPTH) {
+#pragma unroll
+    for (int i = 0; i < DEPTH; ++i)
+      if (t + i < t_hi) fstep(g[i], t + i);
+  }
+}
+
+template <int NV>
+__device__ __forceinline__ void riccati_vec_segments(const int b, const DevOcp *__restrict__ op, const double *__restrict__ dts,
+                                                     const double *__restrict__ qts, const double *__restrict__ Kws,
+                                                     double *__restrict__ kws, double *__restrict__ dxs, double *__restrict__ wss,
+                                                     const double *__restrict__ facs, const double *__restrict__ segP) {
+  constexpr int NX = 2 * NV, TS = QT<NV>::SIZE;
+  typedef QT<NV> Q;
+  typedef FT<NV> F;
+  __shared__ double s_off[kSeg][2][8], s_in[kSeg][2][8];  // segment offsets / boundary values (q | v), indexed by joint
+  const DevOcp &o = *op;
+  const int T = o.T, lane = threadIdx.x & 63, sg = threadIdx.x >> 6;
+  const int r = lane >> 3, c = lane & 7;
+  const int rr = r < NV ? r : 0, cc = c < NV ? c : 0;
+  const int L = seg_len(T), ta = min(T, sg * L), tb = min(T, ta + L);
+  const double *qb = qts + (long long)b * (T + 1) * TS;
+  const double *Kw = Kws + (long long)b * T * NV * NX;
+  double *kw = kws + (long long)b * T * NV;
+  const double *fb = facs + (long long)b * T * F::SIZE;
+  const double *P = segP + ((long long)b * kSeg + sg) * 256;
+  const int sel = c < 3 ? c : 0;
+  // ---- backward 1: offsets from a zero boundary value
+  {
+    const double v = vec_backward_seg<NV, false>(ta, tb, 0.0, dts, qb, fb, kw);
+    if ((c == 1 || c == 2) && r < 8) s_off[sg][c - 1][r] = (r < NV) ? v : 0.0;
+  }
+  __syncthreads();
+  // ---- backward 2: boundary values, last segment first:  v_start(s) = P_s' v_in(s) + offset(s)
+  if (sg == 0) {
+    double vq_r = (r < NV) ? qb[(long long)T * TS + Q::gx + rr] : 0.0, vv_r = (r < NV) ? qb[(long long)T * TS + Q::gx + NV + rr] : 0.0;  // by grid row
+    for (int s2 = kSeg - 1; s2 >= 0; --s2) {
+      if (c == 0 && r < 8) { s_in[s2][0][r] = vq_r; s_in[s2][1][r] = vv_r; }
+      const double *Ps = segP + ((long long)b * kSeg + s2) * 256;
+      const double pqq = Ps[lane], pqv = Ps[64 + lane], pvq = Ps[128 + lane], pvv = Ps[192 + lane];
+      double nq = pqq * vq_r + pvq * vv_r, nv2 = pqv * vq_r + pvv * vv_r;  // column sums over r: (P' v)[c]
+      nq += __shfl_xor(nq, 8, 64); nv2 += __shfl_xor(nv2, 8, 64);
+      nq += __shfl_xor(nq, 16, 64); nv2 += __shfl_xor(nv2, 16, 64);
+      nq += __shfl_xor(nq, 32, 64); nv2 += __shfl_xor(nv2, 32, 64);
+      // back to "indexed by grid row": lane (r, *) takes column r's value, plus the segment's offset
+      vq_r = __shfl(nq, rr, 64) + s_off[s2][0][rr];
+      vv_r = __shfl(nv2, rr, 64) + s_off[s2][1][rr];
+      if (r >= NV) { vq_r = 0.0; vv_r = 0.0; }
+    }
+  }
+  __syncthreads();
+  // ---- backward 3: the segment again from its true boundary value, gains feed-forward kw stored
+  {
+    const double v0 = s_in[sg][sel == 2 ? 1 : 0][rr];
+    vec_backward_seg<NV, true>(ta, tb, v0, dts, qb, fb, kw);
+  }
+  __threadfence_block();  // kw of this segment is read back by other lanes of the wave below
+  // ---- forward 1: offsets from a zero state
+  {
+    double dq = 0.0, dv = 0.0;
+    forward_seg<NV, false>(ta, tb, dq, dv, dts, qb, Kw, kw, nullptr, nullptr);
+    __syncthreads();  // s_off is free again (everyone is past backward 2 / 3 reads of it)
+    if (c == 0 && r < 8) { s_off[sg][0][r] = dq; s_off[sg][1][r] = dv; }
+  }
+  __syncthreads();
+  // ---- forward 2: boundary states, first segment first:  dx_in(s + 1) = P_s dx_in(s) + offset(s)
+  if (sg == 0) {
+    double dq_r = 0.0, dv_r = 0.0;  // dx_0 = 0
+    for (int s2 = 0; s2 < kSeg; ++s2) {
+      if (c == 0 && r < 8) { s_in[s2][0][r] = dq_r; s_in[s2][1][r] = dv_r; }
+      const double *Ps = segP + ((long long)b * kSeg + s2) * 256;
+      const double dq_c = __shfl(dq_r, 8 * cc, 64), dv_c = __shfl(dv_r, 8 * cc, 64);
+      double nq = Ps[lane] * dq_c + Ps[64 + lane] * dv_c, nv2 = Ps[128 + lane] * dq_c + Ps[192 + lane] * dv_c;  // row sums over c
+      nq += dpp_xor1(nq); nv2 += dpp_xor1(nv2);
+      nq += dpp_xor2(nq); nv2 += dpp_xor2(nv2);
+      nq += dpp_xor4(nq); nv2 += dpp_xor4(nv2);
+      dq_r = nq + s_off[s2][0][rr];
+      dv_r = nv2 + s_off[s2][1][rr];
+      if (r >= NV) { dq_r = 0.0; dv_r = 0.0; }
+    }
+  }
+  __syncthreads();
+  // ---- forward 3: the segment again from its true state
+  {
+    double dq = s_in[sg][0][rr], dv = s_in[sg][1][rr];
+    double *dx = dxs + (long long)b * (T + 1) * NX, *ws = wss + (long long)b * T * NV;
+    if (sg == 0 && lane < NV) { dx[lane] = 0.0; dx[NV + lane] = 0.0; }
+    forward_seg<NV, true>(ta, tb, dq, dv, dts, qb, Kw, kw, dx, ws);
+  }
+  (void)P;
+}
+
+// One workgroup of kSeg waves per instance: a factorisation sweep runs on wave 0 alone (the Riccati recursion itself is
+// not affine in the value function), the gradient-only sweeps on all of them.
+template <int NV>
+__global__ void __launch_bounds__(64 * kSeg) k_riccati_admm(const DevOcp *__restrict__ op, const double *__restrict__ dts,
+                                                            const double *__restrict__ qts, const double *__restrict__ auxs,
+                                                            double *__restrict__ Kws, double *__restrict__ kws,
+                                                            double *__restrict__ dxs, double *__restrict__ wss,
+                                                            double *__restrict__ dus, double *__restrict__ Kout,
+                                                            DevState *__restrict__ st, double *__restrict__ facs,
+                                                            const double *__restrict__ segP) {
   const int b = blockIdx.x;
   const DevState &S = st[b];
   if (S.done || S.admm_conv) return;
-  if (S.admm_refactor)
-    riccati_body<NV, false, true>(b, op, dts, qts, auxs, Kws, kws, dxs, wss, dus, Kout, st, 1, 0, 0, facs);
-  else
+  if (S.admm_refactor) {
+    if (threadIdx.x < 64) riccati_body<NV, false, true>(b, op, dts, qts, auxs, Kws, kws, dxs, wss, dus, Kout, st, 1, 0, 0, facs);
+  } else if (segP) {
+    riccati_vec_segments<NV>(b, op, dts, qts, Kws, kws, dxs, wss, facs, segP);
+  } else if (threadIdx.x < 64) {
     riccati_vec_body<NV>(b, op, dts, qts, Kws, kws, dxs, wss, facs);
+  }
 }
 
 // After the Riccati sweep on the augmented tiles: du, the multiplier update and the node's shares of

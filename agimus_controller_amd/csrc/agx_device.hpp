@@ -12,8 +12,8 @@
 #pragma once
 
 #ifdef AGX_HOST_BUILD
-// oracle/agx_analytic.cpp (the analytic-derivative CPU leg of bench.py's cpu_baseline) compiles the per-node arithmetic
-// of this header for the host: plain C++ below, the cross-lane helpers are left out.
+// The analytic-derivative CPU leg of bench.py's cpu_baseline (agx_analytic.cpp under oracle/, test / bench infrastructure)
+// compiles the per-node arithmetic of this header for the host: plain C++ below, the cross-lane helpers are left out.
 #include <cmath>
 #define __device__
 #define __host__
