@@ -309,8 +309,10 @@ __device__ __forceinline__ void riccati_vec_body(const int b, const DevOcp *__re
 //   2. one wave chains the boundaries: value_out = P_s(') value_in + offset   (P_s = product of the segment's Abar_t,
 //      computed once per factorisation by k_seg_products)
 //   3. every wave sweeps its segment again from its true boundary value       -> kw_t (backward), dx_t, w_t (forward)
-// Two passes over T / kSeg nodes + kSeg boundary steps instead of one pass over T nodes: the chain that bounds an ADMM
-// iteration at B = 256 (a quarter of the SIMDs hold a wave at all) shrinks ~3 x at T = 200.
+// Two passes over T / kSeg nodes + kSeg boundary steps instead of one pass over T nodes.  Measured at B = 256, T = 200
+// (config 3): 95 -> 68 us per sweep, not the 3 x the node counts promise: with 8 waves per instance every SIMD holds two
+// of them and the recursion is issue / cache-latency bound (0.8 us per node and wave against 0.3 us alone); 4 segments and
+// deeper prefetch (8 nodes, spills) were slower.  AGX_ADMM_SEGMENTS=0 selects the one-wave sweep.
 // ---------------------------------------------------------------------------
 constexpr int kSeg = 8;
 __host__ __device__ inline int seg_len(int T) { return (T + kSeg - 1) / kSeg; }
@@ -488,8 +490,16 @@ __device__ __forceinline__ void riccati_vec_segments(const int b, const DevOcp *
   const double *Kw = Kws + (long long)b * T * NV * NX;
   double *kw = kws + (long long)b * T * NV;
   const double *fb = facs + (long long)b * T * F::SIZE;
-  const double *P = segP + ((long long)b * kSeg + sg) * 256;
   const int sel = c < 3 ? c : 0;
+  // the wave that chains the boundaries fetches every segment's product now: the loads are in flight during pass 1
+  double pp[kSeg][4];
+  if (sg == 0) {
+#pragma unroll
+    for (int s2 = 0; s2 < kSeg; ++s2) {
+      const double *Ps = segP + ((long long)b * kSeg + s2) * 256;
+      pp[s2][0] = Ps[lane]; pp[s2][1] = Ps[64 + lane]; pp[s2][2] = Ps[128 + lane]; pp[s2][3] = Ps[192 + lane];
+    }
+  }
   // ---- backward 1: offsets from a zero boundary value
   {
     const double v = vec_backward_seg<NV, false>(ta, tb, 0.0, dts, qb, fb, kw);
@@ -499,10 +509,10 @@ __device__ __forceinline__ void riccati_vec_segments(const int b, const DevOcp *
   // ---- backward 2: boundary values, last segment first:  v_start(s) = P_s' v_in(s) + offset(s)
   if (sg == 0) {
     double vq_r = (r < NV) ? qb[(long long)T * TS + Q::gx + rr] : 0.0, vv_r = (r < NV) ? qb[(long long)T * TS + Q::gx + NV + rr] : 0.0;  // by grid row
+#pragma unroll
     for (int s2 = kSeg - 1; s2 >= 0; --s2) {
       if (c == 0 && r < 8) { s_in[s2][0][r] = vq_r; s_in[s2][1][r] = vv_r; }
-      const double *Ps = segP + ((long long)b * kSeg + s2) * 256;
-      const double pqq = Ps[lane], pqv = Ps[64 + lane], pvq = Ps[128 + lane], pvv = Ps[192 + lane];
+      const double pqq = pp[s2][0], pqv = pp[s2][1], pvq = pp[s2][2], pvv = pp[s2][3];
       double nq = pqq * vq_r + pvq * vv_r, nv2 = pqv * vq_r + pvv * vv_r;  // column sums over r: (P' v)[c]
       nq += __shfl_xor(nq, 8, 64); nv2 += __shfl_xor(nv2, 8, 64);
       nq += __shfl_xor(nq, 16, 64); nv2 += __shfl_xor(nv2, 16, 64);
@@ -531,11 +541,11 @@ __device__ __forceinline__ void riccati_vec_segments(const int b, const DevOcp *
   // ---- forward 2: boundary states, first segment first:  dx_in(s + 1) = P_s dx_in(s) + offset(s)
   if (sg == 0) {
     double dq_r = 0.0, dv_r = 0.0;  // dx_0 = 0
+#pragma unroll
     for (int s2 = 0; s2 < kSeg; ++s2) {
       if (c == 0 && r < 8) { s_in[s2][0][r] = dq_r; s_in[s2][1][r] = dv_r; }
-      const double *Ps = segP + ((long long)b * kSeg + s2) * 256;
       const double dq_c = __shfl(dq_r, 8 * cc, 64), dv_c = __shfl(dv_r, 8 * cc, 64);
-      double nq = Ps[lane] * dq_c + Ps[64 + lane] * dv_c, nv2 = Ps[128 + lane] * dq_c + Ps[192 + lane] * dv_c;  // row sums over c
+      double nq = pp[s2][0] * dq_c + pp[s2][1] * dv_c, nv2 = pp[s2][2] * dq_c + pp[s2][3] * dv_c;  // row sums over c
       nq += dpp_xor1(nq); nv2 += dpp_xor1(nv2);
       nq += dpp_xor2(nq); nv2 += dpp_xor2(nv2);
       nq += dpp_xor4(nq); nv2 += dpp_xor4(nv2);
@@ -552,7 +562,6 @@ __device__ __forceinline__ void riccati_vec_segments(const int b, const DevOcp *
     if (sg == 0 && lane < NV) { dx[lane] = 0.0; dx[NV + lane] = 0.0; }
     forward_seg<NV, true>(ta, tb, dq, dv, dts, qb, Kw, kw, dx, ws);
   }
-  (void)P;
 }
 
 // One workgroup of kSeg waves per instance: a factorisation sweep runs on wave 0 alone (the Riccati recursion itself is
