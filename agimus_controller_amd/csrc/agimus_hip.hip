@@ -68,6 +68,7 @@ struct agx_ocp {
   bool lanes_coll = false;  // ... in its variant with one collision cost row
   bool speculate = true;  // AGX_SPECULATE_GAINS=0: gains sweep only on exit
   bool gains_mfma = true; // AGX_GAINS_MFMA=0: scalar K = M Kw - taux for large models
+  bool riccati_mx = true;    // AGX_RICCATI_MX=0: nv <= 7 sweeps on the 8 x 8 lane grid (k_riccati) instead of the MFMA operand layout (k_riccati_mx)
   bool riccati_mfma = true;  // AGX_RICCATI_MFMA=0: large models sweep with the LDS Gauss-Jordan kernel (k_riccati_big)
   bool k1_fused = true;     // AGX_K1_FUSED=0: running and terminal nodes of the derivative pass as two launches (profiling)
   // Batch policy (agx_ocp_set_quorum): the SQP loop of a batch step ends once this fraction of the instances has
@@ -315,9 +316,15 @@ int launch_riccati(agx_ocp *o, int forward, bool pair = false, int iter = 0, con
     constexpr int NV = decltype(NVc)::value;
     const double *qt = tiles ? tiles : o->d_qt;
     if constexpr (NV <= 7) {
-      if (pair)
+      if (pair && o->riccati_mx)
+        hipLaunchKernelGGL((agx::k_riccati_mx_pair<NV>), dim3(2 * o->B), dim3(64), 0, o->stream, o->d_ocp, o->d_dt, o->d_qt, o->d_aux,
+                           o->d_Kws, o->d_kws, o->d_dx, o->d_w, o->d_Kout, o->d_state, iter);
+      else if (pair)
         hipLaunchKernelGGL((agx::k_riccati_pair<NV>), dim3(2 * o->B), dim3(64), 0, o->stream, o->d_ocp, o->d_dt, o->d_qt, o->d_aux,
                            o->d_Kws, o->d_kws, o->d_dx, o->d_w, o->d_du, o->d_Kout, o->d_state, iter);
+      else if (o->riccati_mx)
+        hipLaunchKernelGGL((agx::k_riccati_mx<NV, false>), dim3(o->B), dim3(64), 0, o->stream, o->d_ocp, o->d_dt, qt, o->d_aux,
+                           o->d_Kws, o->d_kws, o->d_dx, o->d_w, o->d_Kout, o->d_state, forward, 0);
       else
         hipLaunchKernelGGL((agx::k_riccati<NV, false>), dim3(o->B), dim3(64), 0, o->stream, o->d_ocp, o->d_dt, qt, o->d_aux,
                            o->d_Kws, o->d_kws, o->d_dx, o->d_w, o->d_du, o->d_Kout, o->d_state, forward, 0);
@@ -399,6 +406,10 @@ int launch_gains(agx_ocp *o, int gmode = 0) {
   return dispatch(o->nv, o->chain, [&](auto NVc, auto CHc) -> int {
     constexpr int NV = decltype(NVc)::value;
     if constexpr (NV <= 7) {
+      if (o->riccati_mx)
+        hipLaunchKernelGGL((agx::k_riccati_mx<NV, true>), dim3(o->B), dim3(64), 0, o->stream, o->d_ocp, o->d_dt, o->d_qt, o->d_aux, o->d_Kws,
+                           o->d_kws, o->d_dx, o->d_w, o->d_Kout, o->d_state, 0, gmode);
+      else
       hipLaunchKernelGGL((agx::k_riccati<NV, true>), dim3(o->B), dim3(64), 0, o->stream, o->d_ocp, o->d_dt, o->d_qt, o->d_aux, o->d_Kws,
                          o->d_kws, o->d_dx, o->d_w, o->d_du, o->d_Kout, o->d_state, 0, gmode);
     } else {
@@ -771,6 +782,7 @@ int agx_ocp_create(const agx_model *m, const agx_ocp_desc *d, int batch, int dev
   if (const char *e = getenv("AGX_SPECULATE_GAINS")) o->speculate = (e[0] != '0');
   if (const char *e = getenv("AGX_GAINS_MFMA")) o->gains_mfma = (e[0] != '0');
   if (const char *e = getenv("AGX_RICCATI_MFMA")) o->riccati_mfma = (e[0] != '0');
+  if (const char *e = getenv("AGX_RICCATI_MX")) o->riccati_mx = (e[0] != '0');
   if (const char *e = getenv("AGX_QUEUE_AHEAD")) o->queue_ahead = (e[0] != '0');
   if (const char *e = getenv("AGX_K1_FUSED")) o->k1_fused = (e[0] != '0');
   o->T = d->horizon; o->B = batch; o->device = device;

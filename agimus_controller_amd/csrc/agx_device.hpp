@@ -111,9 +111,9 @@ __device__ __forceinline__ double dpp_xor1(double x) { return dpp_mov<0xB1>(x); 
 __device__ __forceinline__ double dpp_xor2(double x) { return dpp_mov<0x4E>(x); }  // quad_perm [2,3,0,1]
 __device__ __forceinline__ double dpp_xor4(double x) {                            // lanes 0-3 <-> 4-7 of each group
   const int lo = __double2loint(x), hi = __double2hiint(x);
-  int l2 = dpp_i32<0x104, 0x5>(0, lo);  // row_shl:4 into banks 0, 2
-  l2 = dpp_i32<0x114, 0xa>(l2, lo);     // row_shr:4 into banks 1, 3
-  int h2 = dpp_i32<0x104, 0x5>(0, hi);
+  int l2 = __builtin_amdgcn_mov_dpp(lo, 0x104, 0xf, 0xf, true);  // row_shl:4 (banks 0, 2 keep it)
+  l2 = dpp_i32<0x114, 0xa>(l2, lo);                               // row_shr:4 into banks 1, 3
+  int h2 = __builtin_amdgcn_mov_dpp(hi, 0x104, 0xf, 0xf, true);
   h2 = dpp_i32<0x114, 0xa>(h2, hi);
   return __hiloint2double(h2, l2);
 }

@@ -467,17 +467,19 @@ __device__ __forceinline__ double wave_sum(double v) {
 // the feed-forward kw.  Per pivot: 6 cross-lane fetches (column k of the lane's row, row k of
 // the lane's column), 12 FMAs.
 // ---------------------------------------------------------------------------
-// value held by lane (my row, column K) of the 8 x 8 lane grid, K a compile-time constant: DPP
-// row_share inside the 16-lane DPP row (two grid rows), one pass per half selected by the bank mask.
+// value held by lane (my row, column K) of the 8 x 8 lane grid, K a compile-time constant.  gfx950's
+// double-precision ALU takes a DPP operand for the row_newbcast control only (v_mov_b64_dpp): one
+// broadcast of lane K over the whole 16-lane DPP row (two grid rows), then lane 8 + K over the upper
+// grid row through the bank mask -- two 64-bit moves instead of four 32-bit ones plus the zero fill.
 template <int K>
 __device__ __forceinline__ double grid_col(double x) {
-  const int lo = __double2loint(x), hi = __double2hiint(x);
-  int lo2 = __builtin_amdgcn_update_dpp(0, lo, 0x150 + K, 0xf, 0x3, false);
-  lo2 = __builtin_amdgcn_update_dpp(lo2, lo, 0x150 + 8 + K, 0xf, 0xc, false);
-  int hi2 = __builtin_amdgcn_update_dpp(0, hi, 0x150 + K, 0xf, 0x3, false);
-  hi2 = __builtin_amdgcn_update_dpp(hi2, hi, 0x150 + 8 + K, 0xf, 0xc, false);
-  return __hiloint2double(hi2, lo2);
+  double d = __builtin_amdgcn_mov_dpp(x, 0x150 + K, 0xf, 0xf, false);
+  return __builtin_amdgcn_update_dpp(d, x, 0x150 + 8 + K, 0xf, 0xc, false);
 }
+// In front of a software-pipelined loop that keeps several nodes of loads in flight: wait for the loads of
+// the prologue once.  The compiler's s_waitcnt at the loop head is the minimum over the paths that reach it,
+// and the prologue (whose loads it is free to reorder) would otherwise pin it near vmcnt(0) on every pass.
+__device__ __forceinline__ void prefetch_queue_settle() { __builtin_amdgcn_s_waitcnt(0x0f70); }  // vmcnt(0)
 __device__ __forceinline__ double fast_rcp(double x) {
   double y = __builtin_amdgcn_rcp(x);
   y = y * (2.0 - x * y);
@@ -528,7 +530,9 @@ __device__ __forceinline__ void riccati_forward(const int b, const int T, const 
     const double h = g.h, h2 = h * h;
     double p = g.kq * dq_c + g.kv * dv_c;
     const double kwv = g.kw, fqc = g.fq, fvc = g.fv;
-    if (t + FWD_DEPTH < T) load_gain(g, t + FWD_DEPTH);  // refill this register set FWD_DEPTH nodes ahead
+    // refill this register set FWD_DEPTH nodes ahead -- unconditionally (the last node again at the end): behind a
+    // branch the loaded values become loop-carried through a join and a vmcnt(0) drains the queue on every pass
+    load_gain(g, t + FWD_DEPTH < T ? t + FWD_DEPTH : T - 1);
     p += dpp_xor1(p); p += dpp_xor2(p); p += dpp_xor4(p);  // row sum, on every lane of the row
     const double wv = -(kwv + p);
     const double nq = dq_r + h * dv_r + h2 * wv + fqc;
@@ -542,14 +546,22 @@ __device__ __forceinline__ void riccati_forward(const int b, const int T, const 
       dx[(long long)(t + 1) * NX + NV + r] = nv2;
     }
   };
-  Gain g[FWD_DEPTH];
+  int t = 0;
+  // the nodes that do not fill a group first, one at a time; the pipelined loop then runs whole groups
+  for (int rem = T % FWD_DEPTH; rem > 0; --rem, ++t) {
+    Gain g1;
+    load_gain(g1, t);
+    fstep(g1, t);
+  }
+  if (t < T) {
+    Gain g[FWD_DEPTH];
 #pragma unroll
-  for (int i = 0; i < FWD_DEPTH; ++i)
-    if (i < T) load_gain(g[i], i);
-  for (int t = 0; t < T; t += FWD_DEPTH) {
+    for (int i = 0; i < FWD_DEPTH; ++i) load_gain(g[i], t + i);
+    prefetch_queue_settle();
+    for (; t < T; t += FWD_DEPTH) {
 #pragma unroll
-    for (int i = 0; i < FWD_DEPTH; ++i)
-      if (t + i < T) fstep(g[i], t + i);
+      for (int i = 0; i < FWD_DEPTH; ++i) fstep(g[i], t + i);
+    }
   }
 }
 
@@ -812,6 +824,10 @@ __global__ void __launch_bounds__(64) k_riccati_pair(const DevOcp *__restrict__ 
   else
     riccati_body<NV, false>(b, op, dts, qts, auxs, Kws, kws, dxs, wss, dus, Kout, st, 1, 0, iter);
 }
+
+}  // namespace agx
+#include "agx_riccati_mx.hpp"  // the same sweep in the MFMA operand layout (default for NV <= 7)
+namespace agx {
 
 // ---------------------------------------------------------------------------
 // K3: per-node quantities of the direction, node parallel with 8 lanes per node:

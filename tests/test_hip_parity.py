@@ -90,6 +90,30 @@ def test_direction_kernels_against_oracle(hip_backend, panda):
     np.testing.assert_allclose(kkt, kkto, rtol=1e-7)
 
 
+@pytest.mark.parametrize("name,T,timesteps", [("panda", 100, None), ("panda", 61, [0.01] * 31 + [0.02] * 20 + [0.04] * 10),
+                                              ("panda", 511, None), ("chain4", 37, None), ("chain6", 18, None), ("pendulum", 9, None)])
+def test_mfma_layout_sweep_agrees_with_the_lane_grid_sweep(hip_backend, monkeypatch, name, T, timesteps):
+    """K2 has two implementations for nv <= 7: the 8 x 8 lane grid (k_riccati, AGX_RICCATI_MX=0) and the MFMA operand
+    layout (k_riccati_mx, default).  Same tiles in, same direction / gains out to round-off -- over a long horizon
+    too: the MFMA sweep symmetrises the value function at every node, without which round-off asymmetry grows
+    ~1.5 x per node (visible beyond ~50 nodes)."""
+    table = MODELS[name]()
+    B = 3
+    po, ref, x0, xs, us = workloads.random_goal_problem(table, T, 0.01, B, seed=31, frame=len(table.frame_names) - 1, timesteps=timesteps)
+    xs[:, 0] = x0
+    out = {}
+    for mx in ("0", "1"):
+        monkeypatch.setenv("AGX_RICCATI_MX", mx)
+        h = hip_backend.HipOcp(table, po, B)
+        h.set_refs(ref)
+        h.upload_warmstart(xs, us)
+        out[mx] = h.direction()
+        h.close()
+    for a, b, tol in zip(out["0"], out["1"], (1e-9, 1e-9, 1e-10, 1e-10, 1e-10)):  # K, k, dx, du, kkt
+        assert np.isfinite(b).all()
+        assert rel(b, a) < tol
+
+
 @pytest.mark.parametrize("name,rows,T,seed", [("panda", "goal", 25, 10), ("panda", "reg", 40, 11), ("chain4", "goal", 12, 12), ("chain6", "goal", 15, 13)])
 def test_full_solve_matches_oracle(hip_backend, name, rows, T, seed):
     table = MODELS[name]()
