@@ -276,7 +276,6 @@ __device__ __forceinline__ void riccati_vec_body(const int b, const DevOcp *__re
     double f[NV];
 #pragma unroll
     for (int k = 0; k < NV; ++k) f[k] = z.f[k];
-    if (t >= 4) load_node(z, t - 4);
 #pragma unroll
     for (int k = 0; k < NV; ++k) {
       const double gk = readlane_f64(g, 8 * k);  // gW of row k (its own factor fw[k] is 0 there)
@@ -284,17 +283,23 @@ __device__ __forceinline__ void riccati_vec_body(const int b, const DevOcp *__re
     }
     if (c == 0 && r < NV) kw[(long long)t * NV + r] = g * rp;
     v = g;
+    load_node(z, t >= 4 ? t - 4 : 0);  // unconditional, after the last use of the old contents (see agx_riccati_mx.hpp)
   };
-  Node n0, n1, n2, n3;
-  load_node(n0, T - 1);
-  if (T >= 2) load_node(n1, T - 2);
-  if (T >= 3) load_node(n2, T - 3);
-  if (T >= 4) load_node(n3, T - 4);
-  for (int t = T - 1; t >= 0; t -= 4) {
-    step(n0, t);
-    if (t >= 1) step(n1, t - 1);
-    if (t >= 2) step(n2, t - 2);
-    if (t >= 3) step(n3, t - 3);
+  int t = T - 1;
+  for (int rem = T % 4; rem > 0; --rem, --t) {
+    Node z;
+    load_node(z, t);
+    step(z, t);
+  }
+  if (t >= 0) {
+    Node n[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) load_node(n[i], t - i);
+    prefetch_queue_settle();
+    for (; t >= 0; t -= 4) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) step(n[i], t - i);
+    }
   }
   riccati_forward<NV>(b, T, dts, qb, Kw, kw, dxs, wss);
 }
@@ -394,7 +399,6 @@ __device__ __forceinline__ double vec_backward_seg(const int t_lo, const int t_h
     double f[NV];
 #pragma unroll
     for (int k = 0; k < NV; ++k) f[k] = z.f[k];
-    if (t - 4 >= t_lo) load_node(z, t - 4);
 #pragma unroll
     for (int k = 0; k < NV; ++k) {
       const double gk = readlane_f64(g, 8 * k);
@@ -402,18 +406,24 @@ __device__ __forceinline__ double vec_backward_seg(const int t_lo, const int t_h
     }
     if (STORE_KW && c == 0 && r < NV) kw[(long long)t * NV + r] = g * rp;
     v = g;
+    load_node(z, t - 4 >= t_lo ? t - 4 : t_lo);  // unconditional, after the last use of the old contents (see agx_riccati_mx.hpp)
   };
   if (t_hi <= t_lo) return v;
-  Node n0, n1, n2, n3;
-  load_node(n0, t_hi - 1);
-  if (t_hi - 2 >= t_lo) load_node(n1, t_hi - 2);
-  if (t_hi - 3 >= t_lo) load_node(n2, t_hi - 3);
-  if (t_hi - 4 >= t_lo) load_node(n3, t_hi - 4);
-  for (int t = t_hi - 1; t >= t_lo; t -= 4) {
-    step(n0, t);
-    if (t - 1 >= t_lo) step(n1, t - 1);
-    if (t - 2 >= t_lo) step(n2, t - 2);
-    if (t - 3 >= t_lo) step(n3, t - 3);
+  int t = t_hi - 1;
+  for (int rem = (t_hi - t_lo) % 4; rem > 0; --rem, --t) {
+    Node z;
+    load_node(z, t);
+    step(z, t);
+  }
+  if (t >= t_lo) {
+    Node n[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) load_node(n[i], t - i);
+    prefetch_queue_settle();
+    for (; t >= t_lo; t -= 4) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) step(n[i], t - i);
+    }
   }
   return v;
 }
@@ -447,7 +457,6 @@ __device__ __forceinline__ void forward_seg(const int t_lo, const int t_hi, doub
     const double h = g.h, h2 = h * h;
     double p = g.kq * dq_c + g.kv * dv_c;
     const double kwv = g.kw, fqc = g.fq, fvc = g.fv;
-    if (t + DEPTH < t_hi) load_gain(g, t + DEPTH);
     p += dpp_xor1(p); p += dpp_xor2(p); p += dpp_xor4(p);
     const double wv = -(kwv + p);
     const double nq = dq_r + h * dv_r + h2 * wv + fqc;
@@ -460,15 +469,24 @@ __device__ __forceinline__ void forward_seg(const int t_lo, const int t_hi, doub
       dx[(long long)(t + 1) * NX + r] = nq;
       dx[(long long)(t + 1) * NX + NV + r] = nv2;
     }
+    load_gain(g, t + DEPTH < t_hi ? t + DEPTH : t_hi - 1);  // unconditional, at the end (see riccati_forward)
   };
-  Gain g[DEPTH];
+  if (t_hi <= t_lo) return;
+  int t = t_lo;
+  for (int rem = (t_hi - t_lo) % DEPTH; rem > 0; --rem, ++t) {
+    Gain g1;
+    load_gain(g1, t);
+    fstep(g1, t);
+  }
+  if (t < t_hi) {
+    Gain g[DEPTH];
 #pragma unroll
-  for (int i = 0; i < DEPTH; ++i)
-    if (t_lo + i < t_hi) load_gain(g[i], t_lo + i);
-  for (int t = t_lo; t < t_hi; t += DEPTH) {
+    for (int i = 0; i < DEPTH; ++i) load_gain(g[i], t + i);
+    prefetch_queue_settle();
+    for (; t < t_hi; t += DEPTH) {
 #pragma unroll
-    for (int i = 0; i < DEPTH; ++i)
-      if (t + i < t_hi) fstep(g[i], t + i);
+      for (int i = 0; i < DEPTH; ++i) fstep(g[i], t + i);
+    }
   }
 }
 

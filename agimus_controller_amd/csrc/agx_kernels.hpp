@@ -530,9 +530,6 @@ __device__ __forceinline__ void riccati_forward(const int b, const int T, const 
     const double h = g.h, h2 = h * h;
     double p = g.kq * dq_c + g.kv * dv_c;
     const double kwv = g.kw, fqc = g.fq, fvc = g.fv;
-    // refill this register set FWD_DEPTH nodes ahead -- unconditionally (the last node again at the end): behind a
-    // branch the loaded values become loop-carried through a join and a vmcnt(0) drains the queue on every pass
-    load_gain(g, t + FWD_DEPTH < T ? t + FWD_DEPTH : T - 1);
     p += dpp_xor1(p); p += dpp_xor2(p); p += dpp_xor4(p);  // row sum, on every lane of the row
     const double wv = -(kwv + p);
     const double nq = dq_r + h * dv_r + h2 * wv + fqc;
@@ -545,6 +542,9 @@ __device__ __forceinline__ void riccati_forward(const int b, const int T, const 
       dx[(long long)(t + 1) * NX + r] = nq;
       dx[(long long)(t + 1) * NX + NV + r] = nv2;
     }
+    // refill this register set FWD_DEPTH nodes ahead: after the last use of its old contents and unconditionally
+    // (the last node again at the end) -- see the note on the loop latch in agx_riccati_mx.hpp
+    load_gain(g, t + FWD_DEPTH < T ? t + FWD_DEPTH : T - 1);
   };
   int t = 0;
   // the nodes that do not fill a group first, one at a time; the pipelined loop then runs whole groups
@@ -621,7 +621,8 @@ __device__ __forceinline__ void riccati_body(const int b, const DevOcp *__restri
     vxq = (r < NV) ? tt[Q::gx + rr] : 0.0;
     vxv = (r < NV) ? tt[Q::gx + NV + rr] : 0.0;
   }
-  // tile elements of a node, prefetched TWO nodes ahead into two register sets
+  // tile elements of a node, prefetched kGridDepth nodes ahead into as many register sets
+  constexpr int kGridDepth = 4;
   struct Tile {
     double hqq, hqv, hvq, hvv, hqw, hvw, hwq, hwv, hww, gq, gv, gwr, fq, fv;
   };
@@ -655,7 +656,7 @@ __device__ __forceinline__ void riccati_body(const int b, const DevOcp *__restri
   };
   auto step = [&](Tile &z, int t) {
     const double h = dts[t], h2 = h * h;
-    // current tile -> working copies, then refill this register set with the tile two nodes ahead
+    // current tile -> working copies (the register set is refilled at the end of the step)
     double Hqq_ = z.hqq, Hqv_ = z.hqv, Hvq_ = z.hvq, Hvv_ = z.hvv, Hqw_ = z.hqw, Hvw_ = z.hvw, Hwq_ = z.hwq, Hwv_ = z.hwv, Hww_ = z.hww;
     const double gq_ = GAINS ? 0.0 : z.gq, gv_ = GAINS ? 0.0 : z.gv, gw_ = GAINS ? 0.0 : z.gwr;
     const double fq_ = (c < NV && !GAINS) ? z.fq : 0.0, fv_ = (c < NV && !GAINS) ? z.fv : 0.0;
@@ -684,7 +685,6 @@ AGX_UNROLL_NV
       Hqq_ += sig * (xqq + diag); Hqv_ += sig * xqv; Hvq_ += sig * xvq; Hvv_ += sig * (xvv + diag);
       tq_rc = sa[A::tq + rc]; tv_rc = sa[A::tv + rc];
     }
-    if (t >= 2) load_tile(z, t - 2);
     // ---- phase A
     // The gradient rides in the spare grid column c = 7 of the w column block (NV <= 7):
     // lane (r, 7) keeps qw[r] in Mww, qx[r] in Mqw / Mvw, so the pivots below update it like any
@@ -775,14 +775,26 @@ AGX_UNROLL_NV
     // value function of node t
     Vqq = Mqq + dreg * diag; Vqv = Mqv; Vvq = Mvq; Vvv = Mvv + dreg * diag;  // (sigma is part of H at every node)
     if (!in) { Vqq = 0.0; Vqv = 0.0; Vvq = 0.0; Vvv = 0.0; }
+    // refill this register set: after the last use of its old contents and unconditionally (node 0 again at the
+    // end), so that no register copy -- and no s_waitcnt vmcnt(0) -- sits on the loop latch (see agx_riccati_mx.hpp)
+    load_tile(z, t >= kGridDepth ? t - kGridDepth : 0);
   };
-  Tile ta, tb;
   if (GAINS) { aux_fetch(T - 1); aux_put(T - 1); if (T >= 2) aux_fetch(T - 2); }
-  load_tile(ta, T - 1);
-  if (T >= 2) load_tile(tb, T - 2);
-  for (int t = T - 1; t >= 0; t -= 2) {
-    step(ta, t);
-    if (t >= 1) step(tb, t - 1);
+  int t = T - 1;
+  for (int rem = T % kGridDepth; rem > 0; --rem, --t) {  // the nodes that do not fill a group, one at a time
+    Tile z;
+    load_tile(z, t);
+    step(z, t);
+  }
+  if (t >= 0) {
+    Tile tl[kGridDepth];
+#pragma unroll
+    for (int i = 0; i < kGridDepth; ++i) load_tile(tl[i], t - i);
+    prefetch_queue_settle();
+    for (; t >= 0; t -= kGridDepth) {
+#pragma unroll
+      for (int i = 0; i < kGridDepth; ++i) step(tl[i], t - i);
+    }
   }
   if (!GAINS) {
     // Quu of some node not positive definite (SolverCSQP: the LLT of the backward pass fails and the
