@@ -312,6 +312,7 @@ int launch_calc_qp(agx_ocp *o, bool running_only = false, bool term_only = false
 
 // K2: direction sweep; with `pair` the speculative gains sweep of SQP iteration `iter` rides in the same launch
 int launch_riccati(agx_ocp *o, int forward, bool pair = false, int iter = 0, const double *tiles = nullptr) {
+  if (o->nv <= 7 && o->T + 1 > 512) return fail("the sweeps stage the step lengths of up to 511 nodes in LDS: horizon too long");
   return dispatch(o->nv, o->chain, [&](auto NVc, auto CHc) -> int {
     constexpr int NV = decltype(NVc)::value;
     const double *qt = tiles ? tiles : o->d_qt;
@@ -402,6 +403,7 @@ int launch_step(agx_ocp *o, int iter, int max_iter, int mode, bool with_node_kkt
 // exit path: the sigma (proximal) Riccati sweep that yields the gains the solver reports, one kernel.
 // gmode 0: every instance; 2: only instances whose last direction has no (speculative) sweep yet.
 int launch_gains(agx_ocp *o, int gmode = 0) {
+  if (o->nv <= 7 && o->T + 1 > 512) return fail("the sweeps stage the step lengths of up to 511 nodes in LDS: horizon too long");
   if (o->nv > 7 && !o->d_qt2) HIPCHK(hipMalloc((void **)&o->d_qt2, sizeof(double) * (size_t)o->B * (o->T + 1) * o->qt_size));
   return dispatch(o->nv, o->chain, [&](auto NVc, auto CHc) -> int {
     constexpr int NV = decltype(NVc)::value;

@@ -254,20 +254,19 @@ __device__ __forceinline__ void riccati_vec_body(const int b, const DevOcp *__re
   const int foff = sel == 0 ? F::FW : (sel == 1 ? F::FQ : F::FV);
   const int poff = sel == 2 ? F::PV : F::PQ;
   double v = qb[(long long)T * TS + (sel == 2 ? Q::gx + NV : Q::gx) + rr];  // value-function gradient (c = 1: q, c = 2: v)
-  struct Node { double g, rp, p, h, f[NV]; };
-  int vzero;  // dts through the vector memory path, see riccati_forward
-  asm volatile("v_mov_b32 %0, 0" : "=v"(vzero));
+  struct Node { double g, rp, p, f[NV]; };
+  __shared__ double s_dt[kMaxHorizon];  // step lengths (see stage_dts)
+  stage_dts(s_dt, dts, T);
   auto load_node = [&](Node &z, int t) {
     const double *tl = qb + (long long)t * TS;
     const double *ft = fb + (long long)t * F::SIZE;
     z.g = tl[goff + rr];
     z.rp = ft[F::RP + rr]; z.p = ft[poff + rr];
-    z.h = dts[t + vzero];
 #pragma unroll
     for (int k = 0; k < NV; ++k) z.f[k] = ft[foff + k * 8 + rr];
   };
   auto step = [&](Node &z, int t) {
-    const double h = z.h, h2 = h * h;
+    const double h = s_dt[t], h2 = h * h;
     const double vp = v + z.p;
     const double vpq = dpp_mov<0x55>(vp), vpv = dpp_mov<0xAA>(vp);  // quad broadcast of lanes c = 1 / c = 2
     const double ca = sel == 0 ? h2 : (sel == 1 ? 1.0 : h), cb = sel == 0 ? h : (sel == 1 ? 0.0 : 1.0);
@@ -301,7 +300,7 @@ __device__ __forceinline__ void riccati_vec_body(const int b, const DevOcp *__re
       for (int i = 0; i < 4; ++i) step(n[i], t - i);
     }
   }
-  riccati_forward<NV>(b, T, dts, qb, Kw, kw, dxs, wss);
+  riccati_forward<NV>(b, T, dts, qb, Kw, kw, dxs, wss, s_dt);
 }
 
 // ---------------------------------------------------------------------------
@@ -366,7 +365,7 @@ __global__ void __launch_bounds__(64) k_seg_products(const DevOcp *__restrict__ 
 // backward gradient recursion over the nodes t_hi-1 .. t_lo of one segment (see riccati_vec_body); v: the value gradient
 // on the lanes c = 1 (q) and c = 2 (v) of grid row r, in: boundary value, out: value at t_lo
 template <int NV, bool STORE_KW>
-__device__ __forceinline__ double vec_backward_seg(const int t_lo, const int t_hi, double v, const double *__restrict__ dts,
+__device__ __forceinline__ double vec_backward_seg(const int t_lo, const int t_hi, double v, const double *s_dt,
                                                    const double *__restrict__ qb, const double *__restrict__ fb, double *__restrict__ kw) {
   constexpr int TS = QT<NV>::SIZE;
   typedef QT<NV> Q;
@@ -377,20 +376,17 @@ __device__ __forceinline__ double vec_backward_seg(const int t_lo, const int t_h
   const int goff = sel == 0 ? Q::gw : (sel == 1 ? Q::gx : Q::gx + NV);
   const int foff = sel == 0 ? F::FW : (sel == 1 ? F::FQ : F::FV);
   const int poff = sel == 2 ? F::PV : F::PQ;
-  struct Node { double g, rp, p, h, f[NV]; };
-  int vzero;  // dts through the vector memory path, see riccati_forward
-  asm volatile("v_mov_b32 %0, 0" : "=v"(vzero));
+  struct Node { double g, rp, p, f[NV]; };
   auto load_node = [&](Node &z, int t) {
     const double *tl = qb + (long long)t * TS;
     const double *ft = fb + (long long)t * F::SIZE;
     z.g = tl[goff + rr];
     z.rp = ft[F::RP + rr]; z.p = ft[poff + rr];
-    z.h = dts[t + vzero];
 #pragma unroll
     for (int k = 0; k < NV; ++k) z.f[k] = ft[foff + k * 8 + rr];
   };
   auto step = [&](Node &z, int t) {
-    const double h = z.h, h2 = h * h;
+    const double h = s_dt[t], h2 = h * h;
     const double vp = v + z.p;
     const double vpq = dpp_mov<0x55>(vp), vpv = dpp_mov<0xAA>(vp);  // quad broadcast of lanes c = 1 / c = 2
     const double ca = sel == 0 ? h2 : (sel == 1 ? 1.0 : h), cb = sel == 0 ? h : (sel == 1 ? 0.0 : 1.0);
@@ -431,7 +427,7 @@ __device__ __forceinline__ double vec_backward_seg(const int t_lo, const int t_h
 // forward pass over the nodes t_lo .. t_hi-1 of one segment (see riccati_forward); the state enters / leaves indexed by the
 // lane's grid row (dq_r, dv_r)
 template <int NV, bool STORE>
-__device__ __forceinline__ void forward_seg(const int t_lo, const int t_hi, double &dq_r, double &dv_r, const double *__restrict__ dts,
+__device__ __forceinline__ void forward_seg(const int t_lo, const int t_hi, double &dq_r, double &dv_r, const double *s_dt,
                                             const double *__restrict__ qb, const double *__restrict__ Kw, const double *__restrict__ kw,
                                             double *__restrict__ dx, double *__restrict__ ws) {
   constexpr int NX = 2 * NV, TS = QT<NV>::SIZE;
@@ -440,9 +436,7 @@ __device__ __forceinline__ void forward_seg(const int t_lo, const int t_hi, doub
   const bool in = (r < NV) && (c < NV);
   const int rr = r < NV ? r : 0, cc = c < NV ? c : 0;
   double dq_c = __shfl(dq_r, 8 * cc, 64), dv_c = __shfl(dv_r, 8 * cc, 64);
-  struct Gain { double kq, kv, kw, fq, fv, h; };
-  int vzero;
-  asm volatile("v_mov_b32 %0, 0" : "=v"(vzero));
+  struct Gain { double kq, kv, kw, fq, fv; };
   constexpr int DEPTH = 4;
   auto load_gain = [&](Gain &g, int t) {
     const double *kr = Kw + ((long long)t * NV + rr) * NX;
@@ -451,10 +445,9 @@ __device__ __forceinline__ void forward_seg(const int t_lo, const int t_hi, doub
     g.kw = kw[(long long)t * NV + rr];
     g.fq = qb[(long long)t * TS + Q::f + rr];
     g.fv = qb[(long long)t * TS + Q::f + NV + rr];
-    g.h = dts[t + vzero];
   };
   auto fstep = [&](Gain &g, int t) {
-    const double h = g.h, h2 = h * h;
+    const double h = s_dt[t], h2 = h * h;
     double p = g.kq * dq_c + g.kv * dv_c;
     const double kwv = g.kw, fqc = g.fq, fvc = g.fv;
     p += dpp_xor1(p); p += dpp_xor2(p); p += dpp_xor4(p);
@@ -499,8 +492,11 @@ __device__ __forceinline__ void riccati_vec_segments(const int b, const DevOcp *
   typedef QT<NV> Q;
   typedef FT<NV> F;
   __shared__ double s_off[kSeg][2][8], s_in[kSeg][2][8];  // segment offsets / boundary values (q | v), indexed by joint
+  __shared__ double s_dt[kMaxHorizon];                     // step lengths (see stage_dts)
   const DevOcp &o = *op;
   const int T = o.T, lane = threadIdx.x & 63, sg = threadIdx.x >> 6;
+  for (int i = threadIdx.x; i < T; i += blockDim.x) s_dt[i] = dts[i];
+  __syncthreads();
   const int r = lane >> 3, c = lane & 7;
   const int rr = r < NV ? r : 0, cc = c < NV ? c : 0;
   const int L = seg_len(T), ta = min(T, sg * L), tb = min(T, ta + L);
@@ -520,7 +516,7 @@ __device__ __forceinline__ void riccati_vec_segments(const int b, const DevOcp *
   }
   // ---- backward 1: offsets from a zero boundary value
   {
-    const double v = vec_backward_seg<NV, false>(ta, tb, 0.0, dts, qb, fb, kw);
+    const double v = vec_backward_seg<NV, false>(ta, tb, 0.0, s_dt, qb, fb, kw);
     if ((c == 1 || c == 2) && r < 8) s_off[sg][c - 1][r] = (r < NV) ? v : 0.0;
   }
   __syncthreads();
@@ -545,13 +541,13 @@ __device__ __forceinline__ void riccati_vec_segments(const int b, const DevOcp *
   // ---- backward 3: the segment again from its true boundary value, gains feed-forward kw stored
   {
     const double v0 = s_in[sg][sel == 2 ? 1 : 0][rr];
-    vec_backward_seg<NV, true>(ta, tb, v0, dts, qb, fb, kw);
+    vec_backward_seg<NV, true>(ta, tb, v0, s_dt, qb, fb, kw);
   }
   __threadfence_block();  // kw of this segment is read back by other lanes of the wave below
   // ---- forward 1: offsets from a zero state
   {
     double dq = 0.0, dv = 0.0;
-    forward_seg<NV, false>(ta, tb, dq, dv, dts, qb, Kw, kw, nullptr, nullptr);
+    forward_seg<NV, false>(ta, tb, dq, dv, s_dt, qb, Kw, kw, nullptr, nullptr);
     __syncthreads();  // s_off is free again (everyone is past backward 2 / 3 reads of it)
     if (c == 0 && r < 8) { s_off[sg][0][r] = dq; s_off[sg][1][r] = dv; }
   }
@@ -578,7 +574,7 @@ __device__ __forceinline__ void riccati_vec_segments(const int b, const DevOcp *
     double dq = s_in[sg][0][rr], dv = s_in[sg][1][rr];
     double *dx = dxs + (long long)b * (T + 1) * NX, *ws = wss + (long long)b * T * NV;
     if (sg == 0 && lane < NV) { dx[lane] = 0.0; dx[NV + lane] = 0.0; }
-    forward_seg<NV, true>(ta, tb, dq, dv, dts, qb, Kw, kw, dx, ws);
+    forward_seg<NV, true>(ta, tb, dq, dv, s_dt, qb, Kw, kw, dx, ws);
   }
 }
 

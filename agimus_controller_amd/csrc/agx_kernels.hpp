@@ -480,6 +480,15 @@ __device__ __forceinline__ double grid_col(double x) {
 // the prologue once.  The compiler's s_waitcnt at the loop head is the minimum over the paths that reach it,
 // and the prologue (whose loads it is free to reorder) would otherwise pin it near vmcnt(0) on every pass.
 __device__ __forceinline__ void prefetch_queue_settle() { __builtin_amdgcn_s_waitcnt(0x0f70); }  // vmcnt(0)
+// Step lengths of the horizon for the time-serial sweeps, staged in LDS once per wave.  Read per node from global
+// memory they sit at the end of every group of prefetch loads: the scalar path would put an s_waitcnt lgkmcnt(0)
+// on every node, and on the vector path the compiler gathers the loads of the unrolled steps at the top of the
+// loop, where waiting for them (vmcnt counts in order) drains the tile prefetch queue behind them.
+constexpr int kMaxHorizon = 512;  // nodes per instance the sweeps (and k_step) take; checked on the host
+__device__ __forceinline__ void stage_dts(double *__restrict__ s_dt, const double *__restrict__ dts, int T) {
+  for (int i = threadIdx.x & 63; i < T; i += 64) s_dt[i] = dts[i];
+  wave_lds_sync();
+}
 __device__ __forceinline__ double fast_rcp(double x) {
   double y = __builtin_amdgcn_rcp(x);
   y = y * (2.0 - x * y);
@@ -500,7 +509,7 @@ __device__ __forceinline__ double fast_rcp(double x) {
 template <int NV>
 __device__ __forceinline__ void riccati_forward(const int b, const int T, const double *__restrict__ dts, const double *__restrict__ qb,
                                                 const double *__restrict__ Kw, const double *__restrict__ kw,
-                                                double *__restrict__ dxs, double *__restrict__ wss) {
+                                                double *__restrict__ dxs, double *__restrict__ wss, const double *s_dt) {
   constexpr int NX = 2 * NV, TS = QT<NV>::SIZE;
   typedef QT<NV> Q;
   const int lane = threadIdx.x;
@@ -511,11 +520,7 @@ __device__ __forceinline__ void riccati_forward(const int b, const int T, const 
   if (lane < NV) { dx[lane] = 0.0; dx[NV + lane] = 0.0; }
   __threadfence_block();  // the gains written by the backward sweep are read back by other lanes below
   double dq_r = 0.0, dv_r = 0.0, dq_c = 0.0, dv_c = 0.0;
-  struct Gain { double kq, kv, kw, fq, fv, h; };
-  // dts through the vector memory path (index laundered through a VGPR): a scalar load would put an
-  // s_waitcnt lgkmcnt(0) -- which also drains the ds_bpermutes -- on every node of the chain
-  int vzero;
-  asm volatile("v_mov_b32 %0, 0" : "=v"(vzero));
+  struct Gain { double kq, kv, kw, fq, fv; };
   constexpr int FWD_DEPTH = 8;  // nodes of gains in flight (4: 36.6 us, 8: 32 us, 12: 28.7 us per 100 nodes; 8 keeps the pair kernel below 256 VGPRs)
   auto load_gain = [&](Gain &g, int t) {
     const double *kr = Kw + ((long long)t * NV + rr) * NX;
@@ -524,10 +529,9 @@ __device__ __forceinline__ void riccati_forward(const int b, const int T, const 
     g.kw = kw[(long long)t * NV + rr];
     g.fq = qb[(long long)t * TS + Q::f + rr];
     g.fv = qb[(long long)t * TS + Q::f + NV + rr];
-    g.h = dts[t + vzero];
   };
   auto fstep = [&](Gain &g, int t) {
-    const double h = g.h, h2 = h * h;
+    const double h = s_dt[t], h2 = h * h;
     double p = g.kq * dq_c + g.kv * dv_c;
     const double kwv = g.kw, fqc = g.fq, fvc = g.fv;
     p += dpp_xor1(p); p += dpp_xor2(p); p += dpp_xor4(p);  // row sum, on every lane of the row
@@ -654,8 +658,10 @@ __device__ __forceinline__ void riccati_body(const int b, const DevOcp *__restri
       z.fq = tl[Q::f + cc]; z.fv = tl[Q::f + NV + cc];
     }
   };
+  __shared__ double s_dt[kMaxHorizon];
+  stage_dts(s_dt, dts, T);
   auto step = [&](Tile &z, int t) {
-    const double h = dts[t], h2 = h * h;
+    const double h = s_dt[t], h2 = h * h;
     // current tile -> working copies (the register set is refilled at the end of the step)
     double Hqq_ = z.hqq, Hqv_ = z.hqv, Hvq_ = z.hvq, Hvv_ = z.hvv, Hqw_ = z.hqw, Hvw_ = z.hvw, Hwq_ = z.hwq, Hwv_ = z.hwv, Hww_ = z.hww;
     const double gq_ = GAINS ? 0.0 : z.gq, gv_ = GAINS ? 0.0 : z.gv, gw_ = GAINS ? 0.0 : z.gwr;
@@ -807,7 +813,7 @@ AGX_UNROLL_NV
     }
   }
   if (GAINS || !forward) return;
-  riccati_forward<NV>(b, T, dts, qb, Kw, kw, dxs, wss);
+  riccati_forward<NV>(b, T, dts, qb, Kw, kw, dxs, wss, s_dt);
 }
 
 template <int NV, bool GAINS>

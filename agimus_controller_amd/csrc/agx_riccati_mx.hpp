@@ -138,10 +138,9 @@ __device__ __forceinline__ void riccati_mx_body(const int b, const DevOcp *__res
     }
   }
 
-  struct Tile { double hxx[4], hwx[2], hww[2], fb[4], tx[2], mt[2], h; };
-  // dts through the vector memory path: a scalar load would put an s_waitcnt lgkmcnt(0) -- which also drains the ds_bpermutes -- on every node
-  int vzero;
-  asm volatile("v_mov_b32 %0, 0" : "=v"(vzero));
+  struct Tile { double hxx[4], hwx[2], hww[2], fb[4], tx[2], mt[2]; };
+  __shared__ double s_dt[kMaxHorizon];
+  stage_dts(s_dt, dts, T);
   auto load_tile = [&](Tile &z, int t) {
     const double *tl = qb + (long long)t * TS;
 #pragma unroll
@@ -159,7 +158,6 @@ __device__ __forceinline__ void riccati_mx_body(const int b, const DevOcp *__res
         z.mt[s] = al[oMt[s]];
       }
     }
-    z.h = dts[t + vzero];
   };
 
   // value function of node t+1: the terminal tile (+ regularisation)
@@ -172,7 +170,7 @@ __device__ __forceinline__ void riccati_mx_body(const int b, const DevOcp *__res
   bool bad_pivot = false;
 
   auto step = [&](Tile &z, int t) {
-    const double h = z.h, h2 = h * h;
+    const double h = s_dt[t], h2 = h * h;
     double Hxx[4] = {z.hxx[0], z.hxx[1], z.hxx[2], z.hxx[3]};
     double Hwx[2] = {z.hwx[0], z.hwx[1]}, Hww[2] = {z.hww[0], z.hww[1]};
     double Tx[2] = {0.0, 0.0}, Mt[2] = {0.0, 0.0};
@@ -295,7 +293,7 @@ __device__ __forceinline__ void riccati_mx_body(const int b, const DevOcp *__res
     }
   }
   if (GAINS || !forward) return;
-  riccati_forward<NV>(b, T, dts, qb, Kws + (long long)b * T * NV * NX, kws + (long long)b * T * NV, dxs, wss);
+  riccati_forward<NV>(b, T, dts, qb, Kws + (long long)b * T * NV * NX, kws + (long long)b * T * NV, dxs, wss, s_dt);
 }
 
 template <int NV, bool GAINS>
