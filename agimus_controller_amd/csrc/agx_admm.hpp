@@ -282,7 +282,9 @@ __device__ __forceinline__ void riccati_vec_body(const int b, const DevOcp *__re
     }
     if (c == 0 && r < NV) kw[(long long)t * NV + r] = g * rp;
     v = g;
+    prefetch_group_begin();
     load_node(z, t >= 4 ? t - 4 : 0);  // unconditional, after the last use of the old contents (see agx_riccati_mx.hpp)
+    prefetch_group_end();
   };
   int t = T - 1;
   for (int rem = T % 4; rem > 0; --rem, --t) {
@@ -294,7 +296,7 @@ __device__ __forceinline__ void riccati_vec_body(const int b, const DevOcp *__re
     Node n[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) load_node(n[i], t - i);
-    prefetch_queue_settle();
+    prefetch_queue_settle(n);
     for (; t >= 0; t -= 4) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) step(n[i], t - i);
@@ -402,7 +404,9 @@ __device__ __forceinline__ double vec_backward_seg(const int t_lo, const int t_h
     }
     if (STORE_KW && c == 0 && r < NV) kw[(long long)t * NV + r] = g * rp;
     v = g;
+    prefetch_group_begin();
     load_node(z, t - 4 >= t_lo ? t - 4 : t_lo);  // unconditional, after the last use of the old contents (see agx_riccati_mx.hpp)
+    prefetch_group_end();
   };
   if (t_hi <= t_lo) return v;
   int t = t_hi - 1;
@@ -415,7 +419,7 @@ __device__ __forceinline__ double vec_backward_seg(const int t_lo, const int t_h
     Node n[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) load_node(n[i], t - i);
-    prefetch_queue_settle();
+    prefetch_queue_settle(n);
     for (; t >= t_lo; t -= 4) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) step(n[i], t - i);
@@ -462,7 +466,9 @@ __device__ __forceinline__ void forward_seg(const int t_lo, const int t_hi, doub
       dx[(long long)(t + 1) * NX + r] = nq;
       dx[(long long)(t + 1) * NX + NV + r] = nv2;
     }
+    prefetch_group_begin();
     load_gain(g, t + DEPTH < t_hi ? t + DEPTH : t_hi - 1);  // unconditional, at the end (see riccati_forward)
+    prefetch_group_end();
   };
   if (t_hi <= t_lo) return;
   int t = t_lo;
@@ -475,7 +481,7 @@ __device__ __forceinline__ void forward_seg(const int t_lo, const int t_hi, doub
     Gain g[DEPTH];
 #pragma unroll
     for (int i = 0; i < DEPTH; ++i) load_gain(g[i], t + i);
-    prefetch_queue_settle();
+    prefetch_queue_settle(g);
     for (; t < t_hi; t += DEPTH) {
 #pragma unroll
       for (int i = 0; i < DEPTH; ++i) fstep(g[i], t + i);

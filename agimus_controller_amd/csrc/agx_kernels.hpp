@@ -476,10 +476,26 @@ __device__ __forceinline__ double grid_col(double x) {
   double d = __builtin_amdgcn_mov_dpp(x, 0x150 + K, 0xf, 0xf, false);
   return __builtin_amdgcn_update_dpp(d, x, 0x150 + 8 + K, 0xf, 0xc, false);
 }
-// In front of a software-pipelined loop that keeps several nodes of loads in flight: wait for the loads of
-// the prologue once.  The compiler's s_waitcnt at the loop head is the minimum over the paths that reach it,
-// and the prologue (whose loads it is free to reorder) would otherwise pin it near vmcnt(0) on every pass.
-__device__ __forceinline__ void prefetch_queue_settle() { __builtin_amdgcn_s_waitcnt(0x0f70); }  // vmcnt(0)
+// In front of a software-pipelined loop that keeps several nodes of loads in flight: make the loads of the prologue
+// land once.  The compiler's s_waitcnt at the loop head is the minimum over the paths that reach it, and the prologue
+// (whose loads it reorders, and sinks towards the loop -- neither s_waitcnt nor a memory clobber holds back a load
+// through a __restrict__ pointer) would otherwise pin it near vmcnt(0) on every pass.  An empty asm that "modifies"
+// every prefetched register is a use the loads cannot move past.
+template <class SET, int N>
+__device__ __forceinline__ void prefetch_queue_settle(SET (&sets)[N]) {
+  static_assert(sizeof(SET) % sizeof(double) == 0, "register sets of doubles");
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    double *p = reinterpret_cast<double *>(&sets[i]);
+#pragma unroll
+    for (int e = 0; e < (int)(sizeof(SET) / sizeof(double)); ++e) asm volatile("" : "+v"(p[e]));
+  }
+}
+// Around the reload of one register set at the end of a step: keeps the loads of the step together and in program
+// order.  Left to itself the scheduler regroups the loads of the unrolled steps by base pointer; vmcnt counts in
+// order, so the first use of the group issued last then waits for every load in flight.
+__device__ __forceinline__ void prefetch_group_begin() { __builtin_amdgcn_sched_barrier(0); }
+__device__ __forceinline__ void prefetch_group_end() { __builtin_amdgcn_sched_barrier(0); }
 // Step lengths of the horizon for the time-serial sweeps, staged in LDS once per wave.  Read per node from global
 // memory they sit at the end of every group of prefetch loads: the scalar path would put an s_waitcnt lgkmcnt(0)
 // on every node, and on the vector path the compiler gathers the loads of the unrolled steps at the top of the
@@ -548,7 +564,9 @@ __device__ __forceinline__ void riccati_forward(const int b, const int T, const 
     }
     // refill this register set FWD_DEPTH nodes ahead: after the last use of its old contents and unconditionally
     // (the last node again at the end) -- see the note on the loop latch in agx_riccati_mx.hpp
+    prefetch_group_begin();
     load_gain(g, t + FWD_DEPTH < T ? t + FWD_DEPTH : T - 1);
+    prefetch_group_end();
   };
   int t = 0;
   // the nodes that do not fill a group first, one at a time; the pipelined loop then runs whole groups
@@ -561,7 +579,7 @@ __device__ __forceinline__ void riccati_forward(const int b, const int T, const 
     Gain g[FWD_DEPTH];
 #pragma unroll
     for (int i = 0; i < FWD_DEPTH; ++i) load_gain(g[i], t + i);
-    prefetch_queue_settle();
+    prefetch_queue_settle(g);
     for (; t < T; t += FWD_DEPTH) {
 #pragma unroll
       for (int i = 0; i < FWD_DEPTH; ++i) fstep(g[i], t + i);
@@ -783,7 +801,9 @@ AGX_UNROLL_NV
     if (!in) { Vqq = 0.0; Vqv = 0.0; Vvq = 0.0; Vvv = 0.0; }
     // refill this register set: after the last use of its old contents and unconditionally (node 0 again at the
     // end), so that no register copy -- and no s_waitcnt vmcnt(0) -- sits on the loop latch (see agx_riccati_mx.hpp)
+    prefetch_group_begin();
     load_tile(z, t >= kGridDepth ? t - kGridDepth : 0);
+    prefetch_group_end();
   };
   if (GAINS) { aux_fetch(T - 1); aux_put(T - 1); if (T >= 2) aux_fetch(T - 2); }
   int t = T - 1;
@@ -796,7 +816,7 @@ AGX_UNROLL_NV
     Tile tl[kGridDepth];
 #pragma unroll
     for (int i = 0; i < kGridDepth; ++i) load_tile(tl[i], t - i);
-    prefetch_queue_settle();
+    prefetch_queue_settle(tl);
     for (; t >= 0; t -= kGridDepth) {
 #pragma unroll
       for (int i = 0; i < kGridDepth; ++i) step(tl[i], t - i);

@@ -265,7 +265,9 @@ __device__ __forceinline__ void riccati_mx_body(const int b, const DevOcp *__res
     // Refill this register set, (a) after the last use of its old contents and (b) unconditionally (node 0 again at
     // the end).  Either a live old value or a branch makes the loaded values reach the next pass through register
     // copies at the loop latch, and the s_waitcnt vmcnt(0) in front of those copies drains the prefetch queue.
+    prefetch_group_begin();
     load_tile(z, t >= kMxDepth ? t - kMxDepth : 0);
+    prefetch_group_end();
   };
 
   int t = T - 1;
@@ -279,7 +281,7 @@ __device__ __forceinline__ void riccati_mx_body(const int b, const DevOcp *__res
     Tile tl[kMxDepth];
 #pragma unroll
     for (int i = 0; i < kMxDepth; ++i) load_tile(tl[i], t - i);
-    prefetch_queue_settle();
+    prefetch_queue_settle(tl);
     for (; t >= 0; t -= kMxDepth) {
 #pragma unroll
       for (int i = 0; i < kMxDepth; ++i) step(tl[i], t - i);
