@@ -537,7 +537,10 @@ __device__ __forceinline__ void riccati_forward(const int b, const int T, const 
   __threadfence_block();  // the gains written by the backward sweep are read back by other lanes below
   double dq_r = 0.0, dv_r = 0.0, dq_c = 0.0, dv_c = 0.0;
   struct Gain { double kq, kv, kw, fq, fv; };
-  constexpr int FWD_DEPTH = 8;  // nodes of gains in flight (4: 36.6 us, 8: 32 us, 12: 28.7 us per 100 nodes; 8 keeps the pair kernel below 256 VGPRs)
+#ifndef AGX_FWD_DEPTH
+#define AGX_FWD_DEPTH 8
+#endif
+  constexpr int FWD_DEPTH = AGX_FWD_DEPTH;  // nodes of gains in flight
   auto load_gain = [&](Gain &g, int t) {
     const double *kr = Kw + ((long long)t * NV + rr) * NX;
     g.kq = in ? kr[cc] : 0.0;

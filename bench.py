@@ -44,12 +44,13 @@ PARITY = {
     "cartesian": "UNPINNED: colmpc distance / QuadExp and the ADMM loop are recalled forms, HIP == this repository's checker only",
 }
 K1_NAME = {
-    "sine": "k_calc_qp_lj", "generic": "k_calc_qp_lj", "humanoid": "k_calc_qp_wg", "collision": "k_calc_qp", "cartesian": "k_calc_qp",
+    "sine": "k_calc_qp_lj", "generic": "k_calc_qp_lj", "humanoid": "k_calc_qp_wg", "collision": "k_calc_qp_lj_coll", "cartesian": "k_calc_qp_lj_coll",
 }
 K1_TEXT = {
     "k_calc_qp_lj": "k_calc_qp_lj (node-parallel derivative pass, running nodes, 8 lanes per node)",
     "k_calc_qp_wg": "k_calc_qp_wg<30> (one workgroup per node: LDS-resident dynamics, tree sums and contractions on the fp64 matrix cores)",
-    "k_calc_qp": "k_calc_qp<7> (one lane per node: problems with a collision cost row do not use the 8-lane kernel yet)",
+    "k_calc_qp_lj_coll": ("k_calc_qp_lj<7, COLL> (8 lanes per node, the collision cost row evaluated by the node's lanes); launches of later SQP "
+                          "iterations skip finished instances, so the in-situ average is over partly empty launches: an upper bound of the rate"),
 }
 
 
@@ -407,7 +408,7 @@ def main():
         if tfile.exists():
             try:
                 doc = json.loads(tfile.read_text())
-                traffic = doc.get(f"{K1_NAME[args.workload]},B={B},T={T}")
+                traffic = doc.get(f"{K1_NAME[args.workload].replace('_coll', '')},B={B},T={T}")
                 step_traffic = doc.get(f"step:{args.workload},B={B},T={T}")
                 tsrc = doc.get("_source")
             except Exception:
