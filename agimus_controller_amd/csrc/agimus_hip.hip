@@ -68,6 +68,7 @@ struct agx_ocp {
   bool lanes_coll = false;  // ... in its variant with one collision cost row
   bool speculate = true;  // AGX_SPECULATE_GAINS=0: gains sweep only on exit
   bool gains_mfma = true; // AGX_GAINS_MFMA=0: scalar K = M Kw - taux for large models
+  bool fuse_kkt = false;     // AGX_FUSED_KKT=1: K3 inside the forward pass of k_riccati_mx instead of its own launch (measured slower)
   bool riccati_mx = true;    // AGX_RICCATI_MX=0: nv <= 7 sweeps on the 8 x 8 lane grid (k_riccati) instead of the MFMA operand layout (k_riccati_mx)
   bool riccati_mfma = true;  // AGX_RICCATI_MFMA=0: large models sweep with the LDS Gauss-Jordan kernel (k_riccati_big)
   bool k1_fused = true;     // AGX_K1_FUSED=0: running and terminal nodes of the derivative pass as two launches (profiling)
@@ -310,6 +311,11 @@ int launch_calc_qp(agx_ocp *o, bool running_only = false, bool term_only = false
   });
 }
 
+// K3 (k_node_kkt) folded into the forward pass of K2 (AGX_FUSED_KKT=1; off by default: the 12-value prefetch sets of
+// that pass end up behind register copies on the loop latch and the pass gains 65 us for the 51 us K3 takes alone):
+// the MFMA-layout sweep of unconstrained problems without general cost rows (those have their own node kernels).
+static inline bool fused_kkt(const agx_ocp *o) { return o->fuse_kkt && o->riccati_mx && o->nv <= 7 && !o->has_con && !o->general; }
+
 // K2: direction sweep; with `pair` the speculative gains sweep of SQP iteration `iter` rides in the same launch
 int launch_riccati(agx_ocp *o, int forward, bool pair = false, int iter = 0, const double *tiles = nullptr) {
   if (o->nv <= 7 && o->T + 1 > 512) return fail("the sweeps stage the step lengths of up to 511 nodes in LDS: horizon too long");
@@ -317,15 +323,16 @@ int launch_riccati(agx_ocp *o, int forward, bool pair = false, int iter = 0, con
     constexpr int NV = decltype(NVc)::value;
     const double *qt = tiles ? tiles : o->d_qt;
     if constexpr (NV <= 7) {
+      const int fwd = forward ? (fused_kkt(o) ? 2 : 1) : 0;  // 2: K3 rides along in the forward pass
       if (pair && o->riccati_mx)
         hipLaunchKernelGGL((agx::k_riccati_mx_pair<NV>), dim3(2 * o->B), dim3(64), 0, o->stream, o->d_ocp, o->d_dt, o->d_qt, o->d_aux,
-                           o->d_Kws, o->d_kws, o->d_dx, o->d_w, o->d_Kout, o->d_state, iter);
+                           o->d_Kws, o->d_kws, o->d_dx, o->d_w, o->d_Kout, o->d_state, iter, fused_kkt(o) ? 2 : 1, o->d_du, o->d_nodestat);
       else if (pair)
         hipLaunchKernelGGL((agx::k_riccati_pair<NV>), dim3(2 * o->B), dim3(64), 0, o->stream, o->d_ocp, o->d_dt, o->d_qt, o->d_aux,
                            o->d_Kws, o->d_kws, o->d_dx, o->d_w, o->d_du, o->d_Kout, o->d_state, iter);
       else if (o->riccati_mx)
         hipLaunchKernelGGL((agx::k_riccati_mx<NV, false>), dim3(o->B), dim3(64), 0, o->stream, o->d_ocp, o->d_dt, qt, o->d_aux,
-                           o->d_Kws, o->d_kws, o->d_dx, o->d_w, o->d_Kout, o->d_state, forward, 0);
+                           o->d_Kws, o->d_kws, o->d_dx, o->d_w, o->d_Kout, o->d_state, fwd, 0, o->d_du, o->d_nodestat);
       else
         hipLaunchKernelGGL((agx::k_riccati<NV, false>), dim3(o->B), dim3(64), 0, o->stream, o->d_ocp, o->d_dt, qt, o->d_aux,
                            o->d_Kws, o->d_kws, o->d_dx, o->d_w, o->d_du, o->d_Kout, o->d_state, forward, 0);
@@ -362,7 +369,7 @@ int launch_step(agx_ocp *o, int iter, int max_iter, int mode, bool with_node_kkt
       HIPCHK(hipGetLastError());
       return 0;
     }
-    if (with_node_kkt) {
+    if (with_node_kkt && !fused_kkt(o)) {
       if constexpr (NV <= 7)
         hipLaunchKernelGGL((agx::k_node_kkt<NV>), dim3((int)((nodes * 8 + 255) / 256)), dim3(256), 0, o->stream, o->d_ocp, o->d_qt, o->d_aux,
                            o->d_dx, o->d_w, o->d_du, o->d_nodestat, o->d_state);
@@ -410,7 +417,7 @@ int launch_gains(agx_ocp *o, int gmode = 0) {
     if constexpr (NV <= 7) {
       if (o->riccati_mx)
         hipLaunchKernelGGL((agx::k_riccati_mx<NV, true>), dim3(o->B), dim3(64), 0, o->stream, o->d_ocp, o->d_dt, o->d_qt, o->d_aux, o->d_Kws,
-                           o->d_kws, o->d_dx, o->d_w, o->d_Kout, o->d_state, 0, gmode);
+                           o->d_kws, o->d_dx, o->d_w, o->d_Kout, o->d_state, 0, gmode, (double *)nullptr, (double *)nullptr);
       else
       hipLaunchKernelGGL((agx::k_riccati<NV, true>), dim3(o->B), dim3(64), 0, o->stream, o->d_ocp, o->d_dt, o->d_qt, o->d_aux, o->d_Kws,
                          o->d_kws, o->d_dx, o->d_w, o->d_du, o->d_Kout, o->d_state, 0, gmode);
@@ -785,6 +792,7 @@ int agx_ocp_create(const agx_model *m, const agx_ocp_desc *d, int batch, int dev
   if (const char *e = getenv("AGX_GAINS_MFMA")) o->gains_mfma = (e[0] != '0');
   if (const char *e = getenv("AGX_RICCATI_MFMA")) o->riccati_mfma = (e[0] != '0');
   if (const char *e = getenv("AGX_RICCATI_MX")) o->riccati_mx = (e[0] != '0');
+  if (const char *e = getenv("AGX_FUSED_KKT")) o->fuse_kkt = (e[0] != '0');
   if (const char *e = getenv("AGX_QUEUE_AHEAD")) o->queue_ahead = (e[0] != '0');
   if (const char *e = getenv("AGX_K1_FUSED")) o->k1_fused = (e[0] != '0');
   o->T = d->horizon; o->B = batch; o->device = device;

@@ -438,21 +438,22 @@ __device__ __forceinline__ void forward_seg(const int t_lo, const int t_hi, doub
   typedef QT<NV> Q;
   const int lane = threadIdx.x & 63, r = lane >> 3, c = lane & 7;
   const bool in = (r < NV) && (c < NV);
+  const double inm = in ? 1.0 : 0.0;
   const int rr = r < NV ? r : 0, cc = c < NV ? c : 0;
   double dq_c = __shfl(dq_r, 8 * cc, 64), dv_c = __shfl(dv_r, 8 * cc, 64);
   struct Gain { double kq, kv, kw, fq, fv; };
   constexpr int DEPTH = 4;
   auto load_gain = [&](Gain &g, int t) {
     const double *kr = Kw + ((long long)t * NV + rr) * NX;
-    g.kq = in ? kr[cc] : 0.0;
-    g.kv = in ? kr[NV + cc] : 0.0;
+    g.kq = kr[cc];  // masked at the use (see riccati_forward)
+    g.kv = kr[NV + cc];
     g.kw = kw[(long long)t * NV + rr];
     g.fq = qb[(long long)t * TS + Q::f + rr];
     g.fv = qb[(long long)t * TS + Q::f + NV + rr];
   };
   auto fstep = [&](Gain &g, int t) {
     const double h = s_dt[t], h2 = h * h;
-    double p = g.kq * dq_c + g.kv * dv_c;
+    double p = (g.kq * inm) * dq_c + (g.kv * inm) * dv_c;
     const double kwv = g.kw, fqc = g.fq, fvc = g.fv;
     p += dpp_xor1(p); p += dpp_xor2(p); p += dpp_xor4(p);
     const double wv = -(kwv + p);

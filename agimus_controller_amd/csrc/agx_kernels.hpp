@@ -522,39 +522,85 @@ __device__ __forceinline__ double fast_rcp(double x) {
 // twice -- indexed by the lane's column (operand of the products) and by its row (the update).
 // Per node: two FMAs, a DPP row reduction (w = -kw - Kw dx), the lane-local state update and one
 // transposing broadcast of the new state (row r's value to every lane of column r).
-template <int NV>
+// KKT = true folds K3 (k_node_kkt) into the pass: du = M w + taux dx of every node, and the instance totals of the
+// KKT residual / cost / gap shares (same identities as k_node_kkt).  The pass is a dependent chain with idle issue
+// slots, so the node-parallel kernel's 2 KB per node of aux-tile reads hide behind it.  The totals go to the
+// nodestat entry of node 0 (the entries of the other nodes stay zero from allocation: k_step's reduction over the
+// nodes then returns them unchanged); cost and gap are summed node by node, in horizon order.
+struct FwdKkt {
+  const double *ab;   // aux tiles of the instance
+  double preg, dreg;  // regularisation of the direction
+  double *du;         // [T][NV] of the instance
+  double *ns;         // nodestat of the instance's node 0
+};
+template <int NV, bool KKT = false>
 __device__ __forceinline__ void riccati_forward(const int b, const int T, const double *__restrict__ dts, const double *__restrict__ qb,
                                                 const double *__restrict__ Kw, const double *__restrict__ kw,
-                                                double *__restrict__ dxs, double *__restrict__ wss, const double *s_dt) {
+                                                double *__restrict__ dxs, double *__restrict__ wss, const double *s_dt,
+                                                const FwdKkt kk = FwdKkt()) {
   constexpr int NX = 2 * NV, TS = QT<NV>::SIZE;
   typedef QT<NV> Q;
+  typedef AUX<NV> A;
   const int lane = threadIdx.x;
   const int r = lane >> 3, c = lane & 7;
   const bool in = (r < NV) && (c < NV);
   const int rr = r < NV ? r : 0, cc = c < NV ? c : 0;
+  const double inm = in ? 1.0 : 0.0, rowm = r < NV ? 1.0 : 0.0;
   double *dx = dxs + (long long)b * (T + 1) * NX, *ws = wss + (long long)b * T * NV;
   if (lane < NV) { dx[lane] = 0.0; dx[NV + lane] = 0.0; }
   __threadfence_block();  // the gains written by the backward sweep are read back by other lanes below
   double dq_r = 0.0, dv_r = 0.0, dq_c = 0.0, dv_c = 0.0;
-  struct Gain { double kq, kv, kw, fq, fv; };
+  double kkt_run = 0.0, gap_run = 0.0, cost_run = 0.0;
+  int vz = 0;
+  if (KKT) asm volatile("v_mov_b32 %0, 0" : "=v"(vz));
+  struct GainPlain { double kq, kv, kw, fq, fv; };
+  struct GainKkt { double kq, kv, kw, fq, fv, am, atq, atv, alqq, aluu, alvv, cost; };
+  typedef typename std::conditional<KKT, GainKkt, GainPlain>::type Gain;
 #ifndef AGX_FWD_DEPTH
 #define AGX_FWD_DEPTH 8
 #endif
-  constexpr int FWD_DEPTH = AGX_FWD_DEPTH;  // nodes of gains in flight
+#ifndef AGX_FWDK_DEPTH
+#define AGX_FWDK_DEPTH 4
+#endif
+  constexpr int FWD_DEPTH = KKT ? AGX_FWDK_DEPTH : AGX_FWD_DEPTH;  // nodes of gains in flight (12 doubles per node with KKT, 5 without)
   auto load_gain = [&](Gain &g, int t) {
     const double *kr = Kw + ((long long)t * NV + rr) * NX;
-    g.kq = in ? kr[cc] : 0.0;
-    g.kv = in ? kr[NV + cc] : 0.0;
+    g.kq = kr[cc];  // lanes outside the block load element [0] of their row / column and are masked at the use: a
+    g.kv = kr[NV + cc];  // conditional load is a branch, and the join behind it puts register copies on the loop latch
     g.kw = kw[(long long)t * NV + rr];
     g.fq = qb[(long long)t * TS + Q::f + rr];
     g.fv = qb[(long long)t * TS + Q::f + NV + rr];
+    if constexpr (KKT) {
+      const double *ax = kk.ab + (long long)t * A::SIZE;
+      g.am = ax[A::M + rr * A::LD + cc]; g.atq = ax[A::tq + rr * A::LD + cc]; g.atv = ax[A::tv + rr * A::LD + cc];
+      g.alqq = ax[A::Lqq + rr * A::LD + cc];
+      g.aluu = ax[A::Luu + rr]; g.alvv = ax[A::Lvv + rr];
+      g.cost = qb[(long long)t * TS + Q::cost + vz];  // vz: a zero the compiler cannot see -- a wave-uniform address would go
+                                                      // through the scalar cache, and its s_waitcnt lgkmcnt(0) onto the chain
+    }
+  };
+  auto row_sum = [](double p) { p += dpp_xor1(p); p += dpp_xor2(p); p += dpp_xor4(p); return p; };
+  // the state-dependent shares of node t's KKT residual: |Lqq dq + dreg dq|, |(Lvv + dreg) dv|  (zero at t = 0: dx_0 = 0)
+  auto state_share = [&](double alqq, double alvv) {
+    const double hq = row_sum(alqq * dq_c * inm);
+    return fmax(fabs(hq + kk.dreg * dq_r), fabs((alvv + kk.dreg) * dv_r));
   };
   auto fstep = [&](Gain &g, int t) {
     const double h = s_dt[t], h2 = h * h;
-    double p = g.kq * dq_c + g.kv * dv_c;
+    double p = (g.kq * inm) * dq_c + (g.kv * inm) * dv_c;
     const double kwv = g.kw, fqc = g.fq, fvc = g.fv;
-    p += dpp_xor1(p); p += dpp_xor2(p); p += dpp_xor4(p);  // row sum, on every lane of the row
+    p = row_sum(p);  // on every lane of the row
     const double wv = -(kwv + p);
+    if constexpr (KKT) {
+      const double w_c = __shfl(wv, 8 * cc, 64);
+      const double du = row_sum((g.am * w_c + g.atq * dq_c + g.atv * dv_c) * inm);  // du = M w + taux dx, row r
+      double share = fmax(fmax(fabs(fqc), fabs(fvc)), fabs((g.aluu + kk.preg) * du));
+      share = fmax(share, state_share(g.alqq, g.alvv));
+      kkt_run = fmax(kkt_run, share * rowm);
+      gap_run += (fabs(fqc) + fabs(fvc)) * rowm;
+      cost_run += g.cost;
+      if (c == 0 && r < NV) kk.du[(long long)t * NV + r] = du;
+    }
     const double nq = dq_r + h * dv_r + h2 * wv + fqc;
     const double nv2 = dv_r + h * wv + fvc;
     dq_r = nq; dv_r = nv2;
@@ -587,6 +633,17 @@ __device__ __forceinline__ void riccati_forward(const int b, const int T, const 
 #pragma unroll
       for (int i = 0; i < FWD_DEPTH; ++i) fstep(g[i], t + i);
     }
+  }
+  if constexpr (KKT) {
+    // terminal node: only the state-dependent shares and its cost
+    const double *ax = kk.ab + (long long)T * A::SIZE;
+    kkt_run = fmax(kkt_run, state_share(ax[A::Lqq + rr * A::LD + cc], ax[A::Lvv + rr]) * rowm);
+    cost_run += qb[(long long)T * TS + Q::cost];
+    kkt_run = wave_max(kkt_run);
+    double gap = 0.0;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) gap += readlane_f64(gap_run, 8 * i);  // rows in order (every lane of a row holds the row's sum)
+    if (lane == 0) { kk.ns[0] = kkt_run; kk.ns[1] = cost_run; kk.ns[2] = gap; kk.ns[3] = 0.0; }
   }
 }
 

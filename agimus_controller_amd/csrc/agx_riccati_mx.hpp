@@ -51,7 +51,8 @@ __device__ __forceinline__ void riccati_mx_body(const int b, const DevOcp *__res
                                                 const double *__restrict__ qts, const double *__restrict__ auxs,
                                                 double *__restrict__ Kws, double *__restrict__ kws, double *__restrict__ dxs,
                                                 double *__restrict__ wss, double *__restrict__ Kout, DevState *__restrict__ st,
-                                                int forward, int gmode, int iter) {
+                                                int forward, int gmode, int iter, double *__restrict__ dus = nullptr,
+                                                double *__restrict__ nodestat = nullptr) {
   static_assert(NV <= 7, "16-column tiles: 7 joints + the gradient slot per half");
   typedef QT<NV> Q;
   typedef AUX<NV> A;
@@ -295,7 +296,13 @@ __device__ __forceinline__ void riccati_mx_body(const int b, const DevOcp *__res
     }
   }
   if (GAINS || !forward) return;
-  riccati_forward<NV>(b, T, dts, qb, Kws + (long long)b * T * NV * NX, kws + (long long)b * T * NV, dxs, wss, s_dt);
+  if (forward == 2) {  // K3 rides along (see riccati_forward)
+    FwdKkt kk;
+    kk.ab = ab; kk.preg = S.preg; kk.dreg = dreg; kk.du = dus + (long long)b * T * NV; kk.ns = nodestat + (long long)b * (T + 1) * 4;
+    riccati_forward<NV, true>(b, T, dts, qb, Kws + (long long)b * T * NV * NX, kws + (long long)b * T * NV, dxs, wss, s_dt, kk);
+  } else {
+    riccati_forward<NV>(b, T, dts, qb, Kws + (long long)b * T * NV * NX, kws + (long long)b * T * NV, dxs, wss, s_dt);
+  }
 }
 
 template <int NV, bool GAINS>
@@ -303,8 +310,8 @@ __global__ void __launch_bounds__(64, 2) k_riccati_mx(const DevOcp *__restrict__
                                                    const double *__restrict__ qts, const double *__restrict__ auxs,
                                                    double *__restrict__ Kws, double *__restrict__ kws, double *__restrict__ dxs,
                                                    double *__restrict__ wss, double *__restrict__ Kout, DevState *__restrict__ st,
-                                                   int forward, int gmode) {
-  riccati_mx_body<NV, GAINS>(blockIdx.x, op, dts, qts, auxs, Kws, kws, dxs, wss, Kout, st, forward, gmode, 0);
+                                                   int forward, int gmode, double *__restrict__ dus, double *__restrict__ nodestat) {
+  riccati_mx_body<NV, GAINS>(blockIdx.x, op, dts, qts, auxs, Kws, kws, dxs, wss, Kout, st, forward, gmode, 0, dus, nodestat);
 }
 
 // direction sweep (even workgroups) and speculative exit sweep (odd) of one SQP iteration in one launch, as k_riccati_pair
@@ -313,12 +320,12 @@ __global__ void __launch_bounds__(64, 2) k_riccati_mx_pair(const DevOcp *__restr
                                                         const double *__restrict__ qts, const double *__restrict__ auxs,
                                                         double *__restrict__ Kws, double *__restrict__ kws, double *__restrict__ dxs,
                                                         double *__restrict__ wss, double *__restrict__ Kout, DevState *__restrict__ st,
-                                                        int iter) {
+                                                        int iter, int forward, double *__restrict__ dus, double *__restrict__ nodestat) {
   const int b = blockIdx.x >> 1;
   if (blockIdx.x & 1)
     riccati_mx_body<NV, true>(b, op, dts, qts, auxs, Kws, kws, dxs, wss, Kout, st, 0, 1, iter);
   else
-    riccati_mx_body<NV, false>(b, op, dts, qts, auxs, Kws, kws, dxs, wss, Kout, st, 1, 0, iter);
+    riccati_mx_body<NV, false>(b, op, dts, qts, auxs, Kws, kws, dxs, wss, Kout, st, forward, 0, iter, dus, nodestat);
 }
 
 }  // namespace agx

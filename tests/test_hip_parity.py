@@ -114,6 +114,26 @@ def test_mfma_layout_sweep_agrees_with_the_lane_grid_sweep(hip_backend, monkeypa
         assert rel(b, a) < tol
 
 
+def test_node_shares_inside_the_forward_pass_agree_with_the_node_kernel(hip_backend, monkeypatch, panda):
+    """AGX_FUSED_KKT=1 computes du and the KKT / cost / gap totals inside the forward pass of k_riccati_mx instead of in
+    k_node_kkt: same solve (iterations, xs, us, K, status) up to the summation order of the totals."""
+    T, B = 37, 6  # not a multiple of the prefetch depth
+    po, ref, x0, xs, us = workloads.random_goal_problem(panda, T, 0.01, B, seed=41, frame=panda.frame_id("panda_hand_tcp"))
+    out = {}
+    for fused in ("0", "1"):
+        monkeypatch.setenv("AGX_FUSED_KKT", fused)
+        h = hip_backend.HipOcp(panda, po, B)
+        h.set_refs(ref)
+        out[fused] = h.solve(x0, xs, us, 10)
+        h.close()
+    (xs0, us0, K0, st0), (xs1, us1, K1, st1) = out["0"], out["1"]
+    np.testing.assert_array_equal(st0["iter"], st1["iter"])
+    np.testing.assert_array_equal(st0["solved"], st1["solved"])
+    assert rel(xs1, xs0) < 1e-11 and rel(us1, us0) < 1e-10 and rel(K1, K0) < 1e-9
+    np.testing.assert_allclose(st1["kkt"], st0["kkt"], rtol=1e-9)
+    np.testing.assert_allclose(st1["cost"], st0["cost"], rtol=1e-12)
+
+
 @pytest.mark.parametrize("name,rows,T,seed", [("panda", "goal", 25, 10), ("panda", "reg", 40, 11), ("chain4", "goal", 12, 12), ("chain6", "goal", 15, 13)])
 def test_full_solve_matches_oracle(hip_backend, name, rows, T, seed):
     table = MODELS[name]()
