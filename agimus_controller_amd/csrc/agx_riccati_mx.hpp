@@ -44,6 +44,15 @@ __device__ __forceinline__ double row_ror8(double x) {
   const int lo = __double2loint(x), hi = __double2hiint(x);
   return __hiloint2double(__builtin_amdgcn_mov_dpp(hi, 0x128, 0xf, 0xf, false), __builtin_amdgcn_mov_dpp(lo, 0x128, 0xf, 0xf, false));
 }
+// 1 / x to full precision with a dependent chain of 1 + 3 operations instead of 1 + 4 (fast_rcp): with e = 1 - x y0,
+// y0 (1 + e)(1 + e^2) = y0 (1 + e + e^2 + e^3), e^2 formed next to the first correction.  The pivots are on the
+// critical path of the sweep 7 times per node.
+__device__ __forceinline__ double chain_rcp(double x) {
+  const double y0 = __builtin_amdgcn_rcp(x);
+  const double e = __builtin_fma(-x, y0, 1.0);
+  const double y1 = __builtin_fma(y0, e, y0), e2 = e * e;
+  return __builtin_fma(y1, e2, y1);
+}
 __device__ __forceinline__ double flip_sign(double x) { return __hiloint2double(__double2hiint(x) ^ (int)0x80000000, __double2loint(x)); }
 
 template <int NV, bool GAINS>
@@ -233,11 +242,15 @@ __device__ __forceinline__ void riccati_mx_body(const int b, const DevOcp *__res
       if constexpr (k < NV) {
         constexpr int s = k >> 2, gk = k & 3;
         const double piv = readlane_f64(Ww[s], 16 * gk + k);
+#ifdef AGX_MX_OLD_CHAIN
         const double rp = fast_rcp(piv);
+#else
+        const double rp = chain_rcp(piv);
+#endif
         const double rW = __shfl(Ww[s], 16 * gk + j, 64), rX = __shfl(Wx[s], 16 * gk + j, 64);
-        const double c0 = row_bcast<k>(Ww[0]), c1 = row_bcast<k>(Ww[1]);
-        const double rpm = rp * nz[gk];  // the pivot row itself is left untouched
-        const double f0 = c0 * (s == 0 ? rpm : rp), f1 = c1 * (s == 1 ? rpm : rp);
+        // column k of my rows, with the pivot row's own entry zeroed (it is left untouched): off the reciprocal's chain
+        const double c0 = row_bcast<k>(Ww[0]) * (s == 0 ? nz[gk] : 1.0), c1 = row_bcast<k>(Ww[1]) * (s == 1 ? nz[gk] : 1.0);
+        const double f0 = c0 * rp, f1 = c1 * rp;
         Ww[0] -= f0 * rW; Wx[0] -= f0 * rX;
         Ww[1] -= f1 * rW; Wx[1] -= f1 * rX;
         rpr[s] += rp * ez[gk];
