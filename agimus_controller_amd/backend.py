@@ -30,6 +30,7 @@ EXPORTED_SYMBOLS = [
     "agx_model_frame_placement", "agx_ocp_get_residuals", "agx_ocp_calc_diff", "agx_ocp_direction",
     "agx_ocp_time_kernel", "agx_ocp_profile", "agx_traj_sine_create", "agx_traj_set_window",
     "agx_traj_get_point", "agx_traj_warmstart_from_reference", "agx_ocp_mpc_step", "agx_ocp_qp_tiles", "agx_ocp_set_quorum",
+    "agx_traj_cartesian_sine_create",
 ]  # fmt: skip
 
 
@@ -354,6 +355,17 @@ class HipOcp:
         bc = lambda a, shape: np.ascontiguousarray(np.broadcast_to(np.asarray(a, dtype=np.float64), shape))  # noqa: E731
         _chk(lib().agx_traj_generic_create(self._h, int(q.shape[1]), _p(q), _p(dq), _p(ddq), _p(bc(w_q, (nv,))), _p(bc(w_qdot, (nv,))),
                                            _p(bc(w_effort, (nv,))), _p(bc(w_pose, (6,))), int(frame)))
+
+    def cartesian_sine_trajectory(self, n_points, dt, q0, amp, pulsation, w_q, w_qdot, w_effort, w_pose, frame,
+                                  scale_duration=0.2, precision=1e-5, it_max=200):
+        """Resident trajectory of the Cartesian sine generator (SinusWaveCartesianSpace upstream): inverse kinematics of
+        every instance and point on the device.  q0 [B][nv], amp / pulsation [B][3]."""
+        B, nv = self.B, self.nv
+        bc = lambda a, shape: np.ascontiguousarray(np.broadcast_to(np.asarray(a, dtype=np.float64), shape))  # noqa: E731
+        _chk(lib().agx_traj_cartesian_sine_create(self._h, int(n_points), C.c_double(dt), _p(bc(q0, (B, nv))), _p(bc(amp, (B, 3))),
+                                                  _p(bc(pulsation, (B, 3))), C.c_double(scale_duration), C.c_double(precision), int(it_max),
+                                                  _p(bc(w_q, (nv,))), _p(bc(w_qdot, (nv,))), _p(bc(w_effort, (nv,))), _p(bc(w_pose, (6,))),
+                                                  int(frame)))
 
     def set_horizon_indexes(self, idx):
         """TrajectoryBuffer.horizon_indexes for the resident trajectory (None = uniform)."""

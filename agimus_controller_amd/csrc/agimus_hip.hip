@@ -1487,6 +1487,67 @@ int agx_traj_generic_create(agx_ocp *o, int n_points, const double *q, const dou
   return agx_traj_set_window(o, 0);
 }
 
+int agx_traj_cartesian_sine_create(agx_ocp *o, int n_points, double dt, const double *q0, const double *amp, const double *pulsation,
+                                   double scale_duration, double precision, int it_max, const double *w_q, const double *w_qdot,
+                                   const double *w_effort, const double *w_pose, int frame) {
+  if (!o || !q0 || !amp || !pulsation || !w_q || !w_qdot || !w_effort || !w_pose) return fail("agx_traj_cartesian_sine_create: null argument");
+  if (n_points < o->T + 1) return fail("agx_traj_cartesian_sine_create: trajectory shorter than the horizon");
+  if (frame < 0 || frame >= o->hm.nframes) return fail("agx_traj_cartesian_sine_create: frame id out of range");
+  if (!(scale_duration > 0.0) || !(precision > 0.0) || it_max < 1) return fail("agx_traj_cartesian_sine_create: scale_duration, precision, it_max must be positive");
+  if (o->nv > 7) return fail("agx_traj_cartesian_sine_create: nv <= 7");
+  if (set_device(o)) return -1;
+  const size_t B = o->B, nv = o->nv, n = B * (size_t)n_points * nv;
+  if (o->d_traj) { (void)hipFree(o->d_traj); o->d_traj = nullptr; }
+  if (o->d_pts) { (void)hipFree(o->d_pts); o->d_pts = nullptr; }
+  if (o->d_sine) { (void)hipFree(o->d_sine); o->d_sine = nullptr; }
+  HIPCHK(hipMalloc((void **)&o->d_traj, sizeof(double) * B * n_points * 2 * o->stride));
+  HIPCHK(hipMalloc((void **)&o->d_pts, sizeof(double) * B * n_points * (4 * nv + 12)));
+  // q | dq | ddq samples, then the per-instance parameters q0 | amp | pulsation and the failure flags
+  const size_t npar = B * (nv + 6);
+  HIPCHK(hipMalloc((void **)&o->d_sine, sizeof(double) * (3 * n + npar) + sizeof(int) * B));
+  double *d = o->d_sine, *dpar = d + 3 * n;
+  int *dfail = reinterpret_cast<int *>(dpar + npar);
+  HIPCHK(hipMemsetAsync(d + 2 * n, 0, sizeof(double) * n, o->stream));  // ddq = 0
+  HIPCHK(hipMemcpyAsync(dpar, q0, sizeof(double) * B * nv, hipMemcpyHostToDevice, o->stream));
+  HIPCHK(hipMemcpyAsync(dpar + B * nv, amp, sizeof(double) * B * 3, hipMemcpyHostToDevice, o->stream));
+  HIPCHK(hipMemcpyAsync(dpar + B * nv + B * 3, pulsation, sizeof(double) * B * 3, hipMemcpyHostToDevice, o->stream));
+  agx::CartSineParams cp;
+  cp.q0 = dpar; cp.amp = dpar + B * nv; cp.puls = dpar + B * nv + B * 3;
+  cp.dt = dt; cp.scale = scale_duration; cp.precision = precision;
+  cp.n_points = n_points; cp.frame = frame; cp.it_max = it_max;
+  cp.q = d; cp.dq = d + n; cp.fail = dfail;
+  agx::SineParams sp;
+  std::memset(&sp, 0, sizeof(sp));
+  sp.gq = d; sp.gdq = d + n; sp.gddq = d + 2 * n;
+  for (size_t i = 0; i < nv; ++i) { sp.w_q[i] = w_q[i]; sp.w_qdot[i] = w_qdot[i]; sp.w_effort[i] = w_effort[i]; }
+  for (int i = 0; i < 6; ++i) sp.w_pose[i] = w_pose[i];
+  sp.dt = 0.0; sp.n_points = n_points; sp.frame = frame;
+  o->n_points = n_points;
+  int rc = dispatch(o->nv, o->chain, [&](auto NVc, auto CHc) -> int {
+    constexpr int NV = decltype(NVc)::value;
+    constexpr bool CH = decltype(CHc)::value;
+    if constexpr (NV <= 7) {
+      hipLaunchKernelGGL((agx::k_cartesian_sine_ik<NV, CH>), dim3((int)((B + 63) / 64)), dim3(64), 0, o->stream, o->d_model, (int)B, cp);
+      const long long units = (long long)B * n_points;
+      hipLaunchKernelGGL((agx::k_sine_fill<NV, CH>), dim3((int)((units + 63) / 64)), dim3(64), 0, o->stream, o->d_model, o->d_ocp, sp, o->d_traj, o->d_pts);
+    }
+    HIPCHK(hipGetLastError());
+    return 0;
+  });
+  if (rc) return rc;
+  std::vector<int> failed(B);
+  HIPCHK(hipMemcpyAsync(failed.data(), dfail, sizeof(int) * B, hipMemcpyDeviceToHost, o->stream));
+  HIPCHK(hipStreamSynchronize(o->stream));
+  for (size_t b = 0; b < B; ++b)
+    if (failed[b]) {
+      char msg[160];
+      std::snprintf(msg, sizeof(msg), "inverse kinematics failed to converge: instance %zu at point %d (it_max %d)", b, failed[b] - 1, it_max);
+      return fail(msg);
+    }
+  if (traj_frames(o, frame)) return -1;
+  return agx_traj_set_window(o, 0);
+}
+
 int agx_traj_set_horizon_indexes(agx_ocp *o, const int32_t *idx) {
   if (!o) return fail("null handle");
   if (set_device(o)) return -1;

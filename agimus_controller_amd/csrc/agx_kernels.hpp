@@ -1482,22 +1482,10 @@ AGX_UNROLL_NV
 }
 
 // Frame Jacobian 6 x nv (pinocchio getFrameJacobian): rows linear | angular, LOCAL_WORLD_ALIGNED
-// (local = 0: axes of the world, origin at the frame) or LOCAL (local = 1: the frame's own axes).
+// (local = 0: axes of the world, origin at the frame) or LOCAL (local = 1: the frame's own axes); J row-major [6][NV].
 template <int NV, bool CHAIN>
-__global__ void k_frame_jacobian(const DevModel *__restrict__ mp, int n, int frame, int local, const double *__restrict__ q,
-                                 double *__restrict__ out) {
-  const DevModel &m = *mp;
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  double ql[NV];
-AGX_UNROLL_NV
-  for (int e = 0; e < NV; ++e) ql[e] = q[(long long)i * NV + e];
-  Kin<NV> k;
-  kinematics<NV, CHAIN>(m, ql, k);
-  double R[9], p[3];
-  int jf;
-  frame_world<NV>(m, k, frame, R, p, &jf);
-  double *J = out + (long long)i * 6 * NV;
+AGX_DEV void frame_jacobian_rows(const DevModel &m, const Kin<NV> &k, const double *R, const double *p, const int jf, const int local,
+                                 double *J) {
 AGX_UNROLL_NV
   for (int j = 0; j < NV; ++j) {
     const bool on = (jf >= 0) && (CHAIN ? (j <= jf) : ((m.anc[jf >= 0 ? jf : 0] >> j) & 1u));
@@ -1517,6 +1505,142 @@ AGX_UNROLL_NV
       J[(3 + e) * NV + j] = on ? ang[e] : 0.0;
     }
   }
+}
+template <int NV, bool CHAIN>
+__global__ void k_frame_jacobian(const DevModel *__restrict__ mp, int n, int frame, int local, const double *__restrict__ q,
+                                 double *__restrict__ out) {
+  const DevModel &m = *mp;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double ql[NV];
+AGX_UNROLL_NV
+  for (int e = 0; e < NV; ++e) ql[e] = q[(long long)i * NV + e];
+  Kin<NV> k;
+  kinematics<NV, CHAIN>(m, ql, k);
+  double R[9], p[3];
+  int jf;
+  frame_world<NV>(m, k, frame, R, p, &jf);
+  double J[6 * NV];
+  frame_jacobian_rows<NV, CHAIN>(m, k, R, p, jf, local, J);
+#pragma unroll
+  for (int e = 0; e < 6 * NV; ++e) out[(long long)i * 6 * NV + e] = J[e];
+}
+
+// ---------------------------------------------------------------------------
+// SinusWaveCartesianSpace on the device (trajectories/sine_wave_cartesian_space.py:62-111 upstream): the end effector
+// `frame` of instance b follows  p0 + A s(t) sin(w t)  with its initial orientation.  One lane per instance walks the
+// points in order (the inverse kinematics of a point starts from the solution of the previous one, exactly as the
+// class keeps `ik_q`): Newton steps  q <- q - J' (J J')^-1 log6(des^-1 cur)  with the LOCAL Jacobian until the error
+// norm is below `precision`, then  dq = J' (J J')^-1 v_des  with the LOCAL_WORLD_ALIGNED Jacobian; accelerations are
+// zero.  All six components of the pose error are used (the class's default mask).  fail[b] = 1 + index of the first
+// point whose iteration did not converge within it_max steps (0: none).
+// ---------------------------------------------------------------------------
+struct CartSineParams {
+  const double *q0, *amp, *puls;  // [B][nv], [B][3], [B][3]
+  double dt, scale, precision;
+  int n_points, frame, it_max;
+  double *q, *dq;                 // [B][n_points][nv]
+  int *fail;                      // [B]
+};
+// x <- A^-1 x for a symmetric positive definite 6 x 6 (J J'): elimination without pivoting
+AGX_DEV void solve_spd6(double *A, double *x) {
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    const double rp = 1.0 / A[7 * k];
+#pragma unroll
+    for (int i = k + 1; i < 6; ++i) {
+      const double f = A[6 * i + k] * rp;
+#pragma unroll
+      for (int j = k + 1; j < 6; ++j) A[6 * i + j] -= f * A[6 * k + j];
+      x[i] -= f * x[k];
+    }
+  }
+#pragma unroll
+  for (int k = 5; k >= 0; --k) {
+    double s = x[k];
+#pragma unroll
+    for (int j = k + 1; j < 6; ++j) s -= A[6 * k + j] * x[j];
+    x[k] = s / A[7 * k];
+  }
+}
+// y = J' (J J')^-1 r  (J row-major [6][NV])
+template <int NV>
+AGX_DEV void pinv_apply(const double *J, const double *r, double *y) {
+  double A[36], x[6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    x[i] = r[i];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      double s = 0.0;
+AGX_UNROLL_NV
+      for (int c = 0; c < NV; ++c) s += J[i * NV + c] * J[j * NV + c];
+      A[6 * i + j] = s;
+    }
+  }
+  solve_spd6(A, x);
+AGX_UNROLL_NV
+  for (int c = 0; c < NV; ++c) {
+    double s = 0.0;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) s += J[i * NV + c] * x[i];
+    y[c] = s;
+  }
+}
+template <int NV, bool CHAIN>
+__global__ void __launch_bounds__(64) k_cartesian_sine_ik(const DevModel *__restrict__ mp, int B, CartSineParams cp) {
+  const DevModel &m = *mp;
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  double q[NV];
+AGX_UNROLL_NV
+  for (int e = 0; e < NV; ++e) q[e] = cp.q0[(long long)b * NV + e];
+  double amp[3], w[3];
+#pragma unroll
+  for (int e = 0; e < 3; ++e) { amp[e] = cp.amp[3 * b + e]; w[e] = cp.puls[3 * b + e]; }
+  Kin<NV> k;
+  double R0[9], p0[3], R[9], p[3], J[6 * NV];
+  int jf;
+  kinematics<NV, CHAIN>(m, q, k);
+  frame_world<NV>(m, k, cp.frame, R0, p0, &jf);
+  int failed = 0;
+  for (int i = 0; i < cp.n_points; ++i) {
+    const double t = i * cp.dt;
+    const double s = fmin(fmax(t / cp.scale, 0.0), 1.0);
+    const double quint = ((6.0 * s - 15.0) * s + 10.0) * s * s * s;
+    const double dquint = (0.0 < t && t < cp.scale) ? ((30.0 * s - 60.0) * s + 30.0) * s * s / cp.scale : 0.0;
+    double des_p[3], des_v[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int e = 0; e < 3; ++e) {
+      double sn, cs;
+      sincos(w[e] * t, &sn, &cs);
+      des_p[e] = p0[e] + amp[e] * quint * sn;
+      des_v[e] = amp[e] * (dquint * sn + quint * w[e] * cs);
+    }
+    for (int it = 0;; ++it) {
+      kinematics<NV, CHAIN>(m, q, k);
+      frame_world<NV>(m, k, cp.frame, R, p, &jf);
+      double Rrel[9], d[3], prel[3], err[6];
+      mtm3(R0, R, Rrel);  // des^-1 * cur (the desired orientation is the initial one)
+      d[0] = p[0] - des_p[0]; d[1] = p[1] - des_p[1]; d[2] = p[2] - des_p[2];
+      mtv3(R0, d, prel);
+      log6<false>(Rrel, prel, err, nullptr, nullptr);
+      if (sqrt(dot6(err, err)) < cp.precision) break;
+      if (it == cp.it_max) { if (!failed) failed = i + 1; break; }
+      frame_jacobian_rows<NV, CHAIN>(m, k, R, p, jf, 1, J);
+      double dq[NV];
+      pinv_apply<NV>(J, err, dq);
+AGX_UNROLL_NV
+      for (int e = 0; e < NV; ++e) q[e] -= dq[e];
+    }
+    frame_jacobian_rows<NV, CHAIN>(m, k, R, p, jf, 0, J);
+    double dq[NV];
+    pinv_apply<NV>(J, des_v, dq);
+    const long long o = ((long long)b * cp.n_points + i) * NV;
+AGX_UNROLL_NV
+    for (int e = 0; e < NV; ++e) { cp.q[o + e] = q[e]; cp.dq[o + e] = dq[e]; }
+  }
+  cp.fail[b] = failed;
 }
 
 // residual vector of one running row at the resident solution (debug data,

@@ -307,13 +307,12 @@ def main():
         workload_name = ("Panda 7-DoF sine_wave_configuration_space, collision-avoidance costs + distance >= 1 cm constraint "
                          "(ocp_traj_tracking_collision_avoidance.yaml; ADMM, max_qp_iters 100)")
     elif args.workload == "cartesian":
-        # BASELINE configs[2] as written: sine_wave_cartesian_space references (lockstep inverse kinematics of the batch,
-        # outside the timed region) resident in HBM as q/dq/ddq arrays, collision-avoidance costs + constraint
+        # BASELINE configs[2] as written: sine_wave_cartesian_space references (inverse kinematics of every instance and
+        # point by k_cartesian_sine_ik, outside the timed region) resident in HBM, collision-avoidance costs + constraint
         cq0, camp, cpuls = workloads.cartesian_sine_batch_params(B, seed0=seed0, lower=table.lower_position_limit,
                                                                  upper=table.upper_position_limit)
-        gq, gdq, gddq = workloads.cartesian_sine_batch_arrays(hip, tcp, n_points, dt, cq0, camp, cpuls)
-        hip.generic_trajectory(gq, gdq, gddq, w["w_q"], w["w_qdot"], w["w_effort"], w["w_pose"], tcp)
-        workload_name = ("Panda 7-DoF sine_wave_cartesian_space (amplitude (0.1, 0.1, 0) m x U(0.5, 1.2), IK on the host at setup), "
+        hip.cartesian_sine_trajectory(n_points, dt, cq0, camp, cpuls, w["w_q"], w["w_qdot"], w["w_effort"], w["w_pose"], tcp)
+        workload_name = ("Panda 7-DoF sine_wave_cartesian_space (amplitude (0.1, 0.1, 0) m x U(0.5, 1.2), IK on the device at setup), "
                          "collision-avoidance costs + distance >= 1 cm constraint (ocp_traj_tracking_collision_avoidance.yaml; ADMM, "
                          "max_qp_iters 100)")
     elif args.workload == "sine":

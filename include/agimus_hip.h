@@ -302,6 +302,16 @@ int agx_traj_sine_create(agx_ocp *ocp, int n_points, double dt, const double *q0
  * feed-forward effort by RNEA and end-effector pose by FK on the device.          */
 int agx_traj_generic_create(agx_ocp *ocp, int n_points, const double *q, const double *dq, const double *ddq,
                             const double *w_q, const double *w_qdot, const double *w_effort, const double *w_pose, int frame);
+/* Same resident trajectory from the Cartesian sine generator (SinusWaveCartesianSpace,
+ * trajectories/sine_wave_cartesian_space.py:62-111): the end effector `frame` of instance b follows
+ * p0_b + amp_b s(t) sin(pulsation_b t) with its initial orientation (s: the quintic of scale_duration);
+ * q by the iterative inverse kinematics on the device (warm-started point to point, all six error components,
+ * stop at |log6| < precision, error after it_max steps), dq from the LOCAL_WORLD_ALIGNED Jacobian, ddq = 0.
+ * q0 [B][nv], amp / pulsation [B][3].  nv <= 7.                                     */
+int agx_traj_cartesian_sine_create(agx_ocp *ocp, int n_points, double dt, const double *q0, const double *amp,
+                                   const double *pulsation, double scale_duration, double precision, int it_max,
+                                   const double *w_q, const double *w_qdot, const double *w_effort, const double *w_pose,
+                                   int frame);
 /* Point the solver at the horizon window starting at sample `k0` of the
  * resident trajectory (TrajectoryBuffer.horizon, trajectory.py:218-222, with
  * uniform horizon indexes).                                                    */

@@ -113,3 +113,32 @@ def test_batch_arrays_match_the_trajectory_class(dyn):
     # the end effector of every instance follows its own sine: x moves, z stays
     P = dyn.frame_placement(tcp, qs[1])
     assert np.ptp(P[:, 9]) > 1e-3 and np.ptp(P[:, 11]) < 1e-4
+
+
+def test_device_generator_matches_the_lockstep_inverse_kinematics(dyn):
+    """agx_traj_cartesian_sine_create (every instance's inverse kinematics, point after point, in one kernel) against
+    workloads.cartesian_sine_batch_arrays -- which the test above ties to the SinusWaveCartesianSpace class and
+    through it to the reference's golden joint velocity."""
+    from agimus_controller_amd import _abi, backend
+
+    table = rt.panda_table(0.1)
+    tcp = table.frame_id("panda_hand_tcp")
+    B, T, n, dt = 5, 8, 60, 0.01
+    q0, amp, puls = workloads.cartesian_sine_batch_params(B, lower=table.lower_position_limit, upper=table.upper_position_limit)
+    qs, dqs, _ = workloads.cartesian_sine_batch_arrays(dyn, tcp, n, dt, q0, amp, puls)
+    running, terminal = workloads.goal_reaching_rows(tcp)
+    hip = backend.HipOcp(table, _abi.PackedOcp(table.nv, [dt] * T, running, terminal), B)
+    hip.cartesian_sine_trajectory(n, dt, q0, amp, puls, 1.0, 0.1, 3e-4, 0.1, tcp)
+    for k in (0, 1, 7, 23, n - 1):
+        q, v, a, u, pose = hip.traj_point(k)
+        np.testing.assert_allclose(q, qs[:, k], atol=1e-9)
+        np.testing.assert_allclose(v, dqs[:, k], atol=1e-8)
+        assert not np.any(a)
+        # the pose reference of the point is the end effector at q: the sine in x / y, constant z for instance 0
+        np.testing.assert_allclose(pose[:, 9:], dyn.frame_placement(tcp, q)[:, 9:], atol=1e-12)
+    # an unreachable target is reported, not returned
+    far = amp.copy()
+    far[2] = [5.0, 0.0, 0.0]
+    with pytest.raises(backend.HipError, match="inverse kinematics failed to converge: instance 2"):
+        hip.cartesian_sine_trajectory(n, dt, q0, far, puls, 1.0, 0.1, 3e-4, 0.1, tcp, it_max=50)
+    hip.close()
