@@ -49,6 +49,8 @@ struct agx_ocp {
   DevOcp *d_ocp = nullptr;
   double *d_dt = nullptr, *d_xs = nullptr, *d_us = nullptr, *d_x0 = nullptr, *d_tiles = nullptr;
   double *d_Kws = nullptr, *d_kws = nullptr, *d_Kout = nullptr, *d_dx = nullptr, *d_du = nullptr;
+  double *d_Kws_lqr = nullptr, *d_kws_lqr = nullptr;  // gains of the plain LQR pass when it runs next to the ADMM factorisation
+  bool admm_prefactor = true;  // AGX_ADMM_PREFACTOR=0: LQR pass, then the factorisation inside the first ADMM iteration
   double *d_qt = nullptr, *d_aux = nullptr, *d_w = nullptr, *d_nodestat = nullptr;  // QP tiles, aux tiles, acceleration steps
   // constrained problems (agx_admm.hpp): augmented tiles, constraint values / collision Jacobians,
   // multipliers y (persistent across solves), slack z, prox centre, per-node residual norms
@@ -529,7 +531,9 @@ int quorum_count(int B, double q) {
 
 // Constrained direction of one SQP iteration (SolverCSQP::computeDirection): the plain LQR pass has
 // run (equality-QP initial guess: dx, w); now du, the constraint data and the ADMM loop.
-int admm_direction(agx_ocp *o) {
+// prefactor: the plain LQR pass has NOT run yet -- it is launched here, in one kernel with the factorisation of the
+// augmented Hessians of the first ADMM iteration (k_riccati_lqr_prefactor).
+int admm_direction(agx_ocp *o, bool prefactor = false) {
   return dispatch(o->nv, o->chain, [&](auto NVc, auto CHc) -> int {
     constexpr int NV = decltype(NVc)::value;
     constexpr bool CH = decltype(CHc)::value;
@@ -537,24 +541,44 @@ int admm_direction(agx_ocp *o) {
     else {
     const long long nodes = (long long)o->B * (o->T + 1);
     const int g8 = (int)((nodes * 8 + 255) / 256), g8b = (int)((nodes * 8 + 127) / 128), g1 = (int)((nodes + 255) / 256);
+    if (prefactor) {
+      if (!o->d_Kws_lqr) {
+        HIPCHK(hipMalloc((void **)&o->d_Kws_lqr, sizeof(double) * (size_t)o->B * o->T * o->nu * o->nx));
+        HIPCHK(hipMalloc((void **)&o->d_kws_lqr, sizeof(double) * (size_t)o->B * o->T * o->nu));
+      }
+      // constraint data and the augmented Hessians need only (xs, us) and rho: before the LQR pass
+      hipLaunchKernelGGL((agx::k_con_eval<NV, CH>), dim3((int)((nodes + 63) / 64)), dim3(64), 0, o->stream, o->d_model, o->d_ocp, o->d_xs,
+                         o->d_us, o->d_cg, o->d_cjac, o->d_nodestat, o->d_state);
+      hipLaunchKernelGGL(agx::k_admm_pre, dim3((o->B + 255) / 256), dim3(256), 0, o->stream, o->d_ocp, o->d_state);
+      hipLaunchKernelGGL((agx::k_admm_tile<NV>), dim3(g8b), dim3(128), 0, o->stream, o->d_ocp, o->d_qt, o->d_qt2, o->d_aux, o->d_cx,
+                         o->d_du, o->d_cjac, o->d_y, o->d_z, o->d_state, 0);  // its gradient part is rewritten below
+      hipLaunchKernelGGL((agx::k_riccati_lqr_prefactor<NV>), dim3(2 * o->B), dim3(64), 0, o->stream, o->d_ocp, o->d_dt, o->d_qt, o->d_qt2,
+                         o->d_aux, o->d_Kws, o->d_kws, o->d_Kws_lqr, o->d_kws_lqr, o->d_dx, o->d_w, o->d_du, o->d_Kout, o->d_state, o->d_fac);
+      if (o->admm_segments)
+        hipLaunchKernelGGL((agx::k_seg_products<NV>), dim3(o->B * agx::kSeg), dim3(64), 0, o->stream, o->d_ocp, o->d_dt, o->d_Kws, o->d_segP,
+                           o->d_state);
+      HIPCHK(hipGetLastError());
+    }
     if (launch_step(o, 0, 0, 0, true, false)) return -1;  // du of the initial guess (k_node_kkt)
     HIPCHK(hipMemsetAsync(o->d_ndone + 1, 0, sizeof(int), o->stream));
     hipLaunchKernelGGL((agx::k_admm_init<NV>), dim3(g1), dim3(256), 0, o->stream, o->d_ocp, o->d_dx, o->d_cx, o->d_z, o->d_state,
                        o->d_ndone + 1);
-    hipLaunchKernelGGL((agx::k_con_eval<NV, CH>), dim3((int)((nodes + 63) / 64)), dim3(64), 0, o->stream, o->d_model, o->d_ocp, o->d_xs,
-                       o->d_us, o->d_cg, o->d_cjac, o->d_nodestat, o->d_state);
+    if (!prefactor)
+      hipLaunchKernelGGL((agx::k_con_eval<NV, CH>), dim3((int)((nodes + 63) / 64)), dim3(64), 0, o->stream, o->d_model, o->d_ocp, o->d_xs,
+                         o->d_us, o->d_cg, o->d_cjac, o->d_nodestat, o->d_state);
     HIPCHK(hipGetLastError());
     const int max_qp = o->ho.max_qp;
     for (int iter = 1; iter <= max_qp; ++iter) {
       // augmented Hessians change at the first iteration and after a rho update (k_admm_reduce decides at
       // multiples of kRhoInterval); in between k_admm_update leaves the next gradient behind
+      const bool pre = prefactor && iter == 1;  // Hessian and factors of this iteration exist: gradient only
       if (iter == 1 || (iter > 2 && (iter - 1) % agx::kRhoInterval == 0))
         hipLaunchKernelGGL((agx::k_admm_tile<NV>), dim3(g8b), dim3(128), 0, o->stream, o->d_ocp, o->d_qt, o->d_qt2, o->d_aux, o->d_cx,
-                           o->d_du, o->d_cjac, o->d_y, o->d_z, o->d_state);
-      const bool may_refactor = iter == 1 || (iter > 2 && (iter - 1) % agx::kRhoInterval == 0);
+                           o->d_du, o->d_cjac, o->d_y, o->d_z, o->d_state, pre ? 1 : 0);
+      const bool may_refactor = !pre && (iter == 1 || (iter > 2 && (iter - 1) % agx::kRhoInterval == 0));
       hipLaunchKernelGGL((agx::k_riccati_admm<NV>), dim3(o->B), dim3(64 * agx::kSeg), 0, o->stream, o->d_ocp, o->d_dt, o->d_qt2, o->d_aux,
                          o->d_Kws, o->d_kws, o->d_dx, o->d_w, o->d_du, o->d_Kout, o->d_state, o->d_fac,
-                         o->admm_segments ? (const double *)o->d_segP : (const double *)nullptr);
+                         o->admm_segments ? (const double *)o->d_segP : (const double *)nullptr, pre ? 1 : 0);
       if (may_refactor && o->admm_segments)  // new gains: the segments' closed-loop products for the gradient-only sweeps that follow
         hipLaunchKernelGGL((agx::k_seg_products<NV>), dim3(o->B * agx::kSeg), dim3(64), 0, o->stream, o->d_ocp, o->d_dt, o->d_Kws, o->d_segP,
                            o->d_state);
@@ -618,8 +642,12 @@ int solve_resident(agx_ocp *o, int max_iter, double max_time, bool prologue_done
     k1_queued = false;
     if (prof_mark(o, 1, true)) return -1;
     // from the second iteration on (where warm-started MPC steps converge) the gains sweep rides along
-    if (launch_riccati(o, 1, pair, it)) return -1;
-    if (o->has_con && admm_direction(o)) return -1;
+    if (o->has_con && o->admm_prefactor && o->riccati_mx && o->nv <= 7 && !o->general) {
+      if (admm_direction(o, true)) return -1;  // LQR pass inside, next to the ADMM factorisation
+    } else {
+      if (launch_riccati(o, 1, pair, it)) return -1;
+      if (o->has_con && admm_direction(o)) return -1;
+    }
     if (prof_mark(o, 1, false)) return -1;
     if (prof_mark(o, 2, true)) return -1;
     if (launch_step(o, it, max_iter, 1, !o->has_con, true)) return -1;
@@ -900,6 +928,7 @@ int agx_ocp_create(const agx_model *m, const agx_ocp_desc *d, int batch, int dev
     ALLOC(o->d_fac, B * T * 192);
     ALLOC(o->d_segP, B * agx::kSeg * 256);
     if (const char *e = getenv("AGX_ADMM_SEGMENTS")) o->admm_segments = (e[0] != '0');
+    if (const char *e = getenv("AGX_ADMM_PREFACTOR")) o->admm_prefactor = (e[0] != '0');
   }
 #undef ALLOC
   // the polled hand-off needs FINE-GRAINED host memory (the stamp must not overtake the data it guards): ask for it
@@ -939,7 +968,7 @@ void agx_ocp_destroy(agx_ocp *o) {
   if (o->stream) (void)hipStreamSynchronize(o->stream);
   void *ptrs[] = {o->d_model, o->d_ocp, o->d_dt, o->d_xs, o->d_us, o->d_x0, o->d_tiles, o->d_Kws, o->d_kws, o->d_Kout, o->d_dx,
                   o->d_du, o->d_ref, o->d_frames, o->d_state, o->d_ndone, o->d_scratch, o->d_traj, o->d_pts, o->d_sine, o->d_qt, o->d_aux, o->d_w, o->d_nodestat,
-                  o->d_qt2, o->d_cg, o->d_cjac, o->d_y, o->d_z, o->d_cx, o->d_admmstat, o->d_fac, o->d_hidx, o->d_trial, o->d_auxg, o->d_shift_nodes, o->d_segP};
+                  o->d_qt2, o->d_cg, o->d_cjac, o->d_y, o->d_z, o->d_cx, o->d_admmstat, o->d_fac, o->d_hidx, o->d_trial, o->d_auxg, o->d_shift_nodes, o->d_segP, o->d_Kws_lqr, o->d_kws_lqr};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
   if (o->h_ndone) (void)hipHostFree(o->h_ndone);

@@ -79,6 +79,19 @@ __global__ void __launch_bounds__(256) k_admm_init(const DevOcp *__restrict__ op
   }
 }
 
+// Pre-factorised flow: the per-instance part of k_admm_init, ahead of the plain LQR pass (the augmented Hessians
+// and their factorisation do not depend on it)
+__global__ void k_admm_pre(const DevOcp *__restrict__ op, DevState *__restrict__ st) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= op->B) return;
+  DevState &S = st[b];
+  if (S.done) return;
+  S.admm_conv = 0;
+  S.admm_refactor = 1;
+  S.admm_iter = op->max_qp;
+  if (!(S.rho_sparse > 0.0)) S.rho_sparse = 1e-1;  // rho_sparse_base of a fresh solver
+}
+
 // Augmented QP tile of one node: 8 lanes per node, lane j owns column j of every block.
 //   H  += [taux M]' diag(sigma + rho_u) [taux M] + sigma I_x + rho_x (state rows) + rho g g' (collision)
 //   g  += [taux M]' (h_u - sigma du_c) - sigma dx_c + h_x + h g,      h = y - rho z
@@ -87,7 +100,7 @@ __global__ void __launch_bounds__(128) k_admm_tile(const DevOcp *__restrict__ op
                                                    double *__restrict__ qt2s, const double *__restrict__ auxs,
                                                    const double *__restrict__ cxs, const double *__restrict__ dus,
                                                    const double *__restrict__ cjac, const double *__restrict__ ys,
-                                                   const double *__restrict__ zs, const DevState *__restrict__ st) {
+                                                   const double *__restrict__ zs, const DevState *__restrict__ st, int grad_only) {
   constexpr int NX = 2 * NV, LD = 8, B2 = NV * LD;
   typedef QT<NV> Q;
   typedef AUX<NV> A;
@@ -113,8 +126,10 @@ __global__ void __launch_bounds__(128) k_admm_tile(const DevOcp *__restrict__ op
   const int j = jl ? l8 : 0;
   // runs only where the Hessian part changed (first ADMM iteration of the SQP iteration, or new rho);
   // otherwise k_admm_update has already written the gradient
-  const bool full = S.admm_refactor != 0;
-  if (!__syncthreads_or(live && full)) return;
+  // grad_only: the Hessian part of these tiles is already there (and factorised: admm_direction, pre-factorised flow);
+  // only the gradient, which needs the plain LQR pass, is (re)written
+  const bool full = S.admm_refactor != 0 && !grad_only, grad = S.admm_refactor != 0;
+  if (!__syncthreads_or(live && grad)) return;
   // stage M | tq | tv (contiguous in the aux tile)
   double *sh = lds[grp];
   for (int e = l8; e < 3 * B2; e += 8) sh[e] = ax[A::M + e];
@@ -217,7 +232,7 @@ __global__ void __launch_bounds__(128) k_admm_tile(const DevOcp *__restrict__ op
       }
     }
   }
-  if (wr && full) {
+  if (wr && grad) {
     if (t < T) q2[Q::gw + j] = qt[Q::gw + j] + gwv;
     q2[Q::gx + j] = qt[Q::gx + j] + gq;
     q2[Q::gx + NV + j] = qt[Q::gx + NV + j] + gv;
@@ -594,17 +609,39 @@ __global__ void __launch_bounds__(64 * kSeg) k_riccati_admm(const DevOcp *__rest
                                                             double *__restrict__ dxs, double *__restrict__ wss,
                                                             double *__restrict__ dus, double *__restrict__ Kout,
                                                             DevState *__restrict__ st, double *__restrict__ facs,
-                                                            const double *__restrict__ segP) {
+                                                            const double *__restrict__ segP, int force_vec) {
   const int b = blockIdx.x;
   const DevState &S = st[b];
   if (S.done || S.admm_conv) return;
-  if (S.admm_refactor) {
+  if (S.admm_refactor && !force_vec) {  // force_vec: the factors of this Hessian exist already (k_riccati_lqr_prefactor)
     if (threadIdx.x < 64) riccati_body<NV, false, true>(b, op, dts, qts, auxs, Kws, kws, dxs, wss, dus, Kout, st, 1, 0, 0, facs);
   } else if (segP) {
     riccati_vec_segments<NV>(b, op, dts, qts, Kws, kws, dxs, wss, facs, segP);
   } else if (threadIdx.x < 64) {
     riccati_vec_body<NV>(b, op, dts, qts, Kws, kws, dxs, wss, facs);
   }
+}
+
+// The plain LQR pass of a constrained SQP iteration (equality-QP initial guess) and the factorisation of the
+// augmented Hessians of its first ADMM iteration in ONE launch: neither needs the other (only the augmented GRADIENT
+// needs the LQR pass), and at the batch sizes of the constrained workloads (B = 256: a quarter of the SIMDs) the two
+// waves of an instance run side by side.  Even workgroups: LQR sweep + forward pass on the base tiles, gains to a
+// scratch buffer; odd ones: Gauss-Jordan sweep on the augmented tiles leaving factors and gains, no forward pass.
+// The first ADMM iteration is then a gradient-only sweep like the others.
+template <int NV>
+__global__ void __launch_bounds__(64, 2) k_riccati_lqr_prefactor(const DevOcp *__restrict__ op, const double *__restrict__ dts,
+                                                                 const double *__restrict__ qts, const double *__restrict__ qt2s,
+                                                                 const double *__restrict__ auxs, double *__restrict__ Kws,
+                                                                 double *__restrict__ kws, double *__restrict__ Kws_lqr,
+                                                                 double *__restrict__ kws_lqr, double *__restrict__ dxs,
+                                                                 double *__restrict__ wss, double *__restrict__ dus,
+                                                                 double *__restrict__ Kout, DevState *__restrict__ st,
+                                                                 double *__restrict__ facs) {
+  const int b = blockIdx.x >> 1;
+  if (blockIdx.x & 1)
+    riccati_body<NV, false, true>(b, op, dts, qt2s, auxs, Kws, kws, dxs, wss, dus, Kout, st, 0, 0, 0, facs);
+  else
+    riccati_mx_body<NV, false>(b, op, dts, qts, auxs, Kws_lqr, kws_lqr, dxs, wss, Kout, st, 1, 3, 0);
 }
 
 // After the Riccati sweep on the augmented tiles: du, the multiplier update and the node's shares of

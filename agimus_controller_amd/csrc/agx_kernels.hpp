@@ -889,7 +889,7 @@ AGX_UNROLL_NV
     const bool any_bad = __any(bad_pivot);
     if (lane == 0) {
       S.dir_fail = any_bad ? 1 : 0;
-      if (any_bad) S.flags |= 1;
+      if (any_bad) atomicOr(&S.flags, 1);  // atomic: the LQR pass of the same instance may raise it at the same time
     }
   }
   if (GAINS || !forward) return;
@@ -989,7 +989,8 @@ AGX_UNROLL_NV
   gap += dpp_xor4(gap); gap += dpp_xor2(gap); gap += dpp_xor1(gap);
   if (act && l8 == 0) {
     double *ns = nodestat + nid * 4;
-    ns[0] = kkt; ns[1] = qt[Q::cost]; ns[2] = gap; ns[3] = 0.0;
+    ns[0] = kkt; ns[1] = qt[Q::cost]; ns[2] = gap;
+    if (!o.has_con) ns[3] = 0.0;  // constrained problems: the violation share of k_con_eval (which may run before this kernel) stays
   }
 }
 

@@ -302,10 +302,12 @@ __device__ __forceinline__ void riccati_mx_body(const int b, const DevOcp *__res
     }
   }
   if (!GAINS) {
+    // gmode 3: the LQR pass next to the ADMM factorisation of the same instance -- that sweep owns dir_fail (as it
+    // does when it runs afterwards); the sticky "a direction was discarded" bit is raised by both
     const bool any_bad = __any(bad_pivot);
     if (lane == 0) {
-      S.dir_fail = any_bad ? 1 : 0;
-      if (any_bad) S.flags |= 1;
+      if (gmode != 3) S.dir_fail = any_bad ? 1 : 0;
+      if (any_bad) atomicOr(&S.flags, 1);
     }
   }
   if (GAINS || !forward) return;
