@@ -270,6 +270,36 @@ def test_hip_frame_translation_constraint_matches_the_checker():
 
 
 @pytest.mark.gpu
+def test_hip_lqr_pass_next_to_the_factorisation_is_the_same_solve(monkeypatch):
+    """The constrained SQP iteration launches the plain LQR pass and the factorisation of the first ADMM iteration in
+    one kernel (k_riccati_lqr_prefactor); AGX_ADMM_PREFACTOR=0 runs them one after the other, the factorisation
+    inside the first ADMM iteration.  Same iterations, same result up to round-off."""
+    from agimus_controller_amd import backend
+
+    table, tcp, running, terminal, ref, x0, xs, us = _translation_box_problem(T=10, B=3)
+    T, B = 10, 3
+    p0 = _oracle(table, _abi.PackedOcp(7, [0.01] * T, running, terminal), B).frame_placement(tcp, x0[:, :7])[:, 9:]
+    fa, fb = table.frame_id("panda_link7_capsule_0"), table.frame_id("obstacle")
+    con = [_abi.ConstraintSpec(_abi.RES_FRAME_TRANSLATION, lower=[-0.02, -0.03, -0.01], upper=[0.02, 0.01, 0.03], ref=p0.mean(0), frame=tcp, name="ee_box"),
+           _abi.ConstraintSpec(_abi.RES_COLLISION, lower=0.05, upper=np.inf, frame=fa, frame_b=fb, name="collision")]
+    po = _abi.PackedOcp(7, [0.01] * T, running, terminal, max_qp_iters=100, running_constraints=con, terminal_constraints=con)
+    out = {}
+    for pre in ("0", "1"):
+        monkeypatch.setenv("AGX_ADMM_PREFACTOR", pre)
+        hb = backend.HipOcp(table, po, B)
+        hb.set_refs(ref)
+        out[pre] = hb.solve(x0, xs, us, 4)
+        hb.close()
+    a, b = out["0"], out["1"]
+    for key in ("iter", "qp_iters", "solved", "flags"):
+        assert np.array_equal(a[3][key], b[3][key]), key
+    np.testing.assert_allclose(b[0], a[0], rtol=1e-9, atol=1e-10)
+    np.testing.assert_allclose(b[1], a[1], rtol=1e-8, atol=1e-8)
+    np.testing.assert_allclose(b[2], a[2], rtol=1e-7, atol=1e-7)
+    np.testing.assert_allclose(b[3]["kkt"], a[3]["kkt"], rtol=1e-7, atol=1e-10)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("which", ["rotation+translation", "placement"])
 def test_hip_frame_rotation_and_placement_constraints_match_the_checker(which):
     """ConstraintModelResidual on ResidualModelFrameRotation (log3, 3 components) and
