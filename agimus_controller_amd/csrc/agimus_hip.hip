@@ -382,7 +382,7 @@ int launch_step(agx_ocp *o, int iter, int max_iter, int mode, bool with_node_kkt
     if (!with_step) { HIPCHK(hipGetLastError()); return 0; }
     if constexpr (NV <= 7) {
 #define AGX_LAUNCH_STEP(FILTER, CON)                                                                                                  \
-  hipLaunchKernelGGL((agx::k_step<NV, CH, false, FILTER, CON>), dim3(o->B), dim3(128), 0, o->stream, o->d_model, o->d_ocp, o->d_dt, \
+  hipLaunchKernelGGL((agx::k_step<NV, CH, false, FILTER, CON>), dim3(o->B), dim3(CON ? 256 : 128), 0, o->stream, o->d_model, o->d_ocp, o->d_dt, \
                      o->d_xs, o->d_us, o->rv, o->d_qt, o->d_aux, o->d_dx, o->d_nodestat, o->d_du, o->d_state, iter, max_iter, mode, \
                      o->d_ndone)
       if (o->ho.use_filter) { if (o->has_con) AGX_LAUNCH_STEP(true, true); else AGX_LAUNCH_STEP(true, false); }

@@ -1006,7 +1006,7 @@ AGX_UNROLL_NV
 // run-time test: compiled into the unconstrained kernel, the registers and scratch of every residual
 // kind a constraint may carry cost the hot path 0.155 -> 0.21 ms.
 template <int NV, bool CHAIN, bool GEN = false, bool FILTER = false, bool CON = false>
-__global__ void __launch_bounds__(128) k_step(const DevModel *__restrict__ mp, const DevOcp *__restrict__ op,
+__global__ void __launch_bounds__(CON ? 256 : 128) k_step(const DevModel *__restrict__ mp, const DevOcp *__restrict__ op,
                                               const double *__restrict__ dts, double *__restrict__ xs,
                                               double *__restrict__ us, RefView rv, const double *__restrict__ qts,
                                               const double *__restrict__ auxs, const double *__restrict__ dxs,
@@ -1015,7 +1015,7 @@ __global__ void __launch_bounds__(128) k_step(const DevModel *__restrict__ mp, c
                                               int *__restrict__ n_done) {
   constexpr int NX = 2 * NV, NU = NV;
   (void)qts; (void)auxs;  // kept in the signature: the step kernel of earlier layouts read them
-  __shared__ double red[12];
+  __shared__ double red[16], s_merit;  // four waves at most (constrained problems run 256 threads: T + 1 = 201 nodes in one round per trial)
   __shared__ int flag;
   const DevModel &m = *mp;
   const DevOcp &o = *op;
@@ -1041,11 +1041,11 @@ __global__ void __launch_bounds__(128) k_step(const DevModel *__restrict__ mp, c
   csum = wave_sum(csum);
   gsum = wave_sum(gsum);
   vsum = wave_sum(vsum);
-  if ((tid & 63) == 0) { red[tid >> 6] = kkt; red[2 + (tid >> 6)] = csum; red[4 + (tid >> 6)] = gsum; red[8 + (tid >> 6)] = vsum; }
+  if ((tid & 63) == 0) { red[tid >> 6] = kkt; red[4 + (tid >> 6)] = csum; red[8 + (tid >> 6)] = gsum; red[12 + (tid >> 6)] = vsum; }
   __syncthreads();
   if (tid == 0) {
     double kk = 0.0, cc = 0.0, gg = 0.0, vv = 0.0;
-    for (int w = 0; w < nw; ++w) { kk = fmax(kk, red[w]); cc += red[2 + w]; gg += red[4 + w]; vv += red[8 + w]; }
+    for (int w = 0; w < nw; ++w) { kk = fmax(kk, red[w]); cc += red[4 + w]; gg += red[8 + w]; vv += red[12 + w]; }
     kk = fmax(kk, vv);  // checkKKTConditions: KKT = max(KKT, constraint_norm)
     if (S.dir_fail) kk = __builtin_nan("");  // discarded direction: its KKT residual is undefined (never "converged")
     S.kkt = kk; S.cost = cc; S.gap = gg; S.con = vv; S.merit = cc + o.mu_dyn * gg + o.mu_con * vv;
@@ -1057,14 +1057,14 @@ __global__ void __launch_bounds__(128) k_step(const DevModel *__restrict__ mp, c
     const bool conv = (kk <= o.tol) && (mode & 1) && !(mode & 4);
     if (conv) { S.solved = 1; S.done = 1; S.iter = iter; atomicAdd(n_done, 1); }
     flag = conv ? 1 : 0;
-    red[6] = S.merit;
+    s_merit = S.merit;
   }
   __syncthreads();
   if (flag || !(mode & 1) || (mode & 8)) return;  // bit3: the line search runs in k_ls_trial_wg / k_ls_accept
   // large models never search here (a per-lane node evaluation needs tens of KB of private arrays: its mere
   // presence in the kernel would reserve that scratch at every launch)
   if constexpr (NV <= 8) {
-  const double merit = red[6];
+  const double merit = s_merit;
   __syncthreads();
   // ---- line search
   double alpha = 1.0, used = 1.0;
@@ -1139,11 +1139,11 @@ AGX_UNROLL_NV
         }
       }
       pc = wave_sum(pc); pg = wave_sum(pg); pv = wave_sum(pv);
-      if ((tid & 63) == 0) { red[tid >> 6] = pc; red[2 + (tid >> 6)] = pg; red[4 + (tid >> 6)] = pv; }
+      if ((tid & 63) == 0) { red[tid >> 6] = pc; red[4 + (tid >> 6)] = pg; red[8 + (tid >> 6)] = pv; }
       __syncthreads();
       if (tid == 0) {
         double tc = 0.0, tg = 0.0, tv = 0.0;
-        for (int w = 0; w < nw; ++w) { tc += red[w]; tg += red[2 + w]; tv += red[4 + w]; }
+        for (int w = 0; w < nw; ++w) { tc += red[w]; tg += red[4 + w]; tv += red[8 + w]; }
         const bool worse = (S.cost <= tc) && (S.gap <= tg) && (S.con <= tv);
         flag = worse ? 0 : 1;
       }
