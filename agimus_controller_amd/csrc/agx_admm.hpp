@@ -336,6 +336,10 @@ __device__ __forceinline__ void riccati_vec_body(const int b, const DevOcp *__re
 // deeper prefetch (8 nodes, spills) were slower.  AGX_ADMM_SEGMENTS=0 selects the one-wave sweep.
 // ---------------------------------------------------------------------------
 constexpr int kSeg = 8;
+#ifndef AGX_VEC_DEPTH
+#define AGX_VEC_DEPTH 4
+#endif
+constexpr int kVecDepth = AGX_VEC_DEPTH;  // nodes of factors / gains in flight per wave in the segment passes
 __host__ __device__ inline int seg_len(int T) { return (T + kSeg - 1) / kSeg; }
 
 // P_s = Abar_{b-1} ... Abar_a of segment s = [a, b) on the 8 x 8 lane grid (blocks qq | qv | vq | vv, element [r][c] on
@@ -402,7 +406,8 @@ __device__ __forceinline__ double vec_backward_seg(const int t_lo, const int t_h
 #pragma unroll
     for (int k = 0; k < NV; ++k) z.f[k] = ft[foff + k * 8 + rr];
   };
-  auto step = [&](Node &z, int t) {
+  constexpr int D = kVecDepth;
+  auto step = [&](Node &z, int t, bool reload) {
     const double h = s_dt[t], h2 = h * h;
     const double vp = v + z.p;
     const double vpq = dpp_mov<0x55>(vp), vpv = dpp_mov<0xAA>(vp);  // quad broadcast of lanes c = 1 / c = 2
@@ -419,27 +424,28 @@ __device__ __forceinline__ double vec_backward_seg(const int t_lo, const int t_h
     }
     if (STORE_KW && c == 0 && r < NV) kw[(long long)t * NV + r] = g * rp;
     v = g;
-    prefetch_group_begin();
-    load_node(z, t - 4 >= t_lo ? t - 4 : t_lo);  // unconditional, after the last use of the old contents (see agx_riccati_mx.hpp)
-    prefetch_group_end();
+    if (reload) {
+      prefetch_group_begin();
+      load_node(z, t - D >= t_lo ? t - D : t_lo);  // unconditional, after the last use of the old contents (see agx_riccati_mx.hpp)
+      prefetch_group_end();
+    }
   };
   if (t_hi <= t_lo) return v;
+  // whole groups of D nodes in the pipelined loop; the nodes that do not fill a group come LAST: the reloads of the final
+  // group have fetched them already (a segment is 25 nodes: in front of the loop the odd node cost one exposed load latency)
+  const int rem = (t_hi - t_lo) % D;
   int t = t_hi - 1;
-  for (int rem = (t_hi - t_lo) % 4; rem > 0; --rem, --t) {
-    Node z;
-    load_node(z, t);
-    step(z, t);
-  }
-  if (t >= t_lo) {
-    Node n[4];
+  Node n[D];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) load_node(n[i], t - i);
-    prefetch_queue_settle(n);
-    for (; t >= t_lo; t -= 4) {
+  for (int i = 0; i < D; ++i) load_node(n[i], t - i >= t_lo ? t - i : t_lo);
+  prefetch_queue_settle(n);
+  for (; t - (D - 1) >= t_lo; t -= D) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) step(n[i], t - i);
-    }
+    for (int i = 0; i < D; ++i) step(n[i], t - i, true);
   }
+#pragma unroll
+  for (int i = 0; i < D - 1; ++i)
+    if (i < rem) step(n[i], t - i, false);
   return v;
 }
 
@@ -457,7 +463,7 @@ __device__ __forceinline__ void forward_seg(const int t_lo, const int t_hi, doub
   const int rr = r < NV ? r : 0, cc = c < NV ? c : 0;
   double dq_c = __shfl(dq_r, 8 * cc, 64), dv_c = __shfl(dv_r, 8 * cc, 64);
   struct Gain { double kq, kv, kw, fq, fv; };
-  constexpr int DEPTH = 4;
+  constexpr int DEPTH = kVecDepth;
   auto load_gain = [&](Gain &g, int t) {
     const double *kr = Kw + ((long long)t * NV + rr) * NX;
     g.kq = kr[cc];  // masked at the use (see riccati_forward)
@@ -466,7 +472,7 @@ __device__ __forceinline__ void forward_seg(const int t_lo, const int t_hi, doub
     g.fq = qb[(long long)t * TS + Q::f + rr];
     g.fv = qb[(long long)t * TS + Q::f + NV + rr];
   };
-  auto fstep = [&](Gain &g, int t) {
+  auto fstep = [&](Gain &g, int t, bool reload) {
     const double h = s_dt[t], h2 = h * h;
     double p = (g.kq * inm) * dq_c + (g.kv * inm) * dv_c;
     const double kwv = g.kw, fqc = g.fq, fvc = g.fv;
@@ -482,27 +488,26 @@ __device__ __forceinline__ void forward_seg(const int t_lo, const int t_hi, doub
       dx[(long long)(t + 1) * NX + r] = nq;
       dx[(long long)(t + 1) * NX + NV + r] = nv2;
     }
-    prefetch_group_begin();
-    load_gain(g, t + DEPTH < t_hi ? t + DEPTH : t_hi - 1);  // unconditional, at the end (see riccati_forward)
-    prefetch_group_end();
+    if (reload) {
+      prefetch_group_begin();
+      load_gain(g, t + DEPTH < t_hi ? t + DEPTH : t_hi - 1);  // unconditional, at the end (see riccati_forward)
+      prefetch_group_end();
+    }
   };
   if (t_hi <= t_lo) return;
+  const int rem = (t_hi - t_lo) % DEPTH;  // the nodes that do not fill a group come last (see vec_backward_seg)
   int t = t_lo;
-  for (int rem = (t_hi - t_lo) % DEPTH; rem > 0; --rem, ++t) {
-    Gain g1;
-    load_gain(g1, t);
-    fstep(g1, t);
-  }
-  if (t < t_hi) {
-    Gain g[DEPTH];
+  Gain g[DEPTH];
 #pragma unroll
-    for (int i = 0; i < DEPTH; ++i) load_gain(g[i], t + i);
-    prefetch_queue_settle(g);
-    for (; t < t_hi; t += DEPTH) {
+  for (int i = 0; i < DEPTH; ++i) load_gain(g[i], t + i < t_hi ? t + i : t_hi - 1);
+  prefetch_queue_settle(g);
+  for (; t + (DEPTH - 1) < t_hi; t += DEPTH) {
 #pragma unroll
-      for (int i = 0; i < DEPTH; ++i) fstep(g[i], t + i);
-    }
+    for (int i = 0; i < DEPTH; ++i) fstep(g[i], t + i, true);
   }
+#pragma unroll
+  for (int i = 0; i < DEPTH - 1; ++i)
+    if (i < rem) fstep(g[i], t + i, false);
 }
 
 template <int NV>
