@@ -101,6 +101,10 @@ struct LjModel {
   double j[8][30];
 };
 
+// Second argument of __launch_bounds__: workgroups (= waves here) per CU the compiler must leave room for.  It has
+// no effect on this kernel up to 16 (measured: 252 VGPRs for every value): the 19 KB of LDS per wave (8 nodes x 2.1 KB
+// + the staged joint constants) already cap residency at 8 waves per CU = 2 per SIMD, so the register allocator is
+// free to use the whole file.  A third wave per SIMD needs the per-node LDS tile below 1.4 KB first.
 #ifndef AGX_K1_WAVES
 #define AGX_K1_WAVES 2
 #endif
