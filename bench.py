@@ -407,7 +407,7 @@ def main():
         if tfile.exists():
             try:
                 doc = json.loads(tfile.read_text())
-                traffic = doc.get(f"{K1_NAME[args.workload].replace('_coll', '')},B={B},T={T}")
+                traffic = doc.get(f"{K1_NAME[args.workload].replace('_coll', '')}:{args.workload},B={B},T={T}")
                 step_traffic = doc.get(f"step:{args.workload},B={B},T={T}")
                 tsrc = doc.get("_source")
             except Exception:

@@ -52,7 +52,7 @@ def main():
             step_total += tot
             lines.append(f"{name[:72]:72s} {n:6d} {f[1]:18.1f} {wr[1]:18.1f} {(wr[1] + 2 * f[1]) * 1024 / 1e6:12.2f} {tot / N_STEPS / 1e6:10.2f}")
             if K1[w][0] in name:
-                traffic[f"{K1[w][1]},B={B},T={T}"] = (wr[1] + 2 * f[1]) * 1024
+                traffic[f"{K1[w][1]}:{w},B={B},T={T}"] = (wr[1] + 2 * f[1]) * 1024
         lines.append(f"# all kernels of an MPC step: {step_total / N_STEPS / 1e6:.1f} MB per step")
         traffic[f"step:{w},B={B},T={T}"] = step_total / N_STEPS
         mf = src / "pmc_mfma.txt"
