@@ -64,7 +64,7 @@ def main():
         (ROOT / "profiles" / f"r02_pmc_{w}.txt").write_text("\n".join(lines) + "\n")
     traffic["_source"] = "profiles/r02_pmc_<workload>.txt"
     traffic["_comment"] = ("HBM bytes from separate rocprofv3 --pmc passes: WRITE_SIZE + 2 x FETCH_SIZE (gfx950 read-side correction, upper bound), "
-                           "KiB = 1024 B; '<kernel>,B,T' = per launch of the derivative kernel, 'step:<workload>,B,T' = all kernels of one MPC step")
+                           "KiB = 1024 B; '<kernel>:<workload>,B,T' = per launch of the derivative kernel, 'step:<workload>,B,T' = all kernels of one MPC step")
     traffic_file.write_text(json.dumps(traffic, indent=1) + "\n")
 
 
