@@ -114,6 +114,27 @@ def test_mfma_layout_sweep_agrees_with_the_lane_grid_sweep(hip_backend, monkeypa
         assert rel(b, a) < tol
 
 
+def test_qp_tile_cost_line_tail_is_zero(hip_backend, panda):
+    """The MFMA-layout Riccati sweep loads the element behind `cost` of a node's QP tile for its pad lanes: it must be
+    zero after derivative passes, warm-start shifts and solves (nobody writes it; buffers are cleared on allocation)."""
+    import ctypes as C
+
+    T, B = 12, 3
+    po, ref, x0, xs, us = workloads.random_goal_problem(panda, T, 0.01, B, seed=5, frame=panda.frame_id("panda_hand_tcp"))
+    h = hip_backend.HipOcp(panda, po, B)
+    h.set_refs(ref)
+    h.solve(x0, xs, us, 5)
+    lib = hip_backend.lib()
+    qs, as_ = C.c_int(0), C.c_int(0)
+    assert lib.agx_ocp_qp_tiles(h._h, None, None, C.byref(qs), C.byref(as_)) == 0
+    qt = np.empty((B, T + 1, qs.value))
+    aux = np.empty((B, T + 1, as_.value))
+    assert lib.agx_ocp_qp_tiles(h._h, qt.ctypes.data_as(C.c_void_p), aux.ctypes.data_as(C.c_void_p), C.byref(qs), C.byref(as_)) == 0
+    cost = qs.value - 8
+    assert np.all(qt[..., cost + 1:] == 0.0) and np.any(qt[..., cost] != 0.0)
+    h.close()
+
+
 def test_node_shares_inside_the_forward_pass_agree_with_the_node_kernel(hip_backend, monkeypatch, panda):
     """AGX_FUSED_KKT=1 computes du and the KKT / cost / gap totals inside the forward pass of k_riccati_mx instead of in
     k_node_kkt: same solve (iterations, xs, us, K, status) up to the summation order of the totals."""
