@@ -70,7 +70,7 @@ struct agx_ocp {
   bool lanes_coll = false;  // ... in its variant with one collision cost row
   bool speculate = true;  // AGX_SPECULATE_GAINS=0: gains sweep only on exit
   bool gains_mfma = true; // AGX_GAINS_MFMA=0: scalar K = M Kw - taux for large models
-  bool fuse_kkt = false;     // AGX_FUSED_KKT=1: K3 inside the forward pass of k_riccati_mx instead of its own launch (measured slower)
+  bool fuse_kkt = false;     // AGX_FUSED_KKT=1: K3 inside the forward pass of k_riccati_mx instead of its own launch (measured: no gain)
   bool riccati_mx = true;    // AGX_RICCATI_MX=0: nv <= 7 sweeps on the 8 x 8 lane grid (k_riccati) instead of the MFMA operand layout (k_riccati_mx)
   bool riccati_mfma = true;  // AGX_RICCATI_MFMA=0: large models sweep with the LDS Gauss-Jordan kernel (k_riccati_big)
   bool k1_fused = true;     // AGX_K1_FUSED=0: running and terminal nodes of the derivative pass as two launches (profiling)
