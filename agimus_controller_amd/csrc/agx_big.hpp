@@ -449,40 +449,52 @@ __global__ void __launch_bounds__(64) k_gains_to_u_mfma(const DevOcp *__restrict
   const double *Kw = Kws + node * NV * NX;
   double *K = Kout + node * NV * NX;
   const int l15 = lane & 15, l4 = lane >> 4;
+  // Every operand is loaded unconditionally (clamped index, 0 / 1 factor) and ahead of the MFMA chain that consumes it:
+  // a load inside a condition is a branch, and a load between two MFMAs of one accumulator chain exposes its latency
+  // 64 times per node (this kernel was 0.42 ms for 0.9 GB that way).
+  // this lane's A operands for the 8 k-steps of both row tiles: M[16 ti + l15][4 ks + l4]
+  double a[2][8];
 #pragma unroll
   for (int ti = 0; ti < 2; ++ti) {
-    const int arow = 16 * ti + l15;
-    // this lane's A operands for the 8 k-steps: M[arow][4 ks + l4]
-    double a[8];
+    const int arow = 16 * ti + l15, ar = arow < NV ? arow : NV - 1;
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks) {
-      const int kk = 4 * ks + l4;
-      a[ks] = (arow < NV && kk < NV) ? ax[A::M + arow * A::LD + kk] : 0.0;
+      const int kk = 4 * ks + l4, kc = kk < NV ? kk : NV - 1;
+      a[ti][ks] = ax[A::M + ar * A::LD + kc] * ((arow < NV && kk < NV) ? 1.0 : 0.0);
+    }
+  }
+#pragma unroll
+  for (int tj = 0; tj < 4; ++tj) {
+    const int col = 16 * tj + l15, cc = col < NX ? col : NX - 1;
+    const bool cq = cc < NV;
+    double bv[8];
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      const int kk = 4 * ks + l4, kc = kk < NV ? kk : NV - 1;
+      bv[ks] = Kw[kc * NX + cc] * ((kk < NV && col < NX) ? 1.0 : 0.0);
+    }
+    agx_d4 acc[2];
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        // C <- -taux tile: taux = [tq | tv], element [row][col]
+        const int row = 16 * ti + l4 + 4 * r, rc = row < NV ? row : NV - 1;
+        const double tx = ax[(cq ? A::tq + cc : A::tv + (cc - NV)) + rc * A::LD];
+        acc[ti][r] = -tx * ((row < NV && col < NX) ? 1.0 : 0.0);
+      }
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[0][ks], bv[ks], acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[1][ks], bv[ks], acc[1], 0, 0, 0);
     }
 #pragma unroll
-    for (int tj = 0; tj < 4; ++tj) {
-      const int col = 16 * tj + l15;
-      // C <- -taux tile: taux = [tq | tv], element [row][col]
-      agx_d4 acc;
+    for (int ti = 0; ti < 2; ++ti)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int row = 16 * ti + l4 + 4 * r;
-        double v = 0.0;
-        if (row < NV && col < NX) v = -((col < NV) ? ax[A::tq + row * A::LD + col] : ax[A::tv + row * A::LD + (col - NV)]);
-        acc[r] = v;
+        if (row < NV && col < NX) K[row * NX + col] = acc[ti][r];
       }
-#pragma unroll
-      for (int ks = 0; ks < 8; ++ks) {
-        const int kk = 4 * ks + l4;
-        const double bv = (kk < NV && col < NX) ? Kw[kk * NX + col] : 0.0;
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ks], bv, acc, 0, 0, 0);
-      }
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = 16 * ti + l4 + 4 * r;
-        if (row < NV && col < NX) K[row * NX + col] = acc[r];
-      }
-    }
   }
 }
 
