@@ -391,14 +391,19 @@ int launch_step(agx_ocp *o, int iter, int max_iter, int mode, bool with_node_kkt
     } else {
       // large models: convergence test in k_step, line search node parallel
       const bool split = (mode & 1) && !(mode & 4);
+      if (split) HIPCHK(hipMemsetAsync(o->d_ndone + 2, 0, sizeof(int), o->stream));  // instances in the line search: counted by k_step
       hipLaunchKernelGGL((agx::k_step<NV, CH>), dim3(o->B), dim3(128), 0, o->stream, o->d_model, o->d_ocp, o->d_dt, o->d_xs, o->d_us,
                          o->rv, o->d_qt, o->d_aux, o->d_dx, o->d_nodestat, o->d_du, o->d_state, iter, max_iter, split ? (mode | 8) : mode,
                          o->d_ndone);
       if (split) {
         double alpha = 1.0;
         for (int n = 0; n < 10; ++n, alpha *= 0.5) {
-          hipLaunchKernelGGL((agx::k_ls_trial_wg<NV>), dim3((int)nodes), dim3(256), 0, o->stream, o->d_model, o->d_ocp, o->d_dt,
-                             o->d_xs, o->d_us, o->rv, o->d_dx, o->d_du, o->d_trial, o->d_state, alpha);
+          if (n == 0)
+            hipLaunchKernelGGL((agx::k_ls_trial_wg<NV, false>), dim3((int)nodes), dim3(256), 0, o->stream, o->d_model, o->d_ocp, o->d_dt,
+                               o->d_xs, o->d_us, o->rv, o->d_dx, o->d_du, o->d_trial, o->d_state, alpha, o->d_ndone + 2);
+          else
+            hipLaunchKernelGGL((agx::k_ls_trial_wg<NV, true>), dim3((int)(nodes < 1536 ? nodes : 1536)), dim3(256), 0, o->stream, o->d_model,
+                               o->d_ocp, o->d_dt, o->d_xs, o->d_us, o->rv, o->d_dx, o->d_du, o->d_trial, o->d_state, alpha, o->d_ndone + 2);
           hipLaunchKernelGGL((agx::k_ls_accept<NV>), dim3(o->B), dim3(128), 0, o->stream, o->d_ocp, o->d_xs, o->d_us, o->d_dx, o->d_du,
                              o->d_trial, o->d_state, alpha, n == 9 ? 1 : 0, iter, max_iter, o->d_ndone);
         }
@@ -907,7 +912,7 @@ int agx_ocp_create(const agx_model *m, const agx_ocp_desc *d, int batch, int dev
   ALLOC(o->d_ref, B * (T + 1) * (size_t)o->stride);
   ALLOC(o->d_frames, B * (T + 1) * AGX_MAX_ROWS);
   ALLOC(o->d_state, B);
-  ALLOC(o->d_ndone, 2);  // [0] finished instances, [1] instances whose ADMM loop has ended
+  ALLOC(o->d_ndone, 4);  // [0] finished instances, [1] instances whose ADMM loop has ended, [2] instances in the split line search
   if (o->nv > 8) {
     for (int t = 0; t < o->T; ++t)
       if (o->dt[t] != o->dt[0]) o->shift_nodes.push_back(t);

@@ -362,6 +362,7 @@ __global__ void __launch_bounds__(128) k_ls_accept(const DevOcp *__restrict__ op
   const DevOcp &o = *op;
   const int T = o.T, b = blockIdx.x, tid = threadIdx.x, nw = blockDim.x >> 6;
   DevState &S = st[b];
+  if (n_done[2] == 0) return;  // nobody is searching any more
   if (S.done || S.ls_acc) return;
   double part = 0.0;
   for (int t = tid; t <= T; t += blockDim.x) part += trial[(long long)b * (T + 1) + t];
@@ -396,6 +397,7 @@ __global__ void __launch_bounds__(128) k_ls_accept(const DevOcp *__restrict__ op
     }
     S.preg = pr; S.dreg = dr;
     S.ls_acc = 1;
+    atomicSub(n_done + 2, 1);
     if (stop) {
       S.done = 1;
       S.iter = iter + 1;

@@ -730,29 +730,42 @@ __global__ void __launch_bounds__(256, AGX_WG_MINWAVES) k_calc_qp_wg(const DevMo
 }
 
 // Line-search trial for large models: merit share of every node at (xs + alpha dx, us + alpha du).
-template <int NV>
+// Ten step lengths are launched per SQP iteration and nearly always only the first finds anyone searching
+// (n_pending: counted by k_step, released by k_ls_accept).  The first is launched with one workgroup per node; the
+// others (STRIDE) with a small grid that strides over the nodes, so that an empty launch dispatches 1.5 k workgroups
+// instead of 26 k -- as its own instantiation: the loop costs the one-node-per-workgroup kernel 7 % when compiled in.
+template <int NV, bool STRIDE>
 __global__ void __launch_bounds__(256) k_ls_trial_wg(const DevModel *__restrict__ mp, const DevOcp *__restrict__ op,
                                                      const double *__restrict__ dts, const double *__restrict__ xs,
                                                      const double *__restrict__ us, RefView rv, const double *__restrict__ dxs,
                                                      const double *__restrict__ dus, double *__restrict__ trial,
-                                                     const DevState *__restrict__ st, double alpha) {
+                                                     const DevState *__restrict__ st, double alpha,
+                                                     const int *__restrict__ n_pending) {
   constexpr int NX = 2 * NV;
   __shared__ WgNode<NV> L;
   const DevOcp &o = *op;
   const int T = o.T;
-  const long long node = blockIdx.x;
-  const int b = (int)(node / (T + 1)), t = (int)(node % (T + 1));
-  const DevState &S = st[b];
-  if (S.done || S.ls_acc) return;
-  WgIn in;
-  in.x = xs + node * NX; in.dx = dxs + node * NX; in.xn = in.x + NX; in.dxn = in.dx + NX;
-  in.u = us + ((long long)b * T + t) * NV; in.du = dus + ((long long)b * T + t) * NV;
-  in.alpha = alpha; in.preg = 0.0; in.mu_dyn = o.mu_dyn;
-  in.ref = ref_at(rv, b, t, T); in.stride = o.stride; in.frames = frames_at(rv, b, t, T);
-  double part;
-  if (t == T) { in.dt = 0.0; part = wg_node<NV, true, false>(L, *mp, o.rows[1], in, nullptr, nullptr); }
-  else { in.dt = dts[t]; part = wg_node<NV, false, false>(L, *mp, o.rows[0], in, nullptr, nullptr); }
-  if (threadIdx.x == 0) trial[node] = part;
+  if (*n_pending == 0) return;
+  const long long n_nodes = STRIDE ? (long long)o.B * (T + 1) : (long long)blockIdx.x + 1;
+  for (long long node = blockIdx.x; node < n_nodes; node += gridDim.x) {
+    const int b = (int)(node / (T + 1)), t = (int)(node % (T + 1));
+    const DevState &S = st[b];
+    if (S.done || S.ls_acc) {
+      if (STRIDE) continue;  // uniform over the workgroup
+      return;
+    }
+    WgIn in;
+    in.x = xs + node * NX; in.dx = dxs + node * NX; in.xn = in.x + NX; in.dxn = in.dx + NX;
+    in.u = us + ((long long)b * T + t) * NV; in.du = dus + ((long long)b * T + t) * NV;
+    in.alpha = alpha; in.preg = 0.0; in.mu_dyn = o.mu_dyn;
+    in.ref = ref_at(rv, b, t, T); in.stride = o.stride; in.frames = frames_at(rv, b, t, T);
+    double part;
+    if (t == T) { in.dt = 0.0; part = wg_node<NV, true, false>(L, *mp, o.rows[1], in, nullptr, nullptr); }
+    else { in.dt = dts[t]; part = wg_node<NV, false, false>(L, *mp, o.rows[0], in, nullptr, nullptr); }
+    if (threadIdx.x == 0) trial[node] = part;
+    if (!STRIDE) return;
+    __syncthreads();  // the node's LDS is reused by the next one
+  }
 }
 
 // One semi-implicit Euler step (OCPBaseCroco.integrate, ocp_base_croco.py:184-189): forward dynamics only, one

@@ -1056,6 +1056,9 @@ __global__ void __launch_bounds__(CON ? 256 : 128) k_step(const DevModel *__rest
     if (!(kk == kk)) S.flags |= 1;
     const bool conv = (kk <= o.tol) && (mode & 1) && !(mode & 4);
     if (conv) { S.solved = 1; S.done = 1; S.iter = iter; atomicAdd(n_done, 1); }
+    // split line search (large models): n_done[2] counts the instances that still look for a step length, so that
+    // the trial / accept launches behind this one can leave at their first instruction once it is zero
+    if (!conv && (mode & 8) && (mode & 1)) atomicAdd(n_done + 2, 1);
     flag = conv ? 1 : 0;
     s_merit = S.merit;
   }
