@@ -376,7 +376,7 @@ int launch_step(agx_ocp *o, int iter, int max_iter, int mode, bool with_node_kkt
         hipLaunchKernelGGL((agx::k_node_kkt<NV>), dim3((int)((nodes * 8 + 255) / 256)), dim3(256), 0, o->stream, o->d_ocp, o->d_qt, o->d_aux,
                            o->d_dx, o->d_w, o->d_du, o->d_nodestat, o->d_state);
       else
-        hipLaunchKernelGGL((agx::k_node_kkt_big<NV>), dim3((int)((nodes + 63) / 64)), dim3(64), 0, o->stream, o->d_ocp, o->d_qt, o->d_aux,
+        hipLaunchKernelGGL((agx::k_node_kkt_big<NV>), dim3((int)((nodes + 1) / 2)), dim3(64), 0, o->stream, o->d_ocp, o->d_qt, o->d_aux,
                            o->d_dx, o->d_w, o->d_du, o->d_nodestat, o->d_state);
     }
     if (!with_step) { HIPCHK(hipGetLastError()); return 0; }

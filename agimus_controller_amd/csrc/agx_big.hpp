@@ -198,47 +198,83 @@ __global__ void __launch_bounds__(256) k_riccati_big(const DevOcp *__restrict__ 
 
 #undef AGX_VV
 
-// K3 for large nv: one lane per node, plain loops (see k_node_kkt for the identities).
+// K3 for large nv (see k_node_kkt for the identities): 32 lanes per node, lane l = column l of every matrix row (one
+// coalesced 256-byte row load per matrix and row), the row sums  du_i = sum_l M[i][l] w_l + tq[i][l] dq_l + tv[i][l] dv_l
+// and  (Lqq dq)_i  as 32-lane butterflies on the VALU (DPP inside the 16-lane rows, v_permlane16_swap across them).
+// One lane per node with serial loops (round 1) read its 31 KB at 3 TB/s with 0.4 waves per SIMD.
+__device__ __forceinline__ double sum32(double p) {
+  p += dpp_xor1(p); p += dpp_xor2(p); p += dpp_xor4(p);
+  p += dpp_mov<0x128>(p);  // row_ror:8
+  const unsigned lo = __double2loint(p), hi = __double2hiint(p);
+  typedef unsigned int u2 __attribute__((ext_vector_type(2)));
+  const u2 a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false), c = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+  return __hiloint2double(c.x, a.x) + __hiloint2double(c.y, a.y);
+}
+__device__ __forceinline__ double max32(double p) {
+  p = fmax(p, dpp_xor1(p)); p = fmax(p, dpp_xor2(p)); p = fmax(p, dpp_xor4(p));
+  p = fmax(p, dpp_mov<0x128>(p));
+  const unsigned lo = __double2loint(p), hi = __double2hiint(p);
+  typedef unsigned int u2 __attribute__((ext_vector_type(2)));
+  const u2 a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false), c = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+  return fmax(__hiloint2double(c.x, a.x), __hiloint2double(c.y, a.y));
+}
 template <int NV>
 __global__ void __launch_bounds__(64) k_node_kkt_big(const DevOcp *__restrict__ op, const double *__restrict__ qts,
                                                      const double *__restrict__ auxs, const double *__restrict__ dxs,
                                                      const double *__restrict__ wss, double *__restrict__ dus,
                                                      double *__restrict__ nodestat, const DevState *__restrict__ st) {
+  static_assert(NV <= 32, "a matrix row per 32 lanes");
   constexpr int NX = 2 * NV;
   typedef QT<NV> Q;
   typedef AUX<NV> A;
   const DevOcp &o = *op;
-  const int T = o.T;
-  const long long node = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (node >= (long long)o.B * (T + 1)) return;
+  const int T = o.T, l = threadIdx.x & 31;
+  const long long n_nodes = (long long)o.B * (T + 1);
+  const long long node_raw = (long long)blockIdx.x * 2 + (threadIdx.x >> 5);
+  const bool ok = node_raw < n_nodes;
+  const long long node = ok ? node_raw : n_nodes - 1;
   const int b = (int)(node / (T + 1)), t = (int)(node % (T + 1));
   const DevState &S = st[b];
-  if (S.done) return;
+  const bool act = ok && !S.done;
+  if (!__any(act)) return;  // both nodes of the wave finished
   const double preg = S.preg, dreg = S.dreg;
   const double *qt = qts + node * Q::SIZE;
   const double *ax = auxs + node * A::SIZE;
   const double *dx = dxs + node * NX;
+  const bool in = l < NV;
+  const int lc = in ? l : 0;
+  const double m = in ? 1.0 : 0.0;
+  const double dq = dx[lc] * m, dv = dx[NV + lc] * m;
   double kkt = 0.0, gap = 0.0;
-  if (t < T) {
-    const double *w = wss + ((long long)b * T + t) * NV;
-    double *du = dus + ((long long)b * T + t) * NV;
-    for (int i = 0; i < NX; ++i) { kkt = fmax(kkt, fabs(qt[Q::f + i])); gap += fabs(qt[Q::f + i]); }
-    for (int i = 0; i < NV; ++i) {
-      double s = 0.0;
-      for (int l = 0; l < NV; ++l)
-        s += ax[A::M + i * A::LD + l] * w[l] + ax[A::tq + i * A::LD + l] * dx[l] + ax[A::tv + i * A::LD + l] * dx[NV + l];
-      du[i] = s;
-      kkt = fmax(kkt, fabs((ax[A::Luu + i] + preg) * s));
-    }
+  if (t < T) {  // uniform over the node's 32 lanes
+    const double fq = qt[Q::f + lc] * m, fv = qt[Q::f + NV + lc] * m;
+    kkt = fmax(fabs(fq), fabs(fv));
+    gap = fabs(fq) + fabs(fv);
   }
-  if (t > 0)
-    for (int i = 0; i < NV; ++i) {
-      double hq = dreg * dx[i];
-      for (int j = 0; j < NV; ++j) hq += ax[A::Lqq + i * A::LD + j] * dx[j];
-      kkt = fmax(kkt, fmax(fabs(hq), fabs((ax[A::Lvv + i] + dreg) * dx[NV + i])));
+  // the butterflies run on whole waves: both nodes walk the rows together, a terminal node with zero operands
+  const double w = (t < T) ? wss[((long long)b * T + t) * NV + lc] * m : 0.0;
+  const double tm = (t < T) ? 1.0 : 0.0, sm = (t > 0) ? 1.0 : 0.0;
+  double du = 0.0, hq = 0.0;
+#pragma unroll 2
+  for (int i = 0; i < NV; ++i) {
+    const double p = (ax[A::M + i * A::LD + lc] * w + ax[A::tq + i * A::LD + lc] * dq + ax[A::tv + i * A::LD + lc] * dv) * tm;
+    const double q = ax[A::Lqq + i * A::LD + lc] * dq;
+    const double s = sum32(p), h = sum32(q);
+    if (l == i) { du = s; hq = h; }
+  }
+  if (in) {
+    if (t < T) {
+      if (act) dus[((long long)b * T + t) * NV + l] = du;
+      kkt = fmax(kkt, fabs((ax[A::Luu + l] + preg) * du));
     }
-  double *ns = nodestat + node * 4;
-  ns[0] = kkt; ns[1] = qt[Q::cost]; ns[2] = gap; ns[3] = 0.0;
+    kkt = fmax(kkt, sm * fmax(fabs(hq + dreg * dq), fabs((ax[A::Lvv + l] + dreg) * dv)));
+  }
+  kkt = max32(kkt);
+  gap = sum32(gap);
+  if (act && l == 0) {
+    double *ns = nodestat + node * 4;
+    ns[0] = kkt; ns[1] = qt[Q::cost]; ns[2] = gap; ns[3] = 0.0;
+  }
 }
 
 // K3 for problems with general cost rows (agx_general.hpp): the optimality identities with every block,
