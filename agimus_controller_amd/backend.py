@@ -357,7 +357,7 @@ class HipOcp:
                                            _p(bc(w_effort, (nv,))), _p(bc(w_pose, (6,))), int(frame)))
 
     def cartesian_sine_trajectory(self, n_points, dt, q0, amp, pulsation, w_q, w_qdot, w_effort, w_pose, frame,
-                                  scale_duration=0.2, precision=1e-5, it_max=200):
+                                  scale_duration=0.2, precision=1e-5, it_max=10000):
         """Resident trajectory of the Cartesian sine generator (SinusWaveCartesianSpace upstream): inverse kinematics of
         every instance and point on the device.  q0 [B][nv], amp / pulsation [B][3]."""
         B, nv = self.B, self.nv

@@ -91,6 +91,7 @@ struct agx_ocp {
   unsigned long long *h_ndone = nullptr;
   unsigned long long *h_ndone_dev = nullptr;  // the same words as the device sees them (mapped host memory)
   unsigned long long seq = 0;
+  unsigned ls_handed = 0;  // last value seen of the device counter of handed-on line-search trials (d_ndone[3], never reset)
   bool poll = true;  // AGX_HOST_POLL=0: stream-ordered copies + synchronize instead of polled mapped words
   double *d_first = nullptr, *h_first = nullptr;  // packed first-node results [B][first_stride], device / pinned host
   int first_stride = 0;
@@ -257,18 +258,22 @@ int launch_calc_diff(agx_ocp *o, bool masked, bool running_only = false) {
 
 // K1 production: QP tiles in acceleration-input form.  Serial chains use the 8-lanes-per-node
 // kernel (agx_k1_lanes.hpp); trees fall back to one lane per node.
-int launch_calc_qp(agx_ocp *o, bool running_only = false, bool term_only = false) {
+// phase 1: the pass runs at the trial iterates (staging halves of xs / us) of the instances in the line search and leaves
+// their tiles in place of the current ones (k_sqp_head / k_sqp_accept, agx_kernels.hpp); nv <= 7 only.
+int launch_calc_qp(agx_ocp *o, bool running_only = false, bool term_only = false, int phase = 0) {
   return dispatch(o->nv, o->chain, [&](auto NVc, auto CHc) -> int {
     constexpr int NV = decltype(NVc)::value;
     constexpr bool CH = decltype(CHc)::value;
     const long long units = (long long)o->B * o->T;
+    const double *xs_in = phase ? o->d_xs + (size_t)o->B * (o->T + 1) * o->nx : o->d_xs;
+    const double *us_in = phase ? o->d_us + (size_t)o->B * o->T * o->nu : o->d_us;
     if constexpr (NV <= 7) if (o->general) {
       if (!term_only)
         hipLaunchKernelGGL((agx::k_calc_qp<NV, CH, true>), dim3((int)((units + 63) / 64)), dim3(64), 0, o->stream, o->d_model, o->d_ocp,
-                           o->d_dt, o->d_xs, o->d_us, o->rv, o->d_qt, o->d_aux, o->d_state, o->d_auxg);
+                           o->d_dt, xs_in, us_in, o->rv, o->d_qt, o->d_aux, o->d_state, o->d_auxg, phase);
       if (!running_only)
         hipLaunchKernelGGL((agx::k_calc_qp_term<NV, CH, true>), dim3((o->B + 63) / 64), dim3(64), 0, o->stream, o->d_model, o->d_ocp,
-                           o->d_xs, o->rv, o->d_qt, o->d_aux, o->d_state, o->d_auxg);
+                           xs_in, o->rv, o->d_qt, o->d_aux, o->d_state, o->d_auxg, phase);
       HIPCHK(hipGetLastError());
       return 0;
     }
@@ -280,14 +285,14 @@ int launch_calc_qp(agx_ocp *o, bool running_only = false, bool term_only = false
   do {                                                                                                                                   \
     if (o->k1_fused && !term_only && !running_only) { /* both node types in one launch */                                                \
       hipLaunchKernelGGL((agx::k_calc_qp_lj_all<NV, COLL>), dim3(n_run + n_term), dim3(64), 0, o->stream, o->d_model, o->d_ocp, o->d_dt, \
-                         o->d_xs, o->d_us, o->rv, o->d_qt, o->d_aux, o->d_state, n_run);                                                \
+                         xs_in, us_in, o->rv, o->d_qt, o->d_aux, o->d_state, n_run, phase);                                             \
     } else {                                                                                                                             \
       if (!term_only)                                                                                                                    \
         hipLaunchKernelGGL((agx::k_calc_qp_lj<NV, false, COLL>), dim3(n_run), dim3(64), 0, o->stream, o->d_model, o->d_ocp, o->d_dt,     \
-                           o->d_xs, o->d_us, o->rv, o->d_qt, o->d_aux, o->d_state);                                                     \
+                           xs_in, us_in, o->rv, o->d_qt, o->d_aux, o->d_state, phase);                                                  \
       if (!running_only)                                                                                                                 \
         hipLaunchKernelGGL((agx::k_calc_qp_lj<NV, true, COLL>), dim3(n_term), dim3(64), 0, o->stream, o->d_model, o->d_ocp, o->d_dt,     \
-                           o->d_xs, o->d_us, o->rv, o->d_qt, o->d_aux, o->d_state);                                                     \
+                           xs_in, us_in, o->rv, o->d_qt, o->d_aux, o->d_state, phase);                                                  \
     }                                                                                                                                    \
   } while (0)
       if (o->lanes_coll) AGX_LAUNCH_LJ(true); else AGX_LAUNCH_LJ(false);
@@ -297,16 +302,18 @@ int launch_calc_qp(agx_ocp *o, bool running_only = false, bool term_only = false
     }
     if constexpr (NV > 8) {
       // large models: one workgroup per node, running and terminal nodes in one launch (agx_big_k1.hpp)
-      (void)lanes; (void)term_only; (void)running_only;
+      (void)lanes; (void)running_only;
+      if (term_only) return 0;  // the launch of the running nodes (profiled path) already covered the terminal ones
+      if (phase) return fail("launch_calc_qp: large models search with k_ls_trial_wg");
       hipLaunchKernelGGL((agx::k_calc_qp_wg<NV>), dim3((int)(units + o->B)), dim3(256), 0, o->stream, o->d_model, o->d_ocp, o->d_dt, o->d_xs,
                          o->d_us, o->rv, o->d_qt, o->d_aux, o->d_state);
     } else if (!lanes) {
       if (!term_only)
         hipLaunchKernelGGL((agx::k_calc_qp<NV, CH>), dim3((int)((units + 63) / 64)), dim3(64), 0, o->stream, o->d_model, o->d_ocp,
-                           o->d_dt, o->d_xs, o->d_us, o->rv, o->d_qt, o->d_aux, o->d_state);
+                           o->d_dt, xs_in, us_in, o->rv, o->d_qt, o->d_aux, o->d_state, (double *)nullptr, phase);
       if (!running_only)
         hipLaunchKernelGGL((agx::k_calc_qp_term<NV, CH>), dim3((o->B + 63) / 64), dim3(64), 0, o->stream, o->d_model, o->d_ocp,
-                           o->d_xs, o->rv, o->d_qt, o->d_aux, o->d_state);
+                           xs_in, o->rv, o->d_qt, o->d_aux, o->d_state, (double *)nullptr, phase);
     }
     HIPCHK(hipGetLastError());
     return 0;
@@ -354,20 +361,25 @@ int launch_riccati(agx_ocp *o, int forward, bool pair = false, int iter = 0, con
   });
 }
 
+// K3 (node shares of the KKT residual, cost, gaps; du) and the head of the step: instance totals, convergence test and --
+// nv <= 7 -- the first trial iterate of the line search (the caller runs the trial rounds: line_search_rounds); large
+// models search right here with their value-only node kernel.
 int launch_step(agx_ocp *o, int iter, int max_iter, int mode, bool with_node_kkt = true, bool with_step = true) {
   if (o->T + 1 > 512) return fail("step kernel supports horizons up to 511 nodes");
   if (o->nv > 7 && !o->d_trial) HIPCHK(hipMalloc((void **)&o->d_trial, sizeof(double) * (size_t)o->B * (o->T + 1)));
   return dispatch(o->nv, o->chain, [&](auto NVc, auto CHc) -> int {
     constexpr int NV = decltype(NVc)::value;
     constexpr bool CH = decltype(CHc)::value;
+    (void)CH;
     const long long nodes = (long long)o->B * (o->T + 1);
+    double *xs_t = o->d_xs + (size_t)o->B * (o->T + 1) * o->nx, *us_t = o->d_us + (size_t)o->B * o->T * o->nu;
     if constexpr (NV <= 7) if (o->general) {
       if (with_node_kkt)
         hipLaunchKernelGGL((agx::k_node_kkt_gen<NV>), dim3((int)((nodes + 63) / 64)), dim3(64), 0, o->stream, o->d_ocp, o->d_qt, o->d_aux,
                            o->d_auxg, o->d_dx, o->d_w, o->d_du, o->d_nodestat, o->d_state);
       if (with_step)
-        hipLaunchKernelGGL((agx::k_step<NV, CH, true>), dim3(o->B), dim3(128), 0, o->stream, o->d_model, o->d_ocp, o->d_dt, o->d_xs, o->d_us,
-                           o->rv, o->d_qt, o->d_aux, o->d_dx, o->d_nodestat, o->d_du, o->d_state, iter, max_iter, mode, o->d_ndone);
+        hipLaunchKernelGGL((agx::k_sqp_head<NV>), dim3(o->B), dim3(128), 0, o->stream, o->d_ocp, o->d_xs, o->d_us, o->d_dx, o->d_du, xs_t, us_t,
+                           o->d_nodestat, o->d_state, iter, max_iter, mode, o->d_ndone);
       HIPCHK(hipGetLastError());
       return 0;
     }
@@ -381,20 +393,14 @@ int launch_step(agx_ocp *o, int iter, int max_iter, int mode, bool with_node_kkt
     }
     if (!with_step) { HIPCHK(hipGetLastError()); return 0; }
     if constexpr (NV <= 7) {
-#define AGX_LAUNCH_STEP(FILTER, CON)                                                                                                  \
-  hipLaunchKernelGGL((agx::k_step<NV, CH, false, FILTER, CON>), dim3(o->B), dim3(CON ? 256 : 128), 0, o->stream, o->d_model, o->d_ocp, o->d_dt, \
-                     o->d_xs, o->d_us, o->rv, o->d_qt, o->d_aux, o->d_dx, o->d_nodestat, o->d_du, o->d_state, iter, max_iter, mode, \
-                     o->d_ndone)
-      if (o->ho.use_filter) { if (o->has_con) AGX_LAUNCH_STEP(true, true); else AGX_LAUNCH_STEP(true, false); }
-      else { if (o->has_con) AGX_LAUNCH_STEP(false, true); else AGX_LAUNCH_STEP(false, false); }
-#undef AGX_LAUNCH_STEP
+      hipLaunchKernelGGL((agx::k_sqp_head<NV>), dim3(o->B), dim3(128), 0, o->stream, o->d_ocp, o->d_xs, o->d_us, o->d_dx, o->d_du, xs_t, us_t,
+                         o->d_nodestat, o->d_state, iter, max_iter, mode, o->d_ndone);
     } else {
       // large models: convergence test in k_step, line search node parallel
       const bool split = (mode & 1) && !(mode & 4);
       if (split) HIPCHK(hipMemsetAsync(o->d_ndone + 2, 0, sizeof(int), o->stream));  // instances in the line search: counted by k_step
-      hipLaunchKernelGGL((agx::k_step<NV, CH>), dim3(o->B), dim3(128), 0, o->stream, o->d_model, o->d_ocp, o->d_dt, o->d_xs, o->d_us,
-                         o->rv, o->d_qt, o->d_aux, o->d_dx, o->d_nodestat, o->d_du, o->d_state, iter, max_iter, split ? (mode | 8) : mode,
-                         o->d_ndone);
+      hipLaunchKernelGGL((agx::k_step<NV>), dim3(o->B), dim3(128), 0, o->stream, o->d_ocp, o->d_nodestat, o->d_state, iter,
+                         split ? (mode | 8) : mode, o->d_ndone);
       if (split) {
         double alpha = 1.0;
         for (int n = 0; n < 10; ++n, alpha *= 0.5) {
@@ -553,7 +559,7 @@ int admm_direction(agx_ocp *o, bool prefactor = false) {
       }
       // constraint data and the augmented Hessians need only (xs, us) and rho: before the LQR pass
       hipLaunchKernelGGL((agx::k_con_eval<NV, CH>), dim3((int)((nodes + 63) / 64)), dim3(64), 0, o->stream, o->d_model, o->d_ocp, o->d_xs,
-                         o->d_us, o->d_cg, o->d_cjac, o->d_nodestat, o->d_state);
+                         o->d_us, o->d_cg, o->d_cjac, o->d_nodestat, o->d_state, 0);
       hipLaunchKernelGGL(agx::k_admm_pre, dim3((o->B + 255) / 256), dim3(256), 0, o->stream, o->d_ocp, o->d_state);
       hipLaunchKernelGGL((agx::k_admm_tile<NV>), dim3(g8b), dim3(128), 0, o->stream, o->d_ocp, o->d_qt, o->d_qt2, o->d_aux, o->d_cx,
                          o->d_du, o->d_cjac, o->d_y, o->d_z, o->d_state, 0);  // its gradient part is rewritten below
@@ -570,7 +576,7 @@ int admm_direction(agx_ocp *o, bool prefactor = false) {
                        o->d_ndone + 1);
     if (!prefactor)
       hipLaunchKernelGGL((agx::k_con_eval<NV, CH>), dim3((int)((nodes + 63) / 64)), dim3(64), 0, o->stream, o->d_model, o->d_ocp, o->d_xs,
-                         o->d_us, o->d_cg, o->d_cjac, o->d_nodestat, o->d_state);
+                         o->d_us, o->d_cg, o->d_cjac, o->d_nodestat, o->d_state, 0);
     HIPCHK(hipGetLastError());
     const int max_qp = o->ho.max_qp;
     for (int iter = 1; iter <= max_qp; ++iter) {
@@ -614,6 +620,67 @@ int admm_direction(agx_ocp *o, bool prefactor = false) {
   });
 }
 
+// Trial rounds of the line search of SQP iteration `it` (nv <= 7; k_sqp_head has written the first trial iterate):
+// derivative pass (+ constraint evaluation) at the trial points, k_sqp_accept, and -- only while the counter of handed-on
+// trials grows, i.e. when somebody rejected a step length -- the same again.  The finished-instance count comes back with
+// the same stamp.  `queue_k1`: enqueue the next iteration's derivative pass before waiting (it skips every instance whose
+// tiles came out of an accepted trial: normally an empty launch, real work only after a rejected iteration).
+int line_search_rounds(agx_ocp *o, int it, int max_iter, bool queue_k1, bool *k1_queued, int *n_done_out) {
+  double *xs_t = o->d_xs + (size_t)o->B * (o->T + 1) * o->nx, *us_t = o->d_us + (size_t)o->B * o->T * o->nu;
+  for (int round = 0; round < 10; ++round) {
+    if (o->prof && round == 0) {  // the kernel the roofline is quoted on, timed alone: running nodes of the trial pass
+      if (prof_mark(o, 0, true)) return -1;
+      if (launch_calc_qp(o, true, false, 1)) return -1;
+      if (prof_mark(o, 0, false)) return -1;
+      if (launch_calc_qp(o, false, true, 1)) return -1;
+    } else if (launch_calc_qp(o, false, false, 1)) return -1;
+    int rc = dispatch(o->nv, o->chain, [&](auto NVc, auto CHc) -> int {
+      constexpr int NV = decltype(NVc)::value;
+      constexpr bool CH = decltype(CHc)::value;
+      (void)CH;
+      if constexpr (NV > 7) return fail("line_search_rounds: nv <= 7");
+      else {
+        if (o->has_con) {
+          const long long nodes = (long long)o->B * (o->T + 1);
+          hipLaunchKernelGGL((agx::k_con_eval<NV, CH>), dim3((int)((nodes + 63) / 64)), dim3(64), 0, o->stream, o->d_model, o->d_ocp, xs_t, us_t,
+                             o->d_cg, o->d_cjac, o->d_nodestat, o->d_state, 1);
+        }
+        if (prof_mark(o, 2, true)) return -1;
+        hipLaunchKernelGGL((agx::k_sqp_accept<NV>), dim3(o->B), dim3(128), 0, o->stream, o->d_ocp, o->d_xs, o->d_us, o->d_dx, o->d_du, xs_t, us_t,
+                           o->d_qt, o->d_nodestat, o->d_state, it, max_iter, o->d_ndone);
+        HIPCHK(hipGetLastError());
+        return prof_mark(o, 2, false);
+      }
+    });
+    if (rc) return rc;
+    // finished instances + handed-on trials under one stamp
+    const unsigned long long seq = ++o->seq;
+    if (o->poll) {
+      hipLaunchKernelGGL(agx::k_publish2, dim3(1), dim3(1), 0, o->stream, o->d_ndone, o->d_ndone + 3, o->h_ndone_dev + 0, o->h_ndone_dev + 6,
+                         o->h_ndone_dev + 1, seq);
+      HIPCHK(hipGetLastError());
+    } else {
+      o->h_ndone[0] = 0; o->h_ndone[6] = 0;
+      HIPCHK(hipMemcpyAsync(o->h_ndone, o->d_ndone, sizeof(int), hipMemcpyDeviceToHost, o->stream));
+      HIPCHK(hipMemcpyAsync(o->h_ndone + 6, o->d_ndone + 3, sizeof(int), hipMemcpyDeviceToHost, o->stream));
+      HIPCHK(hipEventRecord(o->ev_done, o->stream));
+    }
+    if (queue_k1 && round == 0 && it + 1 < max_iter) {
+      if (launch_calc_qp(o, false, false, 0)) return -1;
+      *k1_queued = true;
+    }
+    if (o->poll) { if (wait_stamp(o, 1, seq)) return -1; }
+    else HIPCHK(hipEventSynchronize(o->ev_done));
+    *n_done_out = (int)__atomic_load_n(o->h_ndone, __ATOMIC_ACQUIRE);
+    const unsigned handed = (unsigned)__atomic_load_n(o->h_ndone + 6, __ATOMIC_ACQUIRE);
+    const bool more = handed != o->ls_handed;
+    o->ls_handed = handed;
+    if (!more) break;
+    *k1_queued = false;  // an instance may end this iteration with every trial rejected: its tiles are stale after the pass queued above
+  }
+  return 0;
+}
+
 // The SQP loop of SolverCSQP::solve on the resident buffers.
 int solve_resident(agx_ocp *o, int max_iter, double max_time, bool prologue_done = false) {
   if (max_iter <= 0) max_iter = 1000;
@@ -623,9 +690,9 @@ int solve_resident(agx_ocp *o, int max_iter, double max_time, bool prologue_done
     if (reset_state(o)) return -1;
     hipLaunchKernelGGL(agx::k_pin_x0, dim3((o->B * o->nx + 255) / 256), dim3(256), 0, o->stream, o->d_xs, o->d_x0, o->B, o->T, o->nx);
   }
-  // The derivative pass of iteration it+1 is enqueued BEFORE the host waits for iteration it's
-  // "everyone finished" word: it skips finished instances, so when the loop ends it was an empty
-  // launch, and when it does not the GPU never idles over the host round trip.
+  const bool small = o->nv <= 7;  // line search by derivative passes at the trial points (k_sqp_head / k_sqp_accept)
+  // Large models: the derivative pass of iteration it+1 is enqueued BEFORE the host waits for iteration it's "everyone
+  // finished" word (it skips finished instances).  nv <= 7: the same for the pass that only instances with stale tiles need.
   const bool ahead = o->queue_ahead && !o->prof && max_time <= 0.0;
   bool k1_queued = false;
   // the exit fix-up of the gains is launched only if an instance can have finished (or the loop can
@@ -637,7 +704,7 @@ int solve_resident(agx_ocp *o, int max_iter, double max_time, bool prologue_done
     // derivative pass: running and terminal nodes in one launch; under agx_ocp_profile the running
     // nodes get their own launch so that the kernel the roofline is quoted on is timed alone
     if (!k1_queued) {
-      if (o->prof) {
+      if (o->prof && (!small || it == 0)) {
         if (prof_mark(o, 0, true)) return -1;
         if (launch_calc_qp(o, true, false)) return -1;
         if (prof_mark(o, 0, false)) return -1;
@@ -654,27 +721,40 @@ int solve_resident(agx_ocp *o, int max_iter, double max_time, bool prologue_done
       if (o->has_con && admm_direction(o)) return -1;
     }
     if (prof_mark(o, 1, false)) return -1;
+    const bool last = it + 1 == max_iter;
     if (prof_mark(o, 2, true)) return -1;
     if (launch_step(o, it, max_iter, 1, !o->has_con, true)) return -1;
     if (prof_mark(o, 2, false)) return -1;
-    if (it + 1 == max_iter) { need_fixup = need_fixup || !pair; break; }
-    // early exit once every instance has finished (one 4-byte read back)
-    const unsigned long long seq = ++o->seq;
-    if (o->poll) {
-      if (publish(o, 0, 1, o->d_ndone, seq)) return -1;
+    int n_done = 0;
+    if (small) {
+      // The trial passes overwrite the tiles of this iterate.  Where the loop may end right after this iteration without a
+      // paired gains sweep (iteration cap, time limit, quorum), the sweep that yields the reported gains runs first --
+      // for the instances the head has not finished (those keep their tiles for the fix-up on exit).
+      if (!pair && !o->has_con && (last || max_time > 0.0 || o->quorum_sqp < 1.0)) {
+        if (launch_gains(o, 4)) return -1;
+      }
+      if (line_search_rounds(o, it, max_iter, ahead && !last, &k1_queued, &n_done)) return -1;
+      if (last) { need_fixup = need_fixup || !pair; break; }
     } else {
-      o->h_ndone[0] = 0;
-      HIPCHK(hipMemcpyAsync(o->h_ndone, o->d_ndone, sizeof(int), hipMemcpyDeviceToHost, o->stream));
-      HIPCHK(hipEventRecord(o->ev_done, o->stream));
+      if (last) { need_fixup = need_fixup || !pair; break; }
+      // early exit once every instance has finished (one 4-byte read back)
+      const unsigned long long seq = ++o->seq;
+      if (o->poll) {
+        if (publish(o, 0, 1, o->d_ndone, seq)) return -1;
+      } else {
+        o->h_ndone[0] = 0;
+        HIPCHK(hipMemcpyAsync(o->h_ndone, o->d_ndone, sizeof(int), hipMemcpyDeviceToHost, o->stream));
+        HIPCHK(hipEventRecord(o->ev_done, o->stream));
+      }
+      if (ahead) {
+        if (launch_calc_qp(o, false, false)) return -1;
+        k1_queued = true;
+      }
+      // waits for the finished count only, not for the pass queued behind it
+      if (o->poll) { if (wait_stamp(o, 1, seq)) return -1; }
+      else HIPCHK(hipEventSynchronize(o->ev_done));
+      n_done = (int)__atomic_load_n(o->h_ndone, __ATOMIC_ACQUIRE);
     }
-    if (ahead) {
-      if (launch_calc_qp(o, false, false)) return -1;
-      k1_queued = true;
-    }
-    // waits for the finished count only, not for the pass queued behind it
-    if (o->poll) { if (wait_stamp(o, 1, seq)) return -1; }
-    else HIPCHK(hipEventSynchronize(o->ev_done));
-    const int n_done = (int)__atomic_load_n(o->h_ndone, __ATOMIC_ACQUIRE);
     if (!pair && n_done > prev_done) need_fixup = true;
     prev_done = n_done;
     if (n_done >= quorum_count(o->B, o->quorum_sqp)) {
@@ -1537,10 +1617,11 @@ int agx_traj_cartesian_sine_create(agx_ocp *o, int n_points, double dt, const do
   HIPCHK(hipMalloc((void **)&o->d_traj, sizeof(double) * B * n_points * 2 * o->stride));
   HIPCHK(hipMalloc((void **)&o->d_pts, sizeof(double) * B * n_points * (4 * nv + 12)));
   // q | dq | ddq samples, then the per-instance parameters q0 | amp | pulsation and the failure flags
-  const size_t npar = B * (nv + 6);
-  HIPCHK(hipMalloc((void **)&o->d_sine, sizeof(double) * (3 * n + npar) + sizeof(int) * B));
-  double *d = o->d_sine, *dpar = d + 3 * n;
-  int *dfail = reinterpret_cast<int *>(dpar + npar);
+  const size_t npar = B * (nv + 6), npose = B * (size_t)n_points * 12;
+  o->n_points = 0;  // until the trajectory is complete: a failed build leaves nothing a later window / MPC step could consume
+  HIPCHK(hipMalloc((void **)&o->d_sine, sizeof(double) * (3 * n + npar + npose) + sizeof(int) * B));
+  double *d = o->d_sine, *dpar = d + 3 * n, *dpose = dpar + npar;
+  int *dfail = reinterpret_cast<int *>(dpose + npose);
   HIPCHK(hipMemsetAsync(d + 2 * n, 0, sizeof(double) * n, o->stream));  // ddq = 0
   HIPCHK(hipMemcpyAsync(dpar, q0, sizeof(double) * B * nv, hipMemcpyHostToDevice, o->stream));
   HIPCHK(hipMemcpyAsync(dpar + B * nv, amp, sizeof(double) * B * 3, hipMemcpyHostToDevice, o->stream));
@@ -1549,14 +1630,14 @@ int agx_traj_cartesian_sine_create(agx_ocp *o, int n_points, double dt, const do
   cp.q0 = dpar; cp.amp = dpar + B * nv; cp.puls = dpar + B * nv + B * 3;
   cp.dt = dt; cp.scale = scale_duration; cp.precision = precision;
   cp.n_points = n_points; cp.frame = frame; cp.it_max = it_max;
-  cp.q = d; cp.dq = d + n; cp.fail = dfail;
+  cp.q = d; cp.dq = d + n; cp.pose = dpose; cp.fail = dfail;
   agx::SineParams sp;
   std::memset(&sp, 0, sizeof(sp));
   sp.gq = d; sp.gdq = d + n; sp.gddq = d + 2 * n;
   for (size_t i = 0; i < nv; ++i) { sp.w_q[i] = w_q[i]; sp.w_qdot[i] = w_qdot[i]; sp.w_effort[i] = w_effort[i]; }
   for (int i = 0; i < 6; ++i) sp.w_pose[i] = w_pose[i];
   sp.dt = 0.0; sp.n_points = n_points; sp.frame = frame;
-  o->n_points = n_points;
+  sp.gpose = dpose;
   int rc = dispatch(o->nv, o->chain, [&](auto NVc, auto CHc) -> int {
     constexpr int NV = decltype(NVc)::value;
     constexpr bool CH = decltype(CHc)::value;
@@ -1576,8 +1657,13 @@ int agx_traj_cartesian_sine_create(agx_ocp *o, int n_points, double dt, const do
     if (failed[b]) {
       char msg[160];
       std::snprintf(msg, sizeof(msg), "inverse kinematics failed to converge: instance %zu at point %d (it_max %d)", b, failed[b] - 1, it_max);
+      // nothing half-built stays behind: set_window / mpc_step refuse a handle without a trajectory
+      (void)hipFree(o->d_traj); o->d_traj = nullptr;
+      (void)hipFree(o->d_pts); o->d_pts = nullptr;
+      (void)hipFree(o->d_sine); o->d_sine = nullptr;
       return fail(msg);
     }
+  o->n_points = n_points;
   if (traj_frames(o, frame)) return -1;
   return agx_traj_set_window(o, 0);
 }

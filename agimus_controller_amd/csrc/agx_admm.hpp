@@ -29,7 +29,7 @@ template <int NV, bool CHAIN>
 __global__ void __launch_bounds__(64) k_con_eval(const DevModel *__restrict__ mp, const DevOcp *__restrict__ op,
                                                  const double *__restrict__ xs, const double *__restrict__ us,
                                                  double *__restrict__ cg, double *__restrict__ cjac,
-                                                 double *__restrict__ nodestat, const DevState *__restrict__ st) {
+                                                 double *__restrict__ nodestat, const DevState *__restrict__ st, int phase) {
   constexpr int NX = 2 * NV, NU = NV;
   const DevModel &m = *mp;
   const DevOcp &o = *op;
@@ -37,7 +37,7 @@ __global__ void __launch_bounds__(64) k_con_eval(const DevModel *__restrict__ mp
   const long long node = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (node >= (long long)o.B * (T + 1)) return;
   const int b = (int)(node / (T + 1)), t = (int)(node % (T + 1));
-  if (st[b].done) return;
+  if (!k1_active(st[b], phase)) return;  // phase 1: at the trial point of a searching instance, results in place
   const DevCons &c = o.cons[t == T ? 1 : 0];
   double x[NX], u[NU], g[AGX_MAX_NC], cj[AGX_MAX_DENSE][24];
 #pragma unroll

@@ -116,7 +116,7 @@ __device__ __forceinline__ void calc_qp_lj_body(const long long blk, LjNode *lds
                                                 const DevOcp *__restrict__ op, const double *__restrict__ dts,
                                                 const double *__restrict__ xs, const double *__restrict__ us, const RefView &rv,
                                                 double *__restrict__ qts, double *__restrict__ auxs,
-                                                const DevState *__restrict__ st) {
+                                                const DevState *__restrict__ st, const int phase) {
   constexpr int NX = 2 * NV;
   typedef QT<NV> Q;
   typedef AUX<NV> A;
@@ -130,11 +130,11 @@ __device__ __forceinline__ void calc_qp_lj_body(const long long blk, LjNode *lds
   const bool node_ok = node < n_nodes;
   const long long nid = node_ok ? node : 0;  // out-of-range groups shadow node 0 and store nothing
   const int b = TERM ? (int)nid : (int)(nid / T), t = TERM ? T : (int)(nid % T);
-  const bool act = node_ok && !st[b].done;
-  if (!__any(act)) return;  // the whole wave (= workgroup) belongs to finished instances
+  const bool act = node_ok && k1_active(st[b], phase);  // phase 1: the trial points of the instances in the line search
+  if (!__any(act)) return;  // the whole wave (= workgroup) belongs to instances this pass skips
   const bool jl = l8 < NV;       // lane carries a joint
   const int j = jl ? l8 : NV - 1;
-  const double preg = st[b].preg;
+  const double preg = k1_preg(st[b], phase);
   const double dt = TERM ? 0.0 : dts[t];
   const double *xp = xs + ((long long)b * (T + 1) + t) * NX;
   const double qj = xp[j], vj = jl ? xp[NV + j] : 0.0;
@@ -688,10 +688,10 @@ template <int NV, bool TERM, bool COLL = false>
 __global__ void __launch_bounds__(64, AGX_K1_WAVES) k_calc_qp_lj(const DevModel *__restrict__ mp, const DevOcp *__restrict__ op,
                                                     const double *__restrict__ dts, const double *__restrict__ xs,
                                                     const double *__restrict__ us, RefView rv, double *__restrict__ qts,
-                                                    double *__restrict__ auxs, const DevState *__restrict__ st) {
+                                                    double *__restrict__ auxs, const DevState *__restrict__ st, int phase) {
   __shared__ LjNode lds[8];  // one wave per workgroup: 8 nodes
   __shared__ LjModel lmod;
-  calc_qp_lj_body<NV, TERM, COLL>(blockIdx.x, lds, lmod, mp, op, dts, xs, us, rv, qts, auxs, st);
+  calc_qp_lj_body<NV, TERM, COLL>(blockIdx.x, lds, lmod, mp, op, dts, xs, us, rv, qts, auxs, st, phase);
 }
 
 // The derivative pass of one SQP iteration in ONE launch: the first n_run workgroups take the running
@@ -701,13 +701,14 @@ template <int NV, bool COLL = false>
 __global__ void __launch_bounds__(64, AGX_K1_WAVES) k_calc_qp_lj_all(const DevModel *__restrict__ mp, const DevOcp *__restrict__ op,
                                                         const double *__restrict__ dts, const double *__restrict__ xs,
                                                         const double *__restrict__ us, RefView rv, double *__restrict__ qts,
-                                                        double *__restrict__ auxs, const DevState *__restrict__ st, int n_run) {
+                                                        double *__restrict__ auxs, const DevState *__restrict__ st, int n_run,
+                                                        int phase) {
   __shared__ LjNode lds[8];
   __shared__ LjModel lmod;
   if ((int)blockIdx.x < n_run)
-    calc_qp_lj_body<NV, false, COLL>(blockIdx.x, lds, lmod, mp, op, dts, xs, us, rv, qts, auxs, st);
+    calc_qp_lj_body<NV, false, COLL>(blockIdx.x, lds, lmod, mp, op, dts, xs, us, rv, qts, auxs, st, phase);
   else
-    calc_qp_lj_body<NV, true, COLL>((long long)blockIdx.x - n_run, lds, lmod, mp, op, dts, xs, us, rv, qts, auxs, st);
+    calc_qp_lj_body<NV, true, COLL>((long long)blockIdx.x - n_run, lds, lmod, mp, op, dts, xs, us, rv, qts, auxs, st, phase);
 }
 
 }  // namespace agx

@@ -31,7 +31,17 @@ struct DevState {
   int ls_acc;                    // split line search (large models): step accepted in this SQP iteration
   int admm_refactor;             // ADMM: the Hessian part of the augmented tiles changed (first iteration / new rho)
   int dir_fail;                  // the last backward sweep met a non-positive / non-finite pivot (Quu not positive definite)
+  // line search by derivative passes at the trial points (nv <= 7: k_sqp_head / k_sqp_accept)
+  int searching;                 // the instance is inside the line search of the current SQP iteration
+  int ls_n;                      // index of the trial in flight: step length 2^-ls_n
+  int tiles_ok;                  // QP / aux tiles (and the constraint data) belong to the current (xs, us): the derivative pass skips it
+  int pad_ls;
+  double preg_trial;             // control regularisation the NEXT iteration runs with if the trial in flight is accepted (baked into its tiles)
 };
+// which instances a derivative pass (K1, k_con_eval) works on: phase 0 = start of an SQP iteration (everyone whose tiles are
+// stale), phase 1 = the trial points of the instances that are searching (their tiles are overwritten in place)
+__device__ __forceinline__ bool k1_active(const DevState &S, int phase) { return phase ? (S.searching != 0) : (!S.done && !S.tiles_ok); }
+__device__ __forceinline__ double k1_preg(const DevState &S, int phase) { return phase ? S.preg_trial : S.preg; }
 
 // Addressing of the reference tiles (host tile or a window of the resident trajectory).
 struct RefView {
@@ -238,7 +248,7 @@ __device__ __forceinline__ void calc_qp_body(const long long unit, const DevMode
                                              const double *__restrict__ dts, const double *__restrict__ xs,
                                              const double *__restrict__ us, const RefView &rv, double *__restrict__ qts,
                                              double *__restrict__ auxs, const DevState *__restrict__ st,
-                                             double *__restrict__ auxg = nullptr) {
+                                             double *__restrict__ auxg = nullptr, int phase = 0) {
   constexpr int NX = 2 * NV, NU = NV;
   typedef QT<NV> Q;
   typedef AUX<NV> A;
@@ -247,8 +257,8 @@ __device__ __forceinline__ void calc_qp_body(const long long unit, const DevMode
   const int T = o.T;
   if (unit >= (long long)o.B * T) return;
   const int b = (int)(unit / T), t = (int)(unit % T);
-  if (st[b].done) return;
-  const double preg = st[b].preg;
+  if (!k1_active(st[b], phase)) return;
+  const double preg = k1_preg(st[b], phase);
   const double dt = dts[t];
   double x[NX], u[NU];
   const double *xp = xs + ((long long)b * (T + 1) + t) * NX;
@@ -367,15 +377,15 @@ __global__ void __launch_bounds__(64) k_calc_qp(const DevModel *__restrict__ mp,
                                                 const double *__restrict__ dts, const double *__restrict__ xs,
                                                 const double *__restrict__ us, RefView rv, double *__restrict__ qts,
                                                 double *__restrict__ auxs, const DevState *__restrict__ st,
-                                                double *__restrict__ auxg = nullptr) {
-  calc_qp_body<NV, CHAIN, GEN>((long long)blockIdx.x * blockDim.x + threadIdx.x, mp, op, dts, xs, us, rv, qts, auxs, st, auxg);
+                                                double *__restrict__ auxg = nullptr, int phase = 0) {
+  calc_qp_body<NV, CHAIN, GEN>((long long)blockIdx.x * blockDim.x + threadIdx.x, mp, op, dts, xs, us, rv, qts, auxs, st, auxg, phase);
 }
 
 template <int NV, bool CHAIN, bool GEN = false>
 __device__ __forceinline__ void calc_qp_term_body(const int b, const DevModel *__restrict__ mp, const DevOcp *__restrict__ op,
                                                   const double *__restrict__ xs, const RefView &rv, double *__restrict__ qts,
                                                   double *__restrict__ auxs, const DevState *__restrict__ st,
-                                                  double *__restrict__ auxg = nullptr) {
+                                                  double *__restrict__ auxg = nullptr, int phase = 0) {
   constexpr int NX = 2 * NV;
   typedef QT<NV> Q;
   typedef AUX<NV> A;
@@ -383,7 +393,7 @@ __device__ __forceinline__ void calc_qp_term_body(const int b, const DevModel *_
   const DevOcp &o = *op;
   const int T = o.T;
   if (b >= o.B) return;
-  if (st[b].done) return;
+  if (!k1_active(st[b], phase)) return;
   double x[NX];
   const double *xp = xs + ((long long)b * (T + 1) + T) * NX;
 #pragma unroll
@@ -433,8 +443,8 @@ template <int NV, bool CHAIN, bool GEN = false>
 __global__ void __launch_bounds__(64) k_calc_qp_term(const DevModel *__restrict__ mp, const DevOcp *__restrict__ op,
                                                      const double *__restrict__ xs, RefView rv, double *__restrict__ qts,
                                                      double *__restrict__ auxs, const DevState *__restrict__ st,
-                                                     double *__restrict__ auxg = nullptr) {
-  calc_qp_term_body<NV, CHAIN, GEN>(blockIdx.x * blockDim.x + threadIdx.x, mp, op, xs, rv, qts, auxs, st, auxg);
+                                                     double *__restrict__ auxg = nullptr, int phase = 0) {
+  calc_qp_term_body<NV, CHAIN, GEN>(blockIdx.x * blockDim.x + threadIdx.x, mp, op, xs, rv, qts, auxs, st, auxg, phase);
 }
 
 __device__ __forceinline__ double wave_max(double v) {
@@ -677,9 +687,11 @@ __device__ __forceinline__ void riccati_body(const int b, const DevOcp *__restri
   //   1  speculative, launched next to the direction sweep of SQP iteration `iter`: live instances, same dreg;
   //   2  fix-up on exit: only instances whose last direction (dir_iter) has no sweep yet.
   if (!gains_pass && (S.done || S.admm_conv)) return;
-  if (gains_pass && gmode == 1 && S.done) return;
+  // gmode 4: as 1 (unfinished instances, current regularisation) but launched on its own after the head of the step, which
+  // has set dir_iter: the sweep of an iteration the loop may end with before the line search overwrites its tiles
+  if (gains_pass && (gmode == 1 || gmode == 4) && S.done) return;
   if (gains_pass && gmode == 2 && S.gains_iter == S.dir_iter) return;
-  const double dreg = (gains_pass && gmode != 1) ? (S.solved ? S.dreg : S.gains_dreg) : S.dreg;
+  const double dreg = (gains_pass && gmode != 1 && gmode != 4) ? (S.solved ? S.dreg : S.gains_dreg) : S.dreg;
   if (gains_pass && gmode != 0 && lane == 0) S.gains_iter = (gmode == 1) ? iter : S.dir_iter;
   const double *qb = qts + (long long)b * (T + 1) * TS;
   const double *ab = auxs + (long long)b * (T + 1) * A::SIZE;
@@ -995,40 +1007,84 @@ AGX_UNROLL_NV
 }
 
 // ---------------------------------------------------------------------------
-// K4: step kernel, one workgroup per instance, lanes over nodes.
-//   instance totals of the per-node KKT / cost / gap shares (k_node_kkt) -> convergence test
-//   then the merit line search: alpha = 2^-n, accept the first merit_try < merit.
-// mode bit0: run the line search / state update; without it only the prologue runs (test hook).
-// mode bit2: timing mode (no convergence exit, nothing committed) so that launches are repeatable.
-// mode bit3: convergence test only; the line search is done node-parallel by k_ls_trial / k_ls_accept (large models).
+// K4: the step of one SQP iteration (SolverCSQP::solve after computeDirection).
+//
+// nv <= 7 (k_sqp_head / k_sqp_accept): THE LINE-SEARCH TRIAL IS THE NEXT DERIVATIVE PASS.  Upstream a trial evaluates
+// problem.calc at (xs + alpha dx, us + alpha du) and the accepted point is evaluated again, with derivatives, at the start of
+// the next iteration.  Here k_sqp_head writes the trial iterate, the node-parallel derivative kernel (K1, and k_con_eval of
+// constrained problems) runs AT THE TRIAL POINT, over the tiles of the current iterate, which nobody needs any more
+// (direction, KKT shares and the speculative gains sweep have consumed them), and k_sqp_accept sums cost, gaps and
+// violation out of the new tiles: merit_try < merit (or the filter test) -> the trial iterate becomes the iterate and its
+// tiles are already there (tiles_ok: the next iteration's derivative pass skips the instance); otherwise the next step
+// length goes through the same two launches (the host learns from a counter that somebody is still searching).  With
+// alpha = 1 accepted -- every step of a warm-started MPC loop -- an SQP iteration costs ONE node evaluation instead of two,
+// and no kernel holds a one-lane-per-node evaluation of a node any more (the step kernel of constrained problems used to:
+// 512 VGPRs, 450 spilled registers).
+//
+// large models (k_step + k_ls_trial_wg / k_ls_accept, agx_big.hpp): convergence test here, value-only trials node parallel.
 // ---------------------------------------------------------------------------
-// CON: the merit of a trial point includes the constraint violation.  A template flag rather than a
-// run-time test: compiled into the unconstrained kernel, the registers and scratch of every residual
-// kind a constraint may carry cost the hot path 0.155 -> 0.21 ms.
-template <int NV, bool CHAIN, bool GEN = false, bool FILTER = false, bool CON = false>
-__global__ void __launch_bounds__(CON ? 256 : 128) k_step(const DevModel *__restrict__ mp, const DevOcp *__restrict__ op,
-                                              const double *__restrict__ dts, double *__restrict__ xs,
-                                              double *__restrict__ us, RefView rv, const double *__restrict__ qts,
-                                              const double *__restrict__ auxs, const double *__restrict__ dxs,
-                                              const double *__restrict__ nodestat, const double *__restrict__ dus,
-                                              DevState *__restrict__ st, int iter, int max_iter, int mode,
-                                              int *__restrict__ n_done) {
+// crocoddyl / mim_solvers regularisation schedule on the step length (th_stepdec 0.5, th_stepinc 0.01, factor 10)
+__device__ __forceinline__ void reg_schedule(double used, double &pr, double &dr, bool &stop) {
+  if (used > 0.5) { pr = fmax(pr / 10.0, kRegMin); dr = fmax(dr / 10.0, kRegMin); }
+  stop = false;
+  if (used <= 0.01) {
+    pr = fmin(pr * 10.0, kRegMax);
+    dr = fmin(dr * 10.0, kRegMax);
+    if (pr == kRegMax) stop = true;
+  }
+}
+// end of an SQP iteration of one instance (one thread): step of length `used` accepted (ok) or every trial rejected
+__device__ __forceinline__ void sqp_iteration_end(DevState &S, bool ok, double used, int iter, int max_iter, int *n_done) {
+  if (!ok) S.flags |= 2;
+  double pr = S.preg, dr = S.dreg;
+  // the gains on exit belong to the point this direction was computed at, with the regularisation
+  // that was in force then: keep it in gains_preg / gains_dreg
+  S.gains_preg = pr;
+  S.gains_dreg = dr;
+  bool stop;
+  reg_schedule(used, pr, dr, stop);
+  S.preg = pr;
+  S.dreg = dr;
+  S.dir_fail = 0;
+  S.searching = 0;
+  if (stop) {
+    S.done = 1;
+    S.iter = iter + 1;
+    atomicAdd(n_done, 1);
+  } else if (iter + 1 == max_iter) {
+    S.iter = max_iter;
+  }
+}
+// trial iterate of step length alpha into the staging halves of xs / us (behind the B instances of the live buffers)
+template <int NV>
+__device__ __forceinline__ void write_trial_iterate(const DevOcp &o, int b, double alpha, const double *__restrict__ xs,
+                                                    const double *__restrict__ us, const double *__restrict__ dxs,
+                                                    const double *__restrict__ dus, double *__restrict__ xs_t, double *__restrict__ us_t) {
   constexpr int NX = 2 * NV, NU = NV;
-  (void)qts; (void)auxs;  // kept in the signature: the step kernel of earlier layouts read them
-  __shared__ double red[16], s_merit;  // four waves at most (constrained problems run 256 threads: T + 1 = 201 nodes in one round per trial)
+  const int T = o.T;
+  const long long ox = (long long)b * (T + 1) * NX, ou = (long long)b * T * NU;
+  for (int e = threadIdx.x; e < (T + 1) * NX; e += blockDim.x) xs_t[ox + e] = xs[ox + e] + alpha * dxs[ox + e];
+  for (int e = threadIdx.x; e < T * NU; e += blockDim.x) us_t[ou + e] = us[ou + e] + alpha * dus[ou + e];
+}
+
+// Head of the step: instance totals of the per-node KKT / cost / gap / violation shares (k_node_kkt, k_con_eval) in a
+// fixed summation order -> KKT test; a converged instance finishes; the others enter the line search at alpha = 1 (trial
+// iterate written here) -- unless their direction came out of a failed factorisation: that one is never accepted (the CPU
+// restatement gets there through NaNs in the trial merit), all ten step lengths count as rejected at once.
+// mode bit0: run the line search; without it only the totals (test hook).  mode bit2: timing mode (nothing committed).
+// n_done[0]: finished instances.
+template <int NV>
+__global__ void __launch_bounds__(128) k_sqp_head(const DevOcp *__restrict__ op, const double *__restrict__ xs, const double *__restrict__ us,
+                                                  const double *__restrict__ dxs, const double *__restrict__ dus,
+                                                  double *__restrict__ xs_t, double *__restrict__ us_t,
+                                                  const double *__restrict__ nodestat, DevState *__restrict__ st, int iter, int max_iter,
+                                                  int mode, int *__restrict__ n_done) {
+  __shared__ double red[8];
   __shared__ int flag;
-  const DevModel &m = *mp;
   const DevOcp &o = *op;
-  const int T = o.T, b = blockIdx.x, tid = threadIdx.x, nw = blockDim.x >> 6;
+  const int T = o.T, b = blockIdx.x, tid = threadIdx.x;
   DevState &S = st[b];
   if (S.done) return;
-  double *X = xs + (long long)b * (T + 1) * NX, *U = us + (long long)b * T * NU;
-  const double *DX = dxs + (long long)b * (T + 1) * NX;
-  const double *DU = dus + (long long)b * T * NU;
-  const double preg = S.preg, dreg = S.dreg;
-
-  constexpr int NPT = 4;  // nodes per thread: supports T + 1 <= 4 * blockDim
-  // ---- per-node KKT / cost / gap shares (k_node_kkt) -> instance totals, fixed summation order
   double kkt = 0.0, csum = 0.0, gsum = 0.0, vsum = 0.0;
   for (int t = tid; t <= T; t += blockDim.x) {
     const double *ns = nodestat + ((long long)b * (T + 1) + t) * 4;
@@ -1041,161 +1097,150 @@ __global__ void __launch_bounds__(CON ? 256 : 128) k_step(const DevModel *__rest
   csum = wave_sum(csum);
   gsum = wave_sum(gsum);
   vsum = wave_sum(vsum);
-  if ((tid & 63) == 0) { red[tid >> 6] = kkt; red[4 + (tid >> 6)] = csum; red[8 + (tid >> 6)] = gsum; red[12 + (tid >> 6)] = vsum; }
+  if ((tid & 63) == 0) { red[tid >> 6] = kkt; red[2 + (tid >> 6)] = csum; red[4 + (tid >> 6)] = gsum; red[6 + (tid >> 6)] = vsum; }
   __syncthreads();
   if (tid == 0) {
-    double kk = 0.0, cc = 0.0, gg = 0.0, vv = 0.0;
-    for (int w = 0; w < nw; ++w) { kk = fmax(kk, red[w]); cc += red[4 + w]; gg += red[8 + w]; vv += red[12 + w]; }
+    double kk = fmax(red[0], red[1]);
+    const double cc = red[2] + red[3], gg = red[4] + red[5], vv = red[6] + red[7];
     kk = fmax(kk, vv);  // checkKKTConditions: KKT = max(KKT, constraint_norm)
-    if (S.dir_fail) kk = __builtin_nan("");  // discarded direction: its KKT residual is undefined (never "converged")
+    const int dir_fail = S.dir_fail;
+    if (dir_fail) kk = __builtin_nan("");  // discarded direction: its KKT residual is undefined (never "converged")
     S.kkt = kk; S.cost = cc; S.gap = gg; S.con = vv; S.merit = cc + o.mu_dyn * gg + o.mu_con * vv;
     S.qp_iters = o.has_con ? S.admm_iter : 1;
     S.admm_conv = 0;  // the next SQP iteration's plain LQR pass runs for this instance again
+    if (!(mode & 4)) S.dir_iter = iter;
+    if (!(kk == kk)) S.flags |= 1;
+    const bool conv = (kk <= o.tol) && (mode & 1) && !(mode & 4);
+    int what = 0;  // 0: nothing more, 1: line search starts
+    if (conv) { S.solved = 1; S.done = 1; S.iter = iter; atomicAdd(n_done, 1); }
+    else if ((mode & 1) && !(mode & 4)) {
+      S.tiles_ok = 0;
+      if (dir_fail) sqp_iteration_end(S, false, 1.0 / 512.0, iter, max_iter, n_done);
+      else {
+        what = 1;
+        S.searching = 1;
+        S.ls_n = 0;
+        double pr = S.preg, dr = S.dreg;
+        bool stop;
+        reg_schedule(1.0, pr, dr, stop);
+        S.preg_trial = pr;
+      }
+    }
+    flag = what;
+  }
+  __syncthreads();
+  if (flag) write_trial_iterate<NV>(o, b, 1.0, xs, us, dxs, dus, xs_t, us_t);
+}
+
+// After the derivative pass at the trial points: totals of the trial (cost and dynamics gaps out of the new tiles, violation
+// shares of k_con_eval), merit test (the reference default: accept the first alpha = 2^-n with merit_try < merit) or
+// the solver's filter of size 1 (rejected only if no better in cost AND gaps AND constraints), then
+//   accepted: (xs, us) <- trial iterate, tiles_ok, regularisation schedule, end of the iteration;
+//   rejected: next step length -> new trial iterate, counted in n_done[3]; after the tenth the iteration ends
+//             with the step rejected and the tiles stale.
+template <int NV>
+__global__ void __launch_bounds__(128) k_sqp_accept(const DevOcp *__restrict__ op, double *__restrict__ xs, double *__restrict__ us,
+                                                    const double *__restrict__ dxs, const double *__restrict__ dus,
+                                                    double *__restrict__ xs_t, double *__restrict__ us_t,
+                                                    const double *__restrict__ qts, const double *__restrict__ nodestat,
+                                                    DevState *__restrict__ st, int iter, int max_iter, int *__restrict__ n_done) {
+  constexpr int NX = 2 * NV, NU = NV;
+  typedef QT<NV> Q;
+  __shared__ double red[6];
+  __shared__ int flag;
+  __shared__ double s_alpha;
+  const DevOcp &o = *op;
+  const int T = o.T, b = blockIdx.x, tid = threadIdx.x;
+  DevState &S = st[b];
+  if (!S.searching) return;
+  double pc = 0.0, pg = 0.0, pv = 0.0;
+  for (int t = tid; t <= T; t += blockDim.x) {
+    const double *qt = qts + ((long long)b * (T + 1) + t) * Q::SIZE;
+    pc += qt[Q::cost];
+    double g = 0.0;
+#pragma unroll
+    for (int i = 0; i < NX; ++i) g += fabs(qt[Q::f + i]);  // the terminal tile carries zeros there
+    pg += g;
+    if (o.has_con) pv += nodestat[((long long)b * (T + 1) + t) * 4 + 3];
+  }
+  pc = wave_sum(pc); pg = wave_sum(pg); pv = wave_sum(pv);
+  if ((tid & 63) == 0) { red[tid >> 6] = pc; red[2 + (tid >> 6)] = pg; red[4 + (tid >> 6)] = pv; }
+  __syncthreads();
+  if (tid == 0) {
+    const double tc = red[0] + red[1], tg = red[2] + red[3], tv = red[4] + red[5];
+    bool ok;
+    if (o.use_filter) ok = !((S.cost <= tc) && (S.gap <= tg) && (S.con <= tv));
+    else ok = S.merit > tc + o.mu_dyn * tg + o.mu_con * tv;
+    const int n = S.ls_n;
+    const double alpha = ldexp(1.0, -n);
+    int what;  // 1: accepted, 2: next trial, 0: all ten rejected
+    if (ok) {
+      what = 1;
+      S.tiles_ok = 1;
+      sqp_iteration_end(S, true, alpha, iter, max_iter, n_done);
+    } else if (n + 1 < 10) {
+      what = 2;
+      S.ls_n = n + 1;
+      double pr = S.preg, dr = S.dreg;
+      bool stop;
+      reg_schedule(0.5 * alpha, pr, dr, stop);
+      S.preg_trial = pr;
+      atomicAdd(n_done + 3, 1);  // never reset: the host follows its growth (trials handed on to the next round)
+      s_alpha = 0.5 * alpha;
+    } else {
+      what = 0;
+      sqp_iteration_end(S, false, alpha, iter, max_iter, n_done);
+    }
+    flag = what;
+  }
+  __syncthreads();
+  if (flag == 1) {
+    const long long ox = (long long)b * (T + 1) * NX, ou = (long long)b * T * NU;
+    for (int e = tid; e < (T + 1) * NX; e += blockDim.x) xs[ox + e] = xs_t[ox + e];
+    for (int e = tid; e < T * NU; e += blockDim.x) us[ou + e] = us_t[ou + e];
+  } else if (flag == 2) {
+    write_trial_iterate<NV>(o, b, s_alpha, xs, us, dxs, dus, xs_t, us_t);
+  }
+}
+
+// Large models: instance totals and the convergence test; the line search runs in k_ls_trial_wg / k_ls_accept (mode bit3),
+// which count the searching instances in n_done[2].  mode bits as k_sqp_head.
+template <int NV>
+__global__ void __launch_bounds__(128) k_step(const DevOcp *__restrict__ op, const double *__restrict__ nodestat,
+                                              DevState *__restrict__ st, int iter, int mode, int *__restrict__ n_done) {
+  __shared__ double red[8];
+  const DevOcp &o = *op;
+  const int T = o.T, b = blockIdx.x, tid = threadIdx.x;
+  DevState &S = st[b];
+  if (S.done) return;
+  double kkt = 0.0, csum = 0.0, gsum = 0.0;
+  for (int t = tid; t <= T; t += blockDim.x) {
+    const double *ns = nodestat + ((long long)b * (T + 1) + t) * 4;
+    kkt = fmax(kkt, ns[0]);
+    csum += ns[1];
+    gsum += ns[2];
+  }
+  kkt = wave_max(kkt);
+  csum = wave_sum(csum);
+  gsum = wave_sum(gsum);
+  if ((tid & 63) == 0) { red[tid >> 6] = kkt; red[2 + (tid >> 6)] = csum; red[4 + (tid >> 6)] = gsum; }
+  __syncthreads();
+  if (tid == 0) {
+    double kk = fmax(red[0], red[1]);
+    const double cc = red[2] + red[3], gg = red[4] + red[5];
+    if (S.dir_fail) kk = __builtin_nan("");
+    S.kkt = kk; S.cost = cc; S.gap = gg; S.con = 0.0; S.merit = cc + o.mu_dyn * gg;
+    S.qp_iters = 1;
+    S.admm_conv = 0;
     S.ls_acc = 0;
     if (!(mode & 4)) S.dir_iter = iter;
     if (!(kk == kk)) S.flags |= 1;
     const bool conv = (kk <= o.tol) && (mode & 1) && !(mode & 4);
     if (conv) { S.solved = 1; S.done = 1; S.iter = iter; atomicAdd(n_done, 1); }
-    // split line search (large models): n_done[2] counts the instances that still look for a step length, so that
-    // the trial / accept launches behind this one can leave at their first instruction once it is zero
+    // n_done[2] counts the instances that still look for a step length, so that the trial / accept launches behind this
+    // one can leave at their first instruction once it is zero
     if (!conv && (mode & 8) && (mode & 1)) atomicAdd(n_done + 2, 1);
-    flag = conv ? 1 : 0;
-    s_merit = S.merit;
   }
-  __syncthreads();
-  if (flag || !(mode & 1) || (mode & 8)) return;  // bit3: the line search runs in k_ls_trial_wg / k_ls_accept
-  // large models never search here (a per-lane node evaluation needs tens of KB of private arrays: its mere
-  // presence in the kernel would reserve that scratch at every launch)
-  if constexpr (NV <= 8) {
-  const double merit = s_merit;
-  __syncthreads();
-  // ---- line search
-  double alpha = 1.0, used = 1.0;
-  bool ok = false;
-  // a direction from a failed factorisation is never accepted (the CPU restatement gets there through
-  // NaNs in the trial merit): all ten step lengths count as rejected
-  const int n_trials = S.dir_fail ? 0 : 10;
-  if (n_trials == 0) used = 1.0 / 512.0;
-  for (int n = 0; n < n_trials; ++n, alpha *= 0.5) {
-    used = alpha;
-    if constexpr (!FILTER) {
-      // merit line search (the reference default): one accumulator, cost + mu_dyn gaps + mu_con violation
-      double part = 0.0;
-      for (int r = 0; r < NPT; ++r) {
-        const int t = tid + r * blockDim.x;
-        if (t > T) break;
-        double x[NX], u[NU];
-AGX_UNROLL_NV
-        for (int i = 0; i < NX; ++i) x[i] = X[(long long)t * NX + i] + alpha * DX[(long long)t * NX + i];
-        if (t < T) {
-AGX_UNROLL_NV
-          for (int i = 0; i < NU; ++i) u[i] = U[(long long)t * NU + i] + alpha * DU[(long long)t * NU + i];
-          double xn[NX], c;
-          node_calc_running<NV, CHAIN, GEN>(m, o.rows[0], dts[t], x, u, ref_at(rv, b, t, T), frames_at(rv, b, t, T), xn, &c);
-          double g = 0.0;
-AGX_UNROLL_NV
-          for (int i = 0; i < NX; ++i)
-            g += fabs(xn[i] - (X[(long long)(t + 1) * NX + i] + alpha * DX[(long long)(t + 1) * NX + i]));
-          part += c + o.mu_dyn * g;
-          if constexpr (CON) part += o.mu_con * constraint_violation<NV, CHAIN>(m, o.cons[0], x, u);
-        } else {
-          double c;
-          node_calc_terminal<NV, CHAIN, GEN>(m, o.rows[1], x, ref_at(rv, b, T, T), frames_at(rv, b, T, T), &c);
-          part += c;
-          if constexpr (CON) part += o.mu_con * constraint_violation<NV, CHAIN>(m, o.cons[1], x, x);
-        }
-      }
-      part = wave_sum(part);
-      if ((tid & 63) == 0) red[tid >> 6] = part;
-      __syncthreads();
-      if (tid == 0) {
-        double tot = 0.0;
-        for (int w = 0; w < nw; ++w) tot += red[w];
-        flag = (merit > tot) ? 1 : 0;
-      }
-    } else {
-      // filter line search with the solver's default filter size 1 (SolverCSQP::solve): the trial is
-      // rejected only if it is no better than the current point in cost AND gaps AND constraints
-      double pc = 0.0, pg = 0.0, pv = 0.0;
-      for (int r = 0; r < NPT; ++r) {
-        const int t = tid + r * blockDim.x;
-        if (t > T) break;
-        double x[NX], u[NU];
-AGX_UNROLL_NV
-        for (int i = 0; i < NX; ++i) x[i] = X[(long long)t * NX + i] + alpha * DX[(long long)t * NX + i];
-        if (t < T) {
-AGX_UNROLL_NV
-          for (int i = 0; i < NU; ++i) u[i] = U[(long long)t * NU + i] + alpha * DU[(long long)t * NU + i];
-          double xn[NX], c;
-          node_calc_running<NV, CHAIN, GEN>(m, o.rows[0], dts[t], x, u, ref_at(rv, b, t, T), frames_at(rv, b, t, T), xn, &c);
-          double g = 0.0;
-AGX_UNROLL_NV
-          for (int i = 0; i < NX; ++i)
-            g += fabs(xn[i] - (X[(long long)(t + 1) * NX + i] + alpha * DX[(long long)(t + 1) * NX + i]));
-          pc += c; pg += g;
-          if constexpr (CON) pv += constraint_violation<NV, CHAIN>(m, o.cons[0], x, u);
-        } else {
-          double c;
-          node_calc_terminal<NV, CHAIN, GEN>(m, o.rows[1], x, ref_at(rv, b, T, T), frames_at(rv, b, T, T), &c);
-          pc += c;
-          if constexpr (CON) pv += constraint_violation<NV, CHAIN>(m, o.cons[1], x, x);
-        }
-      }
-      pc = wave_sum(pc); pg = wave_sum(pg); pv = wave_sum(pv);
-      if ((tid & 63) == 0) { red[tid >> 6] = pc; red[4 + (tid >> 6)] = pg; red[8 + (tid >> 6)] = pv; }
-      __syncthreads();
-      if (tid == 0) {
-        double tc = 0.0, tg = 0.0, tv = 0.0;
-        for (int w = 0; w < nw; ++w) { tc += red[w]; tg += red[4 + w]; tv += red[8 + w]; }
-        const bool worse = (S.cost <= tc) && (S.gap <= tg) && (S.con <= tv);
-        flag = worse ? 0 : 1;
-      }
-    }
-    __syncthreads();
-    ok = flag != 0;
-    if (ok) break;
-    __syncthreads();
-  }
-  if (mode & 4) return;  // timing mode: leave the iterate and the solver state untouched
-  if (ok) {
-    for (int r = 0; r < NPT; ++r) {
-      const int t = tid + r * blockDim.x;
-      if (t > T) break;
-AGX_UNROLL_NV
-      for (int i = 0; i < NX; ++i) X[(long long)t * NX + i] += used * DX[(long long)t * NX + i];
-      if (t < T) {
-AGX_UNROLL_NV
-        for (int i = 0; i < NU; ++i) U[(long long)t * NU + i] += used * DU[(long long)t * NU + i];
-      }
-    }
-  }
-  if (tid == 0) {
-    if (!ok) S.flags |= 2;
-    double pr = S.preg, dr = S.dreg;
-    // crocoddyl/mim_solvers regularisation schedule (th_stepdec 0.5, th_stepinc 0.01, factor 10)
-    if (used > 0.5) { pr = fmax(pr / 10.0, kRegMin); dr = fmax(dr / 10.0, kRegMin); }
-    bool stop = false;
-    if (used <= 0.01) {
-      pr = fmin(pr * 10.0, kRegMax);
-      dr = fmin(dr * 10.0, kRegMax);
-      if (pr == kRegMax) stop = true;
-    }
-    // the gains on exit belong to the point this direction was computed at, with the regularisation
-    // that was in force then: keep it in gains_preg / gains_dreg
-    S.gains_preg = preg;
-    S.gains_dreg = dreg;
-    S.preg = pr;
-    S.dreg = dr;
-    S.dir_fail = 0;
-    if (stop) {
-      S.done = 1;
-      S.iter = iter + 1;
-      atomicAdd(n_done, 1);
-    } else if (iter + 1 == max_iter) {
-      S.iter = max_iter;
-    }
-  }
-  }  // NV <= 8
 }
 
 // ---------------------------------------------------------------------------
@@ -1210,10 +1255,19 @@ __global__ void k_reset_state(DevState *st, int B, int *n_done) {
   s.kkt = 0.0; s.cost = 0.0; s.merit = 0.0; s.gap = 0.0;
   s.preg = kRegMin; s.dreg = kRegMin;
   s.iter = 0; s.qp_iters = 0; s.solved = 0; s.flags = 0; s.done = 0; s.gains_iter = -1; s.dir_iter = -1; s.dir_fail = 0;
+  s.searching = 0; s.ls_n = 0; s.tiles_ok = 0; s.pad_ls = 0; s.preg_trial = kRegMin;
   s.gains_preg = kRegMin; s.gains_dreg = kRegMin;
   st[b] = s;
 }
 
+// two words under one stamp
+__global__ void k_publish2(const int *__restrict__ d_value0, const int *__restrict__ d_value1, unsigned long long *host_value0,
+                           unsigned long long *host_value1, unsigned long long *host_seq, unsigned long long seq) {
+  __hip_atomic_store(host_value0, (unsigned long long)(unsigned)*d_value0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  __hip_atomic_store(host_value1, (unsigned long long)(unsigned)*d_value1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  __threadfence_system();
+  __hip_atomic_store(host_seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 // stream -> host hand-off through mapped pinned memory: value first, then the sequence stamp
 __global__ void k_publish(const int *__restrict__ d_value, unsigned long long *host_value, unsigned long long *host_seq,
                           unsigned long long seq) {
@@ -1379,6 +1433,7 @@ AGX_UNROLL_NV
     s.kkt = 0.0; s.cost = 0.0; s.merit = 0.0; s.gap = 0.0;
     s.preg = kRegMin; s.dreg = kRegMin;
     s.iter = 0; s.qp_iters = 0; s.solved = 0; s.flags = 0; s.done = 0; s.gains_iter = -1; s.dir_iter = -1; s.dir_fail = 0;
+  s.searching = 0; s.ls_n = 0; s.tiles_ok = 0; s.pad_ls = 0; s.preg_trial = kRegMin;
     s.gains_preg = kRegMin; s.gains_dreg = kRegMin;
     st[b] = s;
   }
@@ -1544,6 +1599,7 @@ struct CartSineParams {
   double dt, scale, precision;
   int n_points, frame, it_max;
   double *q, *dq;                 // [B][n_points][nv]
+  double *pose;                   // [B][n_points][12]: the DESIRED end-effector pose (R row major | p), the reference the points carry
   int *fail;                      // [B]
 };
 // x <- A^-1 x for a symmetric positive definite 6 x 6 (J J'): elimination without pivoting
@@ -1630,7 +1686,7 @@ AGX_UNROLL_NV
       mtv3(R0, d, prel);
       log6<false>(Rrel, prel, err, nullptr, nullptr);
       if (sqrt(dot6(err, err)) < cp.precision) break;
-      if (it == cp.it_max) { if (!failed) failed = i + 1; break; }
+      if (it > cp.it_max) { if (!failed) failed = i + 1; break; }  // upstream: `if i > it_max: break` (sine_wave_cartesian_space.py:80)
       frame_jacobian_rows<NV, CHAIN>(m, k, R, p, jf, 1, J);
       double dq[NV];
       pinv_apply<NV>(J, err, dq);
@@ -1643,6 +1699,12 @@ AGX_UNROLL_NV
     const long long o = ((long long)b * cp.n_points + i) * NV;
 AGX_UNROLL_NV
     for (int e = 0; e < NV; ++e) { cp.q[o + e] = q[e]; cp.dq[o + e] = dq[e]; }
+    // the point's end-effector reference is the desired pose ee_des_pos (sine_wave_cartesian_space.py:126-133), not FK(q_ik)
+    double *po = cp.pose + ((long long)b * cp.n_points + i) * 12;
+#pragma unroll
+    for (int e = 0; e < 9; ++e) po[e] = R0[e];
+#pragma unroll
+    for (int e = 0; e < 3; ++e) po[9 + e] = des_p[e];
   }
   cp.fail[b] = failed;
 }
@@ -1741,6 +1803,7 @@ struct SineParams {
   // generic trajectory (trajectories/generic_trajectory.py:37-70): samples given by the caller,
   // [B][n_points][nv] each; when set they replace the sine formula
   const double *gq, *gdq, *gddq;
+  const double *gpose;  // optional [B][n_points][12]: end-effector reference of every sample (otherwise the pose of the sample's q)
   double w_q[AGX_MAX_NV], w_qdot[AGX_MAX_NV], w_effort[AGX_MAX_NV], w_pose[6];
   double dt;
   int n_points, frame;
@@ -1784,6 +1847,12 @@ AGX_UNROLL_NV
   double RF[9], pF[3];
   int jf;
   frame_world<NV>(m, k, sp.frame, RF, pF, &jf);
+  if (sp.gpose) {
+#pragma unroll
+    for (int e = 0; e < 9; ++e) RF[e] = sp.gpose[unit * 12 + e];
+#pragma unroll
+    for (int e = 0; e < 3; ++e) pF[e] = sp.gpose[unit * 12 + 9 + e];
+  }
   double *pt = pts + unit * (4 * NV + 12);
 AGX_UNROLL_NV
   for (int i = 0; i < NV; ++i) { pt[i] = q[i]; pt[NV + i] = dq[i]; pt[2 * NV + i] = ddq[i]; pt[3 * NV + i] = u[i]; }

@@ -72,9 +72,9 @@ __device__ __forceinline__ void riccati_mx_body(const int b, const DevOcp *__res
   DevState &S = st[b];
   // which instances sweep: as riccati_body
   if (!GAINS && (S.done || S.admm_conv)) return;
-  if (GAINS && gmode == 1 && S.done) return;
+  if (GAINS && (gmode == 1 || gmode == 4) && S.done) return;  // gmode 4: see riccati_body
   if (GAINS && gmode == 2 && S.gains_iter == S.dir_iter) return;
-  const double dreg = (GAINS && gmode != 1) ? (S.solved ? S.dreg : S.gains_dreg) : S.dreg;
+  const double dreg = (GAINS && gmode != 1 && gmode != 4) ? (S.solved ? S.dreg : S.gains_dreg) : S.dreg;
   if (GAINS && gmode != 0 && lane == 0) S.gains_iter = (gmode == 1) ? iter : S.dir_iter;
   const double sig = GAINS ? kSigma : 0.0;
   const double *qb = qts + (long long)b * (T + 1) * TS;

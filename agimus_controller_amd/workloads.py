@@ -192,7 +192,7 @@ def _log6_batch(R, p):
 
 
 def cartesian_sine_batch_arrays(dyn, frame: int, n_points: int, dt: float, q0, amp_xyz, pulsation, scale_duration=0.2,
-                                precision=1e-5, it_max=200):
+                                precision=1e-5, it_max=10000):
     """q, dq, ddq [B][n_points][nv] of B sine_wave_cartesian_space trajectories
     (trajectories/sine_wave_cartesian_space.py:62-111 upstream; tests/test_sin_wave_cartesian_space.py:58-62
     for the parameters): the end effector `frame` follows  p0 + A s(t) sin(w t)  with the initial
@@ -218,7 +218,7 @@ def cartesian_sine_batch_arrays(dyn, frame: int, n_points: int, dt: float, q0, a
         des_v = np.zeros((B, 6))
         des_v[:, :3] = amp * (dquint * np.sin(w * t) + quint * w * np.cos(w * t))
         active = np.arange(B)
-        for it in range(it_max + 1):
+        for it in range(it_max + 2):
             P = dyn.frame_placement(frame, q[active])
             R, pp = P[:, :9].reshape(-1, 3, 3), P[:, 9:]
             Ra = R0[active]
@@ -229,7 +229,7 @@ def cartesian_sine_batch_arrays(dyn, frame: int, n_points: int, dt: float, q0, a
             active, err = active[keep], err[keep]
             if active.size == 0:
                 break
-            if it == it_max:
+            if it > it_max:  # upstream: `if i > it_max: break` after the convergence test
                 raise RuntimeError(f"inverse kinematics failed to converge for instances {active.tolist()} at point {i}")
             J = dyn.frame_jacobian(frame, q[active], local=True)
             JJt = np.einsum("nij,nkj->nik", J, J)

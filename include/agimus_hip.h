@@ -190,9 +190,9 @@ int agx_ocp_set_geom_placement(agx_ocp *ocp, int frame, const double *se3);
 /* Batch policy -- no counterpart upstream, where every controller is its own process (mpc.py:14-19) and a slow solve
  * delays only itself.  In a batch the SQP loop of one step runs until EVERY instance has finished; with a quorum
  * below 1 it ends as soon as that fraction has, and the ADMM loop of an SQP iteration as soon as that fraction of
- * the QPs has converged.  The remaining instances keep their current iterate and report solved = 0 (qp_iters =
- * max_qp_iters): exactly what a lone controller returns when it runs into max_iter / max_solve_time
- * (ocp_base_croco.py:160-171); the next MPC step continues from that iterate through the warm-start shift.
+ * the QPs has converged.  The remaining instances keep their current iterate and report solved = 0 with the SQP /
+ * ADMM iterations they really ran (iter, qp_iters): what a lone controller returns when it runs into max_iter /
+ * max_solve_time (ocp_base_croco.py:160-171); the next MPC step continues from that iterate through the warm-start shift.
  * Defaults 1.0 / 1.0: wait for everyone.                                            */
 int agx_ocp_set_quorum(agx_ocp *ocp, double sqp_fraction, double qp_fraction);
 /* Constrained problems keep the ADMM multipliers y and the penalty rho between solves, as the
@@ -306,8 +306,10 @@ int agx_traj_generic_create(agx_ocp *ocp, int n_points, const double *q, const d
  * trajectories/sine_wave_cartesian_space.py:62-111): the end effector `frame` of instance b follows
  * p0_b + amp_b s(t) sin(pulsation_b t) with its initial orientation (s: the quintic of scale_duration);
  * q by the iterative inverse kinematics on the device (warm-started point to point, all six error components,
- * stop at |log6| < precision, error after it_max steps), dq from the LOCAL_WORLD_ALIGNED Jacobian, ddq = 0.
- * q0 [B][nv], amp / pulsation [B][3].  nv <= 7.                                     */
+ * stop at |log6| < precision, error once more than it_max steps were taken -- upstream's `if i > it_max`, default 10000),
+ * dq from the LOCAL_WORLD_ALIGNED Jacobian, ddq = 0.  The end-effector reference of a point is the DESIRED pose
+ * (initial orientation, p0 + amp s sin), as upstream stores ee_des_pos.  On an inverse-kinematics failure the call
+ * returns an error and the handle is left WITHOUT a resident trajectory.  q0 [B][nv], amp / pulsation [B][3].  nv <= 7. */
 int agx_traj_cartesian_sine_create(agx_ocp *ocp, int n_points, double dt, const double *q0, const double *amp,
                                    const double *pulsation, double scale_duration, double precision, int it_max,
                                    const double *w_q, const double *w_qdot, const double *w_effort, const double *w_pose,

@@ -441,26 +441,40 @@ def test_hip_breakdown_of_the_factorisation_is_handled_like_the_checker():
     from agimus_controller_amd import backend
 
     table, po, ref, x0, xs, us, B = _obstacle_entering_problem()
-    for iters in (2, 10):
+    merit_h = {}
+    for iters in (2, 7, 8, 10):
         r_o = _oracle(table, po, B).solve(ref, None, x0, xs, us, iters)
         hb = backend.HipOcp(table, po, B)
         hb.set_refs(ref)
         r_h = hb.solve(x0, xs, us, iters)
         hb.close()
+        # the discrete path is the same in every phase: iterations, QP iterations, discarded-direction / rejected-step flags
         assert np.array_equal(r_h[3]["iter"], r_o[3]["iter"]) and np.array_equal(r_h[3]["qp_iters"], r_o[3]["qp_iters"])
         assert np.array_equal(r_h[3]["flags"], r_o[3]["flags"])
-        # The recovery after the breakdown (regularisation 1e-9 -> 1e0 over rejected steps, 100 ADMM iterations on a nearly
-        # singular QP) amplifies round-off: the checker built with AVX2 and with AVX-512 vectorisation differs from itself by
-        # 2e-2 relative in the KKT value and 8e-3 in xs after the 10 iterations (measured, same source).  The first phase
-        # (2 iterations: discarded direction, rejected step) is exact.
-        loose = iters == 10
-        np.testing.assert_allclose(r_h[3]["kkt"], r_o[3]["kkt"], rtol=5e-2 if loose else 1e-5, atol=1e-8, equal_nan=True)
-        np.testing.assert_allclose(r_h[0], r_o[0], rtol=1e-6, atol=3e-2 if loose else 1e-7)
-        np.testing.assert_allclose(r_h[1], r_o[1], rtol=1e-5, atol=1e-1 if loose else 1e-5)
-        if iters == 2:
-            assert r_o[3]["flags"][0] == 3 and np.array_equal(r_o[0][0], xs[0])  # discarded direction, rejected step
+        merit_h[iters] = r_h[3]["merit"].copy()
+        if iters <= 7:
+            # deterministic phase (the checker's trace: directions discarded and steps rejected while the regularisation climbs
+            # 1e-9 -> 1e-2; the first accepted step comes in iteration 8): exact
+            np.testing.assert_allclose(r_h[3]["kkt"], r_o[3]["kkt"], rtol=1e-5, atol=1e-8, equal_nan=True)
+            np.testing.assert_allclose(r_h[3]["merit"], r_o[3]["merit"], rtol=1e-9)
+            np.testing.assert_allclose(r_h[0], r_o[0], rtol=1e-6, atol=1e-7)
+            np.testing.assert_allclose(r_h[1], r_o[1], rtol=1e-5, atol=1e-5)
+            assert r_o[3]["flags"][0] == 3 and np.array_equal(r_o[0][0], xs[0]) and np.array_equal(r_h[0][0], xs[0])
         else:
-            assert r_o[3]["qp_iters"][0] > 1 and not np.array_equal(r_o[0][0], xs[0])  # it got going again
+            # The recovery (100 ADMM iterations on a nearly singular QP) amplifies round-off: the checker built with AVX2 and
+            # with AVX-512 vectorisation differs from itself by 2e-2 relative in the KKT value and 8e-3 in xs after the 10
+            # iterations (measured, same source).  Values are therefore compared loosely here and the path is pinned by
+            # invariants instead: same discrete path (above), x0 pinned, finite iterates, and a merit that never increases
+            # along the accepted steps and agrees with the checker's.
+            assert r_o[3]["qp_iters"][0] > 1 and not np.array_equal(r_o[0][0], xs[0]) and not np.array_equal(r_h[0][0], xs[0])
+            np.testing.assert_allclose(r_h[3]["kkt"], r_o[3]["kkt"], rtol=5e-2, atol=1e-8, equal_nan=True)
+            np.testing.assert_allclose(r_h[3]["merit"], r_o[3]["merit"], rtol=5e-2)
+            np.testing.assert_allclose(r_h[0], r_o[0], rtol=1e-6, atol=3e-2)
+            np.testing.assert_allclose(r_h[1], r_o[1], rtol=1e-5, atol=1e-1)
+            np.testing.assert_array_equal(r_h[0][:, 0], x0)
+            assert np.all(np.isfinite(r_h[0])) and np.all(np.isfinite(r_h[1]))
+    # merit of the point each run stopped at (evaluated at its last SQP iteration): non-increasing once steps are accepted
+    assert np.all(merit_h[10] <= merit_h[8] * (1 + 1e-12)) and np.all(merit_h[8] <= merit_h[7] * (1 + 1e-12))
     assert np.all(np.isfinite(r_h[2]))
 
 

@@ -129,16 +129,26 @@ def test_device_generator_matches_the_lockstep_inverse_kinematics(dyn):
     running, terminal = workloads.goal_reaching_rows(tcp)
     hip = backend.HipOcp(table, _abi.PackedOcp(table.nv, [dt] * T, running, terminal), B)
     hip.cartesian_sine_trajectory(n, dt, q0, amp, puls, 1.0, 0.1, 3e-4, 0.1, tcp)
+    P0 = dyn.frame_placement(tcp, q0)
     for k in (0, 1, 7, 23, n - 1):
         q, v, a, u, pose = hip.traj_point(k)
         np.testing.assert_allclose(q, qs[:, k], atol=1e-9)
         np.testing.assert_allclose(v, dqs[:, k], atol=1e-8)
         assert not np.any(a)
-        # the pose reference of the point is the end effector at q: the sine in x / y, constant z for instance 0
-        np.testing.assert_allclose(pose[:, 9:], dyn.frame_placement(tcp, q)[:, 9:], atol=1e-12)
+        # the pose reference of the point is the DESIRED pose ee_des_pos (sine_wave_cartesian_space.py:126-133 upstream): the initial
+        # orientation and p0 + amp s(t) sin(w t) -- the pose at the inverse-kinematics solution differs by up to `precision`
+        t = k * dt
+        s = min(max(t / 0.2, 0.0), 1.0)
+        quint = 10 * s**3 - 15 * s**4 + 6 * s**5
+        np.testing.assert_allclose(pose[:, 9:], P0[:, 9:] + amp * quint * np.sin(puls * t), atol=1e-13)
+        np.testing.assert_allclose(pose[:, :9], P0[:, :9], atol=1e-15)
+        assert np.all(np.linalg.norm(pose[:, 9:] - dyn.frame_placement(tcp, q)[:, 9:], axis=1) < 1e-5)
     # an unreachable target is reported, not returned
     far = amp.copy()
     far[2] = [5.0, 0.0, 0.0]
     with pytest.raises(backend.HipError, match="inverse kinematics failed to converge: instance 2"):
         hip.cartesian_sine_trajectory(n, dt, q0, far, puls, 1.0, 0.1, 3e-4, 0.1, tcp, it_max=50)
+    # ... and leaves no half-built trajectory behind for a later MPC step to consume
+    with pytest.raises(backend.HipError, match="no resident trajectory"):
+        hip.set_window(0)
     hip.close()
