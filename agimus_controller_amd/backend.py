@@ -30,7 +30,8 @@ EXPORTED_SYMBOLS = [
     "agx_model_frame_placement", "agx_ocp_get_residuals", "agx_ocp_calc_diff", "agx_ocp_direction",
     "agx_ocp_time_kernel", "agx_ocp_profile", "agx_traj_sine_create", "agx_traj_set_window",
     "agx_traj_get_point", "agx_traj_warmstart_from_reference", "agx_ocp_mpc_step", "agx_ocp_qp_tiles", "agx_ocp_set_quorum",
-    "agx_traj_cartesian_sine_create",
+    "agx_traj_cartesian_sine_create", "agx_ocp_set_refs_async", "agx_ocp_refs_activate", "agx_ocp_refs_wait", "agx_host_alloc", "agx_host_free",
+    "agx_ocp_download_async", "agx_ocp_download_wait",
 ]  # fmt: skip
 
 
@@ -120,6 +121,41 @@ class HipError(RuntimeError):
     pass
 
 
+class _PinnedBlock:
+    """Owner of one page-locked allocation (agx_host_alloc); freed with the last array that views it."""
+
+    def __init__(self, nbytes: int):
+        self.ptr = C.c_void_p()
+        lib().agx_host_alloc.argtypes = [C.c_size_t, C.POINTER(C.c_void_p)]
+        if lib().agx_host_alloc(C.c_size_t(nbytes), C.byref(self.ptr)) != 0:
+            raise HipError(lib().agx_last_error().decode())
+        self.buf = (C.c_char * nbytes).from_address(self.ptr.value)
+
+    def __del__(self):
+        try:
+            lib().agx_host_free.argtypes = [C.c_void_p]
+            lib().agx_host_free(self.ptr)
+        except Exception:  # noqa: BLE001  (interpreter shutdown)
+            pass
+
+
+def pinned_array(shape, dtype=np.float64) -> np.ndarray:
+    """numpy array over page-locked host memory: transfers to and from it run at the rate of the link and asynchronously."""
+    dtype = np.dtype(dtype)
+    n = int(np.prod(shape))
+    block = _PinnedBlock(max(n * dtype.itemsize, 1))
+    arr = np.frombuffer(block.buf, dtype=dtype, count=n).reshape(shape)
+    arr.flags.writeable = True
+    _PINNED[id(block)] = block  # np.frombuffer keeps block.buf alive, not the block: tie the block's life to the array's
+    import weakref
+
+    weakref.finalize(arr.base if arr.base is not None else arr, _PINNED.pop, id(block), None)
+    return arr
+
+
+_PINNED: dict = {}
+
+
 def _chk(rc):
     if rc != 0:
         raise HipError(lib().agx_last_error().decode())
@@ -170,6 +206,35 @@ class HipOcp:
             fr = np.ascontiguousarray(frames, dtype=np.int32)
             assert fr.shape == (self.B, self.T + 1, _abi.AGX_MAX_ROWS)
         _chk(lib().agx_ocp_set_refs(self._h, _p(ref), _p(fr)))
+
+    def set_refs_async(self, ref_tile, frames=None):
+        """Stages a tile (ideally a `pinned_array`): a second stream copies it while the solver still works on the current one;
+        refs_activate() swaps it in.  Keep the buffer untouched until the solve after its activation has returned."""
+        ref = np.asarray(ref_tile)
+        assert ref.dtype == np.float64 and ref.flags.c_contiguous and ref.shape == (self.B, self.T + 1, self.stride)
+        fr = None
+        if frames is not None:
+            fr = np.asarray(frames)
+            assert fr.dtype == np.int32 and fr.flags.c_contiguous and fr.shape == (self.B, self.T + 1, _abi.AGX_MAX_ROWS)
+        self._async_keep = (ref, fr)  # the copy reads the buffers after this call returns
+        _chk(lib().agx_ocp_set_refs_async(self._h, _p(ref), _p(fr)))
+
+    def refs_wait(self):
+        _chk(lib().agx_ocp_refs_wait(self._h))
+
+    def refs_activate(self):
+        """The tile staged by set_refs_async becomes the current one (device-side wait, no host stall)."""
+        _chk(lib().agx_ocp_refs_activate(self._h))
+
+    def download_async(self, xs=None, us=None, K=None):
+        """Full results into caller-owned arrays (ideally `pinned_array`s) behind the solver's back: complete after download_wait()."""
+        for a, shape in ((xs, (self.B, self.T + 1, self.nx)), (us, (self.B, self.T, self.nu)), (K, (self.B, self.T, self.nu, self.nx))):
+            assert a is None or (a.dtype == np.float64 and a.flags.c_contiguous and a.shape == shape)
+        self._dl_keep = (xs, us, K)
+        _chk(lib().agx_ocp_download_async(self._h, _p(xs), _p(us), _p(K)))
+
+    def download_wait(self):
+        _chk(lib().agx_ocp_download_wait(self._h))
 
     def set_stream(self, raw_stream: int):
         _chk(lib().agx_ocp_set_stream(self._h, C.c_void_p(raw_stream)))

@@ -81,6 +81,16 @@ struct agx_ocp {
   double quorum_sqp = 1.0, quorum_qp = 1.0;
   bool queue_ahead = true;  // AGX_QUEUE_AHEAD=0: next derivative pass only after the host saw the finished count (profiling: no empty launches)
   double *d_ref = nullptr;  // owned tile [B][T+1][stride]
+  // asynchronous reference upload (agx_ocp_set_refs_async): second tile / frame table filled by the copy stream while the
+  // solver works on the first; the next solve waits for the copy's event and swaps the two
+  double *d_ref_back = nullptr;
+  int *d_frames_back = nullptr;
+  bool refs_pending = false, refs_pending_frames = false;
+  hipStream_t copy_stream = nullptr;
+  hipEvent_t ev_refs = nullptr, ev_snap = nullptr, ev_dl = nullptr;
+  // asynchronous result download (agx_ocp_download_async): device-side snapshot of xs | us | K taken in the solver's stream
+  double *d_snap = nullptr;
+  bool dl_pending = false;
   int *d_frames = nullptr;  // owned [B][T+1][AGX_MAX_ROWS]
   bool frames_set = false;
   DevState *d_state = nullptr;
@@ -91,7 +101,7 @@ struct agx_ocp {
   unsigned long long *h_ndone = nullptr;
   unsigned long long *h_ndone_dev = nullptr;  // the same words as the device sees them (mapped host memory)
   unsigned long long seq = 0;
-  unsigned ls_handed = 0;  // last value seen of the device counter of handed-on line-search trials (d_ndone[3], never reset)
+  unsigned ls_handed = 0, ls_stale = 0;  // last values seen of the device counters of handed-on line-search trials / iterations ended with stale tiles (d_ndone[3], [4]; never reset)
   bool poll = true;  // AGX_HOST_POLL=0: stream-ordered copies + synchronize instead of polled mapped words
   double *d_first = nullptr, *h_first = nullptr;  // packed first-node results [B][first_stride], device / pinned host
   int first_stride = 0;
@@ -620,12 +630,36 @@ int admm_direction(agx_ocp *o, bool prefactor = false) {
   });
 }
 
+// agx_ocp_refs_activate: the tile staged by agx_ocp_set_refs_async becomes the solver's tile -- the solver's stream waits
+// for the copy (no host wait) and the two device tiles swap roles.
+int adopt_pending_refs(agx_ocp *o) {
+  if (!o->refs_pending) return 0;
+  HIPCHK(hipStreamWaitEvent(o->stream, o->ev_refs, 0));
+  std::swap(o->d_ref, o->d_ref_back);
+  if (o->refs_pending_frames) std::swap(o->d_frames, o->d_frames_back);
+  o->rv.base = o->d_ref;
+  o->rv.bstride = (long long)(o->T + 1) * o->stride;
+  o->rv.tstride = o->stride;
+  o->rv.term_off = 0;
+  o->rv.frames = o->refs_pending_frames ? o->d_frames : nullptr;
+  o->refs_pending = false;
+  return 0;
+}
+int ensure_copy_stream(agx_ocp *o) {
+  if (o->copy_stream) return 0;
+  HIPCHK(hipStreamCreateWithFlags(&o->copy_stream, hipStreamNonBlocking));
+  HIPCHK(hipEventCreateWithFlags(&o->ev_refs, hipEventDisableTiming));
+  HIPCHK(hipEventCreateWithFlags(&o->ev_snap, hipEventDisableTiming));
+  HIPCHK(hipEventCreateWithFlags(&o->ev_dl, hipEventDisableTiming));
+  return 0;
+}
+
 // Trial rounds of the line search of SQP iteration `it` (nv <= 7; k_sqp_head has written the first trial iterate):
 // derivative pass (+ constraint evaluation) at the trial points, k_sqp_accept, and -- only while the counter of handed-on
-// trials grows, i.e. when somebody rejected a step length -- the same again.  The finished-instance count comes back with
-// the same stamp.  `queue_k1`: enqueue the next iteration's derivative pass before waiting (it skips every instance whose
-// tiles came out of an accepted trial: normally an empty launch, real work only after a rejected iteration).
-int line_search_rounds(agx_ocp *o, int it, int max_iter, bool queue_k1, bool *k1_queued, int *n_done_out) {
+// trials grows, i.e. when somebody rejected a step length -- the same again.  The finished-instance count comes back
+// under the same stamp, and so does the counter of iterations that ended with every trial rejected: only then does the
+// next iteration need a derivative pass of its own (`need_k1`); after an accepted trial the tiles are already there.
+int line_search_rounds(agx_ocp *o, int it, int max_iter, bool *need_k1, int *n_done_out) {
   double *xs_t = o->d_xs + (size_t)o->B * (o->T + 1) * o->nx, *us_t = o->d_us + (size_t)o->B * o->T * o->nu;
   for (int round = 0; round < 10; ++round) {
     if (o->prof && round == 0) {  // the kernel the roofline is quoted on, timed alone: running nodes of the trial pass
@@ -653,30 +687,27 @@ int line_search_rounds(agx_ocp *o, int it, int max_iter, bool queue_k1, bool *k1
       }
     });
     if (rc) return rc;
-    // finished instances + handed-on trials under one stamp
     const unsigned long long seq = ++o->seq;
     if (o->poll) {
-      hipLaunchKernelGGL(agx::k_publish2, dim3(1), dim3(1), 0, o->stream, o->d_ndone, o->d_ndone + 3, o->h_ndone_dev + 0, o->h_ndone_dev + 6,
+      hipLaunchKernelGGL(agx::k_publish3, dim3(1), dim3(1), 0, o->stream, o->d_ndone, o->h_ndone_dev + 0, o->h_ndone_dev + 6, o->h_ndone_dev + 7,
                          o->h_ndone_dev + 1, seq);
       HIPCHK(hipGetLastError());
+      if (wait_stamp(o, 1, seq)) return -1;
     } else {
-      o->h_ndone[0] = 0; o->h_ndone[6] = 0;
+      o->h_ndone[0] = 0; o->h_ndone[6] = 0; o->h_ndone[7] = 0;
       HIPCHK(hipMemcpyAsync(o->h_ndone, o->d_ndone, sizeof(int), hipMemcpyDeviceToHost, o->stream));
       HIPCHK(hipMemcpyAsync(o->h_ndone + 6, o->d_ndone + 3, sizeof(int), hipMemcpyDeviceToHost, o->stream));
-      HIPCHK(hipEventRecord(o->ev_done, o->stream));
+      HIPCHK(hipMemcpyAsync(o->h_ndone + 7, o->d_ndone + 4, sizeof(int), hipMemcpyDeviceToHost, o->stream));
+      HIPCHK(hipStreamSynchronize(o->stream));
     }
-    if (queue_k1 && round == 0 && it + 1 < max_iter) {
-      if (launch_calc_qp(o, false, false, 0)) return -1;
-      *k1_queued = true;
-    }
-    if (o->poll) { if (wait_stamp(o, 1, seq)) return -1; }
-    else HIPCHK(hipEventSynchronize(o->ev_done));
     *n_done_out = (int)__atomic_load_n(o->h_ndone, __ATOMIC_ACQUIRE);
     const unsigned handed = (unsigned)__atomic_load_n(o->h_ndone + 6, __ATOMIC_ACQUIRE);
+    const unsigned stale = (unsigned)__atomic_load_n(o->h_ndone + 7, __ATOMIC_ACQUIRE);
     const bool more = handed != o->ls_handed;
+    if (stale != o->ls_stale) *need_k1 = true;
     o->ls_handed = handed;
+    o->ls_stale = stale;
     if (!more) break;
-    *k1_queued = false;  // an instance may end this iteration with every trial rejected: its tiles are stale after the pass queued above
   }
   return 0;
 }
@@ -693,8 +724,9 @@ int solve_resident(agx_ocp *o, int max_iter, double max_time, bool prologue_done
   const bool small = o->nv <= 7;  // line search by derivative passes at the trial points (k_sqp_head / k_sqp_accept)
   // Large models: the derivative pass of iteration it+1 is enqueued BEFORE the host waits for iteration it's "everyone
   // finished" word (it skips finished instances).  nv <= 7: the same for the pass that only instances with stale tiles need.
-  const bool ahead = o->queue_ahead && !o->prof && max_time <= 0.0;
+  const bool ahead = o->queue_ahead && !o->prof && max_time <= 0.0 && !small;
   bool k1_queued = false;
+  bool need_k1 = true;  // nv <= 7: the first iteration, and iterations after one that ended with every trial rejected
   // the exit fix-up of the gains is launched only if an instance can have finished (or the loop can
   // have ended) in an iteration whose direction sweep was not paired with the gains sweep
   bool need_fixup = false;
@@ -703,7 +735,7 @@ int solve_resident(agx_ocp *o, int max_iter, double max_time, bool prologue_done
     const bool pair = o->speculate && it >= 1 && !o->has_con && o->nv <= 7;  // large models: gains only on exit
     // derivative pass: running and terminal nodes in one launch; under agx_ocp_profile the running
     // nodes get their own launch so that the kernel the roofline is quoted on is timed alone
-    if (!k1_queued) {
+    if (!k1_queued && (!small || need_k1)) {
       if (o->prof && (!small || it == 0)) {
         if (prof_mark(o, 0, true)) return -1;
         if (launch_calc_qp(o, true, false)) return -1;
@@ -712,6 +744,7 @@ int solve_resident(agx_ocp *o, int max_iter, double max_time, bool prologue_done
       } else if (launch_calc_qp(o, false, false)) return -1;
     }
     k1_queued = false;
+    need_k1 = false;
     if (prof_mark(o, 1, true)) return -1;
     // from the second iteration on (where warm-started MPC steps converge) the gains sweep rides along
     if (o->has_con && o->admm_prefactor && o->riccati_mx && o->nv <= 7 && !o->general) {
@@ -733,7 +766,7 @@ int solve_resident(agx_ocp *o, int max_iter, double max_time, bool prologue_done
       if (!pair && !o->has_con && (last || max_time > 0.0 || o->quorum_sqp < 1.0)) {
         if (launch_gains(o, 4)) return -1;
       }
-      if (line_search_rounds(o, it, max_iter, ahead && !last, &k1_queued, &n_done)) return -1;
+      if (line_search_rounds(o, it, max_iter, &need_k1, &n_done)) return -1;
       if (last) { need_fixup = need_fixup || !pair; break; }
     } else {
       if (last) { need_fixup = need_fixup || !pair; break; }
@@ -992,7 +1025,7 @@ int agx_ocp_create(const agx_model *m, const agx_ocp_desc *d, int batch, int dev
   ALLOC(o->d_ref, B * (T + 1) * (size_t)o->stride);
   ALLOC(o->d_frames, B * (T + 1) * AGX_MAX_ROWS);
   ALLOC(o->d_state, B);
-  ALLOC(o->d_ndone, 4);  // [0] finished instances, [1] instances whose ADMM loop has ended, [2] instances in the split line search
+  ALLOC(o->d_ndone, 8);  // [0] finished instances, [1] instances whose ADMM loop has ended, [2] instances in the split line search
   if (o->nv > 8) {
     for (int t = 0; t < o->T; ++t)
       if (o->dt[t] != o->dt[0]) o->shift_nodes.push_back(t);
@@ -1051,7 +1084,8 @@ void agx_ocp_destroy(agx_ocp *o) {
   if (!o) return;
   (void)hipSetDevice(o->device);
   if (o->stream) (void)hipStreamSynchronize(o->stream);
-  void *ptrs[] = {o->d_model, o->d_ocp, o->d_dt, o->d_xs, o->d_us, o->d_x0, o->d_tiles, o->d_Kws, o->d_kws, o->d_Kout, o->d_dx,
+  if (o->copy_stream) (void)hipStreamSynchronize(o->copy_stream);
+  void *ptrs[] = {o->d_ref_back, o->d_frames_back, o->d_snap, o->d_model, o->d_ocp, o->d_dt, o->d_xs, o->d_us, o->d_x0, o->d_tiles, o->d_Kws, o->d_kws, o->d_Kout, o->d_dx,
                   o->d_du, o->d_ref, o->d_frames, o->d_state, o->d_ndone, o->d_scratch, o->d_traj, o->d_pts, o->d_sine, o->d_qt, o->d_aux, o->d_w, o->d_nodestat,
                   o->d_qt2, o->d_cg, o->d_cjac, o->d_y, o->d_z, o->d_cx, o->d_admmstat, o->d_fac, o->d_hidx, o->d_trial, o->d_auxg, o->d_shift_nodes, o->d_segP, o->d_Kws_lqr, o->d_kws_lqr};
   for (void *p : ptrs)
@@ -1060,6 +1094,10 @@ void agx_ocp_destroy(agx_ocp *o) {
   if (o->ev0) (void)hipEventDestroy(o->ev0);
   if (o->ev1) (void)hipEventDestroy(o->ev1);
   if (o->ev_done) (void)hipEventDestroy(o->ev_done);
+  if (o->ev_refs) (void)hipEventDestroy(o->ev_refs);
+  if (o->ev_snap) (void)hipEventDestroy(o->ev_snap);
+  if (o->ev_dl) (void)hipEventDestroy(o->ev_dl);
+  if (o->copy_stream) (void)hipStreamDestroy(o->copy_stream);
   if (o->d_first && !o->poll) (void)hipFree(o->d_first);
   if (o->h_first) (void)hipHostFree(o->h_first);
   if (o->own_stream && o->stream) (void)hipStreamDestroy(o->stream);
@@ -1122,6 +1160,7 @@ int agx_ocp_set_geom_placement(agx_ocp *o, int frame, const double *se3) {
 int agx_ocp_set_refs(agx_ocp *o, const double *ref_tile, const int32_t *frame_ids) {
   if (!o || !ref_tile) return fail("agx_ocp_set_refs: null argument");
   if (set_device(o)) return -1;
+  if (o->refs_pending) { HIPCHK(hipEventSynchronize(o->ev_refs)); o->refs_pending = false; }  // superseded
   const size_t n = (size_t)o->B * (o->T + 1);
   HIPCHK(hipMemcpyAsync(o->d_ref, ref_tile, sizeof(double) * n * o->stride, hipMemcpyHostToDevice, o->stream));
   if (frame_ids) HIPCHK(hipMemcpyAsync(o->d_frames, frame_ids, sizeof(int) * n * AGX_MAX_ROWS, hipMemcpyHostToDevice, o->stream));
@@ -1150,6 +1189,73 @@ int agx_ocp_set_refs_device(agx_ocp *o, const double *d_ref_tile, const int32_t 
   o->rv.bstride = (long long)(o->T + 1) * o->stride;
   o->rv.tstride = o->stride;
   o->rv.term_off = 0;
+  return 0;
+}
+
+int agx_host_alloc(size_t bytes, void **out) {
+  if (!out || bytes == 0) return fail("agx_host_alloc: bad argument");
+  HIPCHK(hipHostMalloc(out, bytes, hipHostMallocDefault));
+  return 0;
+}
+int agx_host_free(void *p) {
+  if (p) HIPCHK(hipHostFree(p));
+  return 0;
+}
+
+int agx_ocp_set_refs_async(agx_ocp *o, const double *ref_tile, const int32_t *frame_ids) {
+  if (!o || !ref_tile) return fail("agx_ocp_set_refs_async: null argument");
+  if (set_device(o)) return -1;
+  if (ensure_copy_stream(o)) return -1;
+  const size_t n = (size_t)o->B * (o->T + 1);
+  if (!o->d_ref_back) HIPCHK(hipMalloc((void **)&o->d_ref_back, sizeof(double) * n * o->stride));
+  if (frame_ids && !o->d_frames_back) HIPCHK(hipMalloc((void **)&o->d_frames_back, sizeof(int) * n * AGX_MAX_ROWS));
+  if (o->refs_pending) HIPCHK(hipEventSynchronize(o->ev_refs));  // a second upload before any solve: replaces the first
+  // the back tile is free: the solve that read it has returned (solves are synchronous to the host)
+  HIPCHK(hipMemcpyAsync(o->d_ref_back, ref_tile, sizeof(double) * n * o->stride, hipMemcpyHostToDevice, o->copy_stream));
+  if (frame_ids) HIPCHK(hipMemcpyAsync(o->d_frames_back, frame_ids, sizeof(int) * n * AGX_MAX_ROWS, hipMemcpyHostToDevice, o->copy_stream));
+  HIPCHK(hipEventRecord(o->ev_refs, o->copy_stream));
+  o->refs_pending = true;
+  o->refs_pending_frames = frame_ids != nullptr;
+  return 0;
+}
+int agx_ocp_refs_wait(agx_ocp *o) {
+  if (!o) return fail("null handle");
+  if (o->refs_pending) HIPCHK(hipEventSynchronize(o->ev_refs));
+  return 0;
+}
+int agx_ocp_refs_activate(agx_ocp *o) {
+  if (!o) return fail("null handle");
+  if (!o->refs_pending) return fail("agx_ocp_refs_activate: no staged reference tile (agx_ocp_set_refs_async)");
+  if (set_device(o)) return -1;
+  return adopt_pending_refs(o);
+}
+
+int agx_ocp_download_async(agx_ocp *o, double *xs, double *us, double *K) {
+  if (!o) return fail("null handle");
+  if (set_device(o)) return -1;
+  if (ensure_copy_stream(o)) return -1;
+  const size_t B = o->B, T = o->T, nx = o->nx, nu = o->nu;
+  const size_t n_xs = B * (T + 1) * nx, n_us = B * T * nu, n_K = B * T * nu * nx;
+  if (!o->d_snap) HIPCHK(hipMalloc((void **)&o->d_snap, sizeof(double) * (n_xs + n_us + n_K)));
+  if (o->dl_pending) HIPCHK(hipEventSynchronize(o->ev_dl));  // the previous download still reads the snapshot
+  // snapshot in the solver's stream (device to device, ~0.1 ms for 100 MB), then the copy engine drains it while the
+  // solver goes on with the next step
+  if (xs) HIPCHK(hipMemcpyAsync(o->d_snap, o->d_xs, sizeof(double) * n_xs, hipMemcpyDeviceToDevice, o->stream));
+  if (us) HIPCHK(hipMemcpyAsync(o->d_snap + n_xs, o->d_us, sizeof(double) * n_us, hipMemcpyDeviceToDevice, o->stream));
+  if (K) HIPCHK(hipMemcpyAsync(o->d_snap + n_xs + n_us, o->d_Kout, sizeof(double) * n_K, hipMemcpyDeviceToDevice, o->stream));
+  HIPCHK(hipEventRecord(o->ev_snap, o->stream));
+  HIPCHK(hipStreamWaitEvent(o->copy_stream, o->ev_snap, 0));
+  if (xs) HIPCHK(hipMemcpyAsync(xs, o->d_snap, sizeof(double) * n_xs, hipMemcpyDeviceToHost, o->copy_stream));
+  if (us) HIPCHK(hipMemcpyAsync(us, o->d_snap + n_xs, sizeof(double) * n_us, hipMemcpyDeviceToHost, o->copy_stream));
+  if (K) HIPCHK(hipMemcpyAsync(K, o->d_snap + n_xs + n_us, sizeof(double) * n_K, hipMemcpyDeviceToHost, o->copy_stream));
+  HIPCHK(hipEventRecord(o->ev_dl, o->copy_stream));
+  o->dl_pending = true;
+  return 0;
+}
+int agx_ocp_download_wait(agx_ocp *o) {
+  if (!o) return fail("null handle");
+  if (o->dl_pending) HIPCHK(hipEventSynchronize(o->ev_dl));
+  o->dl_pending = false;
   return 0;
 }
 

@@ -1053,6 +1053,8 @@ __device__ __forceinline__ void sqp_iteration_end(DevState &S, bool ok, double u
     atomicAdd(n_done, 1);
   } else if (iter + 1 == max_iter) {
     S.iter = max_iter;
+  } else if (!ok) {
+    atomicAdd(n_done + 4, 1);  // never reset: the next iteration needs a derivative pass at the unchanged iterate (the host follows the growth)
   }
 }
 // trial iterate of step length alpha into the staging halves of xs / us (behind the B instances of the live buffers)
@@ -1260,11 +1262,12 @@ __global__ void k_reset_state(DevState *st, int B, int *n_done) {
   st[b] = s;
 }
 
-// two words under one stamp
-__global__ void k_publish2(const int *__restrict__ d_value0, const int *__restrict__ d_value1, unsigned long long *host_value0,
-                           unsigned long long *host_value1, unsigned long long *host_seq, unsigned long long seq) {
-  __hip_atomic_store(host_value0, (unsigned long long)(unsigned)*d_value0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-  __hip_atomic_store(host_value1, (unsigned long long)(unsigned)*d_value1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+// three words under one stamp: finished instances, line-search trials handed on, iterations ended with stale tiles
+__global__ void k_publish3(const int *__restrict__ d_counts, unsigned long long *host_done, unsigned long long *host_handed,
+                           unsigned long long *host_stale, unsigned long long *host_seq, unsigned long long seq) {
+  __hip_atomic_store(host_done, (unsigned long long)(unsigned)d_counts[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  __hip_atomic_store(host_handed, (unsigned long long)(unsigned)d_counts[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  __hip_atomic_store(host_stale, (unsigned long long)(unsigned)d_counts[4], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   __threadfence_system();
   __hip_atomic_store(host_seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }

@@ -58,6 +58,25 @@ def ncores():
     return len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
 
 
+def cpu_quota():
+    """CPU time the container may use, in cores (cgroup v2 cpu.max / v1 cfs quota); None = unlimited.  The affinity mask of a
+    GPU box shows every hardware thread of the host, the quota is what the process really gets."""
+    try:
+        txt = pathlib.Path("/sys/fs/cgroup/cpu.max").read_text().split()
+        if txt[0] != "max":
+            return float(txt[0]) / float(txt[1])
+    except Exception:  # noqa: BLE001
+        pass
+    try:
+        q = float(pathlib.Path("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read_text())
+        per = float(pathlib.Path("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read_text())
+        if q > 0:
+            return q / per
+    except Exception:  # noqa: BLE001
+        pass
+    return None
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -80,6 +99,10 @@ def parse():
     ap.add_argument("--loop", choices=("prediction", "feedback"), default="prediction",
                     help="how the next measured state is produced: previous xs[1] (the reference's dummy_mpc_test) or the Riccati "
                          "feedback law rolled out on the model at 1 kHz (SURVEY 8(f-3))")
+    ap.add_argument("--disturb-sigma", type=float, default=0.02,
+                    help="disturbed leg: the measured state of every step is the predicted one + N(0, sigma^2) rad on the joint positions and "
+                         "N(0, (5 sigma)^2) rad/s on the velocities (seeded per instance and step), so that steps need several SQP iterations "
+                         "and the line search backtracks")
     ap.add_argument("--workload", choices=("sine", "generic", "humanoid", "collision", "cartesian"), default="sine",
                     help="sine: BASELINE configs[1] at batch 1024 (the headline); generic: configs[3] generic_trajectory + pick-and-place costs; "
                          "humanoid: configs[4] synthetic 30-DoF tree (T 50, B 512); collision / cartesian: configs[2], collision-avoidance cost "
@@ -169,15 +192,26 @@ class HostRefs:
         sub.run, sub.term, sub.x, sub.u = self.run[:n], self.term[:n], self.x[:n], self.u[:n]
         return sub
 
-    def window(self, k0, out=None):
+    def window(self, k0, out=None, lo=0, hi=None):
+        """Horizon window starting at sample k0 (instances lo:hi) in the tile layout of agx_ocp_set_refs."""
         T = self.T
         out = np.empty((self.run.shape[0], T + 1, self.po.stride)) if out is None else out
-        out[:, :T] = self.run[:, k0:k0 + T]
-        out[:, T] = self.term[:, k0 + T]
+        out[lo:hi, :T] = self.run[lo:hi, k0:k0 + T]
+        out[lo:hi, T] = self.term[lo:hi, k0 + T]
         return out
 
 
-def _cpu_leg(args, table, po, refs: HostRefs, seconds, analytic):
+def disturbance_noise(B, n_steps, nv, sigma, seed0):
+    """[B][n_steps][2 nv] state noise of the disturbed leg: instance b draws from default_rng(977 + seed0 + b)."""
+    out = np.empty((B, n_steps, 2 * nv))
+    for b in range(B):
+        rng = np.random.default_rng(977 + seed0 + b)
+        out[b, :, :nv] = rng.normal(0.0, sigma, (n_steps, nv))
+        out[b, :, nv:] = rng.normal(0.0, 5.0 * sigma, (n_steps, nv))
+    return out
+
+
+def _cpu_leg(args, table, po, refs: HostRefs, seconds, analytic, noise=None):
     """One CPU leg: MPC loop of the first instances on the host cores (OpenMP over instances) + the same loop for one
     instance on one thread (the reference's default n_threads = 1, ocp_param_base.py:65).  None if the leg does not apply."""
     from oracle.oracle import Oracle  # test infrastructure: only the cpu_baseline leg of bench.py uses it
@@ -191,15 +225,16 @@ def _cpu_leg(args, table, po, refs: HostRefs, seconds, analytic):
     x0 = xs0[:, 0].copy()
     ref0 = refs.window(0)
     # thread count: the best of a few candidates on one untimed SQP iteration (big hosts oversubscribe easily)
-    best = None
-    for nt in sorted({min(avail, c) for c in (8, 16, 32, 64, avail)}):
-        o.solve(ref0, None, x0, xs0, us0, 1, nthreads=nt)  # thread pool / page warm-up
+    best, scan = None, {}
+    for nt in sorted({min(avail, c) for c in (1, 8, 16, 32, 64, avail)}):
+        o.solve(ref0, None, x0, xs0, us0, 1, nthreads=nt)  # thread pool / page warm-up (per-thread workspaces are first touched here)
         t0 = time.perf_counter()
         o.solve(ref0, None, x0, xs0, us0, 1, nthreads=nt)
         el = time.perf_counter() - t0
-        if best is None or el < best[0]:
+        scan[str(nt)] = round(el * 1e3, 3)
+        if nt > 1 and (best is None or el < best[0]):
             best = (el, nt)
-    cores = best[1]
+    cores = best[1] if best else 1
     o.reset_duals()
     n_max = refs.run.shape[1] - T - 1
     xs, us = xs0, us0
@@ -208,6 +243,8 @@ def _cpu_leg(args, table, po, refs: HostRefs, seconds, analytic):
     while n_steps < n_max and (n_steps < 2 or time.perf_counter() - t_start < seconds):
         if n_steps > 0:
             x0 = xs[:, 1].copy()
+            if noise is not None:
+                x0 += noise[:B, min(n_steps, noise.shape[1] - 1)]
             xs, us = o.shift_warmstart(xs, us)
         xs, us, K, st = o.solve(refs.window(n_steps), None, x0, xs, us, args.max_iter, nthreads=cores)
         iters.append(float(st["iter"].mean()))
@@ -236,6 +273,9 @@ def _cpu_leg(args, table, po, refs: HostRefs, seconds, analytic):
         "unit": "MPC steps/s",
         "cores": cores,
         "kind": "port-analytic" if analytic else "port-ad",
+        "cpu_quota_cores": cpu_quota(),  # cgroup limit of the container (None = none): what `cores` threads can really draw
+        "hardware_threads_visible": avail,
+        "thread_scan_ms": scan,  # one SQP iteration of the whole sample per thread count: how the host scales
         "sample": f"{B} instances x {n_steps} steps of the same workload (T={T}), OpenMP over instances; {what}; "
                   f"not the Crocoddyl/mim_solvers binaries; mean SQP iters {np.mean(iters):.2f}",
         "seconds": el,
@@ -255,6 +295,12 @@ def cpu_baseline(args, table, po, refs: HostRefs, seconds):
         ad["note"] = "constrained workload: only the automatic-differentiation checker covers the ADMM loop"
         return ad
     ana["port_ad"] = ad
+    if args.disturb_sigma > 0.0 and args.workload in ("sine", "generic"):
+        # the disturbed loop (same noise law) on the CPU: what the GPU leg `disturbed` is to be read against
+        nz = disturbance_noise(refs.run.shape[0], 64, po.nv, args.disturb_sigma, 1234)
+        dl = _cpu_leg(args, table, po, refs, seconds / 2.0, True, noise=nz)
+        if dl is not None:
+            ana["disturbed"] = {k: dl[k] for k in ("value", "unit", "cores", "sample", "seconds")}
     return ana
 
 
@@ -293,7 +339,7 @@ def main():
     hip = backend.HipOcp(table, po, B, device=local_rank)
     if args.quorum < 1.0:
         hip.set_quorum(args.quorum, args.quorum)
-    n_extra = 0 if args.no_batch1 else 64
+    n_extra = 0 if args.no_batch1 else 100
     n_points = args.warmup + args.steps + T + 2 + min(10, T // 2) + n_extra  # + in-situ profile steps + the extra legs
     # per-instance seeds follow the GLOBAL instance index so every rank works on different instances
     nv = table.nv
@@ -494,6 +540,37 @@ def main():
                                 "steps": int(len(lat)), "value": 1e3 / ms1, "unit": "MPC steps/s",
                                 "workload": "same, batch = 1 (BASELINE.json configs[1]); per-step host wall time incl. D2H"}
             h1.close()
+        if extra and args.workload in ("sine", "generic") and args.disturb_sigma > 0.0:
+            # Disturbed leg: closed loop on the prediction never leaves the easy path (one SQP iteration, alpha = 1).  Here the
+            # measured state is the predicted one plus seeded noise: several SQP iterations per step, rejected step lengths,
+            # the regularisation schedule at work -- the same loop, same noise, is timed on the CPU below.
+            nd = 24
+            noise = disturbance_noise(B, nd + 2, nv, args.disturb_sigma, seed0)
+            hist = np.zeros(args.max_iter + 1, dtype=np.int64)
+            flags_any = 0
+            x1 = np.array(hip.download_first(copy=True)[2])
+            for i in range(2):  # settle into the disturbed regime
+                hip.upload_x0(x1 + noise[:, i])
+                hip.mpc_step(k_next + i, args.max_iter, first=2)
+                x1 = np.array(hip.download_first(copy=False)[2])
+            hip.sync()
+            t1 = time.perf_counter()
+            for i in range(2, nd + 2):
+                hip.upload_x0(x1 + noise[:, i])
+                hip.mpc_step(k_next + i, args.max_iter, first=2)
+                _, _, x1v, std = hip.download_first(copy=False)
+                x1 = np.array(x1v)
+                hist += np.bincount(np.minimum(np.asarray(std["iter"]).astype(np.int64), args.max_iter), minlength=args.max_iter + 1)
+                flags_any += int(np.count_nonzero(np.asarray(std["flags"]).astype(np.int64) & 2))
+            hip.sync()
+            msd = (time.perf_counter() - t1) / nd * 1e3
+            k_next += nd + 2
+            result["disturbed"] = {"ms_per_step": msd, "value": B / (msd * 1e-3), "unit": "MPC steps/s", "sigma_q_rad": args.disturb_sigma,
+                                   "sigma_v_rad_s": 5 * args.disturb_sigma, "steps": nd,
+                                   "sqp_iter_histogram": hist.tolist(), "mean_sqp_iters": float((hist * np.arange(hist.size)).sum() / max(hist.sum(), 1)),
+                                   "steps_with_a_rejected_line_search": flags_any,
+                                   "note": "x0 of every step = predicted state + seeded Gaussian noise (uploaded from the host: 8 B nx bytes per "
+                                           "step inside the timed loop); statuses read every step"}
         if extra and args.max_iter != 3:
             # also the pick-and-place iteration cap (max_iter 3) on the same workload
             na = 8
@@ -530,17 +607,29 @@ def main():
                                      "note": "batch quorum 0.985 for the SQP and the ADMM loop; counts every instance of the batch as a step, "
                                              "solved or cut"}
         if extra:
-            # the same step with the FULL result download (xs, us, K of every node) into pageable memory
+            # the same step with the FULL result download (xs, us, K of every node): device-side snapshot in the
+            # solver's stream, drained into page-locked arrays by the copy stream while the next step is being solved
+            # (agx_ocp_download_async); every step's results are complete on the host before the step after next starts
+            nfull = 6
+            res = [tuple(backend.pinned_array(sh) for sh in ((B, T + 1, 2 * nv), (B, T, nv), (B, T, nv, 2 * nv))) for _ in range(2)]
+            hip.sync()
             t1 = time.perf_counter()
-            nfull = 3
-            for k in range(k_next, k_next + nfull):
+            for i, k in enumerate(range(k_next, k_next + nfull)):
                 hip.mpc_step(k, args.max_iter, first=False)
-                hip.download()
+                hip.download_wait()                 # results of step k - 1 (they travelled during this solve)
+                hip.download_async(*res[i % 2])
+            hip.download_wait()
             msf = (time.perf_counter() - t1) / nfull * 1e3
             k_next += nfull
+            nbytes = int(sum(a.nbytes for a in res[0]))
+            t2 = time.perf_counter()
+            hip.download_async(*res[0])
+            hip.download_wait()
+            d2h = nbytes / (time.perf_counter() - t2) / 1e9
             result["full_download"] = {"ms_per_step": msf, "value": B / (msf * 1e-3), "unit": "MPC steps/s",
-                                       "bytes_per_step": int(8 * B * ((T + 1) * 2 * nv + T * nv + T * 2 * nv * nv)),
-                                       "note": "PCIe-inclusive: xs, us, K of all nodes copied to host every step"}
+                                       "bytes_per_step": nbytes, "d2h_GBps_pinned": d2h,
+                                       "note": "PCIe-inclusive: xs, us, K of all nodes copied to page-locked host arrays every step "
+                                               "(agx_ocp_download_async: snapshot + copy stream, overlapped with the next solve)"}
     # ---- host_refs leg (the step as the reference's caller sees it): the reference tiles of every step come
     # from the host (agx_ocp_set_refs: H2D of [B][T+1][stride]), then shift + solve + download of the first-node results.
     # With N > 1 ranks the tiles of the whole job originate on rank 0 and travel through batched.scatter_rows (RCCL
@@ -550,32 +639,56 @@ def main():
     want_cpu = rank == 0 and world == 1 and not args.no_cpu_baseline
     refs = None
     if host_leg:
-        refs = HostRefs(hip, po, w, min(n_points, max(k_next + T + 8, T + 1 + 64)), B)
+        refs = HostRefs(hip, po, w, min(n_points, max(k_next + T + 16, T + 1 + 64)), B)
     elif want_cpu:
         refs = HostRefs(hip, po, w, min(n_points, T + 1 + 64), n_cpu)
     host_err = None
     if host_leg:
-        nh, n_glob = 5, (global_batch if args.scaling == "strong" else world * B)
-        tile = np.empty((B, T + 1, po.stride))
+        # Three page-locked host tiles in rotation: while step k is solved, the tile of step k+1 travels to the handle's second
+        # device tile on the copy stream (agx_ocp_set_refs_async) and the tile of step k+2 is assembled by worker threads
+        # (numpy copies and the solve call release the GIL).  An extra leg after the timed region: whatever happens in it, the
+        # measured line above is still printed.  A rank whose LOCAL work fails keeps taking part in the collectives of every step,
+        # so nobody is left waiting inside gather_rows / scatter_rows; the error flags are MAX-reduced after the leg.
+        import concurrent.futures as cf
+
+        nh, n_glob = 8, (global_batch if args.scaling == "strong" else world * B)
+        n_workers = max(1, min(8, ncores() - 1))
+        pool = cf.ThreadPoolExecutor(n_workers)
+        tiles = [backend.pinned_array((B, T + 1, po.stride)) for _ in range(3)]
+        cuts = np.linspace(0, B, n_workers + 1).astype(int)
+
+        def build(k, out):
+            return [pool.submit(refs.window, k, out, int(lo), int(hi)) for lo, hi in zip(cuts[:-1], cuts[1:]) if hi > lo]
+
+        def through_ranks(tile):  # N > 1: the tiles of the whole job originate on rank 0 (stands in for one generator process)
+            if world == 1:
+                return tile
+            full = batched.gather_rows(tile, n_glob, device=coll_dev)
+            tile[...] = batched.scatter_rows(full, n_glob, device=coll_dev)
+            return tile
+
+        try:
+            cf.wait(build(k_next, tiles[0]))
+            hip.set_refs_async(through_ranks(tiles[0]))
+            pending = build(k_next + 1, tiles[1])
+        except Exception as e:  # noqa: BLE001
+            host_err, pending = repr(e), []
         sync_all()
         t1 = time.perf_counter()
-        # An extra leg after the timed region: whatever happens in it, the measured line above is still printed.  A rank whose
-        # LOCAL work fails (HIP call, tile build) keeps taking part in the collectives of every step, so nobody is left waiting
-        # inside gather_rows / scatter_rows; the error flags are MAX-reduced after the leg and every rank takes the same branch.
-        for k in range(k_next, k_next + nh):
-            mine = tile
+        for i in range(nh):
+            first = np.zeros((B, nv + nv * 2 * nv + 2 * nv))
+            nxt = tiles[(i + 1) % 3]
             try:
                 if host_err is None:
-                    mine = refs.window(k, tile)
+                    hip.refs_activate()           # tile i, staged during step i - 1
+                    cf.wait(pending)
             except Exception as e:  # noqa: BLE001
                 host_err = repr(e)
-            if world > 1:
-                full = batched.gather_rows(mine, n_glob, device=coll_dev)   # (stands in for rank 0 owning the generator)
-                mine = batched.scatter_rows(full, n_glob, device=coll_dev)  # the scatter of the step's inputs
-            first = np.zeros((B, nv + nv * 2 * nv + 2 * nv))
+            nxt = through_ranks(nxt)
             try:
                 if host_err is None:
-                    hip.set_refs(mine)
+                    hip.set_refs_async(nxt)   # travels while step i is solved
+                    pending = build(k_next + i + 2, tiles[(i + 2) % 3])
                     hip.x0_from_prediction()
                     hip.shift_warmstart()
                     hip.solve_resident(args.max_iter)
@@ -592,13 +705,34 @@ def main():
                 host_err = "the leg failed on another rank"
         sync_all()
         msh = (time.perf_counter() - t1) / nh * 1e3
+        try:
+            cf.wait(pending)
+            hip.refs_wait()
+        except Exception:  # noqa: BLE001
+            pass
+        pool.shutdown()
+        # the upload alone (same tile, page-locked, nothing else running): the rate of the link
+        h2d = None
+        try:
+            if host_err is None:
+                hip.sync()
+                t2 = time.perf_counter()
+                for _ in range(3):
+                    hip.set_refs_async(tiles[0])
+                    hip.refs_wait()
+                h2d = tiles[0].nbytes * 3 / (time.perf_counter() - t2) / 1e9
+                hip.refs_activate()
+        except Exception:  # noqa: BLE001
+            h2d = None
+        k_next += nh + 2
         if rank == 0 and host_err is not None:
             result["host_refs"] = {"ms_per_step": None, "value": None, "unit": "MPC steps/s", "note": f"leg failed: {host_err}"}
         elif rank == 0:
             result["host_refs"] = {"ms_per_step": msh, "value": global_batch / (msh * 1e-3), "unit": "MPC steps/s",
-                                   "h2d_bytes_per_step_per_gpu": int(tile.nbytes),
-                                   "note": "PCIe-inclusive: reference tiles [B][T+1][stride] built on the host and uploaded every step "
-                                           "(agx_ocp_set_refs), shift, solve, first-node download"
+                                   "h2d_bytes_per_step_per_gpu": int(tiles[0].nbytes), "h2d_GBps_pinned": h2d, "host_threads": n_workers,
+                                   "note": "PCIe-inclusive: reference tiles [B][T+1][stride] assembled on the host every step in page-locked "
+                                           "memory and staged by agx_ocp_set_refs_async / agx_ocp_refs_activate (the tile of step k+1 "
+                                           "travels while step k is solved), shift, solve, first-node download"
                                            + ("; tiles scattered from / results gathered to rank 0 over RCCL" if world > 1 else "")}
     if rank == 0:
         if want_cpu:

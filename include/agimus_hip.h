@@ -24,6 +24,7 @@
 #ifndef AGIMUS_HIP_H
 #define AGIMUS_HIP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -204,6 +205,22 @@ int agx_ocp_reset_duals(agx_ocp *ocp);
  * (ocp_croco_generic.py:855-892): ref_tile [B][T+1][stride] host doubles,
  * frame_ids [B][T+1][AGX_MAX_ROWS] host int32 (NULL = row defaults).            */
 int agx_ocp_set_refs(agx_ocp *ocp, const double *ref_tile, const int32_t *frame_ids);
+/* The same update without stalling the caller or the solver (the reference pays ~ T x #costs binding calls per step for it,
+ * ocp_croco_generic.py:883-888), in two halves so that the tile of step k+1 can travel while step k is being solved:
+ *   agx_ocp_set_refs_async  STAGES a tile: a second stream copies it into the handle's second device tile (the solver
+ *                           keeps reading the first one); hand in page-locked memory (agx_host_alloc) and the copy runs
+ *                           at the rate of the link, concurrently with kernels;
+ *   agx_ocp_refs_activate   makes the staged tile the current one: the solver's stream waits for the copy (the host does
+ *                           not) and the two device tiles swap roles.
+ * Per step: activate (tile k, staged during step k-1), stage tile k+1, solve step k.  The host buffer of a staged tile must
+ * stay untouched until agx_ocp_refs_wait returns or the solve after its activation has returned.                          */
+int agx_ocp_set_refs_async(agx_ocp *ocp, const double *ref_tile, const int32_t *frame_ids);
+int agx_ocp_refs_activate(agx_ocp *ocp);
+int agx_ocp_refs_wait(agx_ocp *ocp);
+/* Page-locked host memory for the tiles and results handed to this library (a plain allocation works everywhere, but its
+ * transfers are staged by the runtime at a fraction of the link's rate).                                                */
+int agx_host_alloc(size_t bytes, void **out);
+int agx_host_free(void *p);
 /* Same with device-resident tiles (no copy of the doubles is made when
  * `adopt` != 0: the solver then reads the caller's buffer directly).            */
 int agx_ocp_set_refs_device(agx_ocp *ocp, const double *d_ref_tile, const int32_t *d_frame_ids, int adopt);
@@ -223,6 +240,11 @@ int agx_ocp_upload_x0(agx_ocp *ocp, const double *x0);
 int agx_ocp_upload_warmstart(agx_ocp *ocp, const double *xs_ws, const double *us_ws);
 int agx_ocp_solve_resident(agx_ocp *ocp, int max_iter, double max_time);
 int agx_ocp_download(agx_ocp *ocp, double *xs, double *us, double *K, agx_status *st);
+/* The full OCPResults (ocp_base_croco.py:173-177: xs, K, us of every node) without holding up the next step: a device-side
+ * snapshot is taken in the solver's stream and drained to the host by a second stream; the destination buffers (any may be
+ * NULL; page-locked memory from agx_host_alloc for the rate of the link) are complete when agx_ocp_download_wait returns.  */
+int agx_ocp_download_async(agx_ocp *ocp, double *xs, double *us, double *K);
+int agx_ocp_download_wait(agx_ocp *ocp);
 /* Only what the ROS node publishes (agimus_controller_ros/agimus_controller.py:418-426):
  * us0 [B][nu], K0 [B][nu][ndx], x1 [B][nx] (may be NULL).                      */
 int agx_ocp_download_first(agx_ocp *ocp, double *us0, double *K0, double *x1, agx_status *st);

@@ -1307,9 +1307,12 @@ bool direction_admm(int nv, int T, const double *tiles, const std::vector<ConNod
 // ---------------------------------------------------------------------------
 // SQP outer loop for one instance.
 // ---------------------------------------------------------------------------
+// Scratch of one solve.  The batch entry points keep ONE PER THREAD alive across instances and calls (thread_local):
+// a workspace built per instance maps and unmaps its half-megabyte vectors for every solve, and 64 threads doing that
+// at once queue up on the process's address-space lock (bench.py's CPU leg went 11 x on 64 threads).
 struct Workspace {
   std::vector<double> tiles, xs_try, us_try, xn, aug;
-  Direction dir;
+  Direction dir, dirK;
   NodeOut node;
   std::vector<ConNode> cn;
 };
@@ -1369,7 +1372,7 @@ void solve_one(const Model &m, const Ocp &o, const double *ref, const int32_t *f
   // th_stepdec 0.5, th_stepinc 0.01); sigma = 1e-6 is SolverCSQP's proximal weight.
   const double reg_min = 1e-9, reg_max = 1e9, sigma = 1e-6;
   double preg = reg_min, dreg = reg_min;
-  Direction dirK;
+  Direction &dirK = w.dirK;
   auto final_gains = [&]() {
     if (has_con) return;  // constrained: K already holds the gains of the last ADMM backward pass
     // K reported by the solver comes from the sigma-regularised ADMM backward pass
@@ -1540,7 +1543,7 @@ int orc_calc_diff(void *h, const double *ref, const int32_t *frames, const doubl
   const int nv = p->m.nv, nx = 2 * nv, T = p->o.T, TILE = AGX_TILE_DOUBLES(nv);
 #pragma omp parallel for schedule(dynamic)
   for (int b = 0; b < p->B; ++b) {
-    Workspace w;
+    static thread_local Workspace w;
     double c, g;
     eval_tiles(p->m, p->o, xs + (size_t)b * (T + 1) * nx, us + (size_t)b * T * nv, ref + (size_t)b * (T + 1) * p->o.stride,
                frames ? frames + (size_t)b * (T + 1) * AGX_MAX_ROWS : nullptr, w, c, g);
@@ -1577,7 +1580,7 @@ int orc_solve(void *h, const double *ref, const int32_t *frames, const double *x
   (void)nthreads;
 #pragma omp parallel for schedule(dynamic) num_threads(nthreads > 0 ? nthreads : 1)
   for (int b = 0; b < p->B; ++b) {
-    Workspace w;
+    static thread_local Workspace w;
     solve_one(p->m, p->o, ref + (size_t)b * (T + 1) * p->o.stride, frames ? frames + (size_t)b * (T + 1) * AGX_MAX_ROWS : nullptr,
               x0 + (size_t)b * nx, xs_ws + (size_t)b * (T + 1) * nx, us_ws + (size_t)b * T * nu, max_iter, max_time,
               xs + (size_t)b * (T + 1) * nx, us + (size_t)b * T * nu, K + (size_t)b * T * nu * nx, st + b, w, &p->admm[b],
