@@ -33,13 +33,25 @@ int fail(const std::string &msg) {
 }  // namespace
 
 struct agx_model {
-  DevModel h;
+  DevModel h;   // padded to the compiled capacity (see pad_capacity)
+  int nvu = 0;  // joints of the caller's model
 };
 
 struct agx_ocp {
   DevModel hm;
   DevOcp ho;
   int nv = 0, nx = 0, nu = 0, T = 0, B = 0, tile = 0, stride = 0, device = 0;
+  // Model sizes at run time: the kernels exist for a few CAPACITIES (7 joints: eight lanes per node; 30 / 32: a workgroup per
+  // node).  A model with fewer joints is padded with massless, unit-armature joints that couple to nothing (pad_model): every
+  // cross term with a real joint is an exact zero, the pad block of each QP is an independent problem with zero data, so the
+  // real entries of xs, us, K, the costs and KKT residuals are what the exact-size recursion gives.  nv / nx / nu / stride above
+  // are the internal (capacity) sizes; nvu / stride_u the caller's.  Arrays crossing the C ABI are repacked on the host.
+  int nvu = 0, stride_u = 0;
+  bool padded = false;
+  std::vector<int> refmap[2];        // internal reference-tile element -> element of the caller's tile (-1: pad), running / terminal layout
+  std::vector<double> reffill[2];    // value of the pad elements
+  std::vector<double> stage;         // host staging of repacked arrays
+  std::vector<double> h_first_u;     // first-node results in the caller's layout
   bool chain = false;
   std::vector<double> dt;
   hipStream_t stream = nullptr;
@@ -133,6 +145,80 @@ int set_device(agx_ocp *o) {
   return 0;
 }
 
+// capacity a model of nv joints runs at: the smallest compiled size that holds it (0: none)
+int pad_capacity(int nv);
+
+// ---- repacking between the caller's layout (nvu joints) and the internal one (nv = capacity) -----------------------------
+// rows of `blocks` blocks of nvu doubles  <->  rows of `blocks` blocks of nv doubles
+void pad_rows(double *dst, const double *src, size_t rows, int blocks, int nvu, int nv, double fill) {
+  for (size_t r = 0; r < rows; ++r)
+    for (int b = 0; b < blocks; ++b) {
+      double *d = dst + (r * blocks + b) * nv;
+      const double *q = src + (r * blocks + b) * nvu;
+      for (int i = 0; i < nvu; ++i) d[i] = q[i];
+      for (int i = nvu; i < nv; ++i) d[i] = fill;
+    }
+}
+void unpad_rows(double *dst, const double *src, size_t rows, int blocks, int nvu, int nv) {
+  for (size_t r = 0; r < rows; ++r)
+    for (int b = 0; b < blocks; ++b) {
+      double *d = dst + (r * blocks + b) * nvu;
+      const double *q = src + (r * blocks + b) * nv;
+      for (int i = 0; i < nvu; ++i) d[i] = q[i];
+    }
+}
+// host -> device of [rows][blocks][nvu] into [rows][blocks][nv]; synchronous for padded handles (staging is reused)
+int up(agx_ocp *o, double *d_dst, const double *h_src, size_t rows, int blocks, double fill = 0.0) {
+  if (!o->padded) {
+    HIPCHK(hipMemcpyAsync(d_dst, h_src, sizeof(double) * rows * blocks * o->nv, hipMemcpyHostToDevice, o->stream));
+    return 0;
+  }
+  o->stage.resize(rows * blocks * o->nv);
+  pad_rows(o->stage.data(), h_src, rows, blocks, o->nvu, o->nv, fill);
+  HIPCHK(hipMemcpyAsync(d_dst, o->stage.data(), sizeof(double) * o->stage.size(), hipMemcpyHostToDevice, o->stream));
+  HIPCHK(hipStreamSynchronize(o->stream));
+  return 0;
+}
+// device -> host of [rows][blocks][nv] into [rows][blocks][nvu]; padded handles synchronize inside
+int down(agx_ocp *o, double *h_dst, const double *d_src, size_t rows, int blocks) {
+  if (!o->padded) {
+    HIPCHK(hipMemcpyAsync(h_dst, d_src, sizeof(double) * rows * blocks * o->nv, hipMemcpyDeviceToHost, o->stream));
+    return 0;
+  }
+  o->stage.resize(rows * blocks * o->nv);
+  HIPCHK(hipMemcpyAsync(o->stage.data(), d_src, sizeof(double) * o->stage.size(), hipMemcpyDeviceToHost, o->stream));
+  HIPCHK(hipStreamSynchronize(o->stream));
+  unpad_rows(h_dst, o->stage.data(), rows, blocks, o->nvu, o->nv);
+  return 0;
+}
+// gains: [n][nv][2 nv] on the device -> [n][nvu][2 nvu]
+int down_gains(agx_ocp *o, double *h_dst, const double *d_src, size_t n) {
+  if (!o->padded) {
+    HIPCHK(hipMemcpyAsync(h_dst, d_src, sizeof(double) * n * o->nu * o->nx, hipMemcpyDeviceToHost, o->stream));
+    return 0;
+  }
+  const int nv = o->nv, nvu = o->nvu;
+  o->stage.resize(n * nv * 2 * nv);
+  HIPCHK(hipMemcpyAsync(o->stage.data(), d_src, sizeof(double) * o->stage.size(), hipMemcpyDeviceToHost, o->stream));
+  HIPCHK(hipStreamSynchronize(o->stream));
+  for (size_t r = 0; r < n; ++r)
+    for (int i = 0; i < nvu; ++i)
+      unpad_rows(h_dst + (r * nvu + i) * 2 * nvu, o->stage.data() + (r * nv + i) * 2 * nv, 1, 2, nvu, nv);
+  return 0;
+}
+// reference tile [nodes][stride_u] (running layout, `term_every` > 0: every term_every-th node in the terminal layout)
+void pad_ref_tile(const agx_ocp *o, double *dst, const double *src, size_t B, int T) {
+  for (size_t b = 0; b < B; ++b)
+    for (int t = 0; t <= T; ++t) {
+      const int lay = t == T ? 1 : 0;
+      const double *q = src + (b * (T + 1) + t) * o->stride_u;
+      double *d = dst + (b * (T + 1) + t) * o->stride;
+      const int *map = o->refmap[lay].data();
+      const double *fill = o->reffill[lay].data();
+      for (int e = 0; e < o->stride; ++e) d[e] = map[e] >= 0 ? q[map[e]] : fill[e];
+    }
+}
+
 int ensure_scratch(agx_ocp *o, size_t bytes) {
   if (bytes <= o->scratch_bytes) return 0;
   if (o->d_scratch) HIPCHK(hipFree(o->d_scratch));
@@ -163,7 +249,15 @@ void fill_rows(const agx_cost_row *rows, int n, int nv, DevRows &d) {
   }
 }
 
-int fill_cons(const agx_constraint_row *rows, int n, int nv, const DevModel &m, DevCons &d, bool terminal) {
+// component k of a residual of `kind` over nv (capacity) joints -> the caller's component over nvu joints, -1 for a pad joint
+int user_component(int kind, int k, int nv, int nvu, bool is_ref) {
+  const bool joint_blocks = kind == AGX_RES_STATE || kind == AGX_RES_CONTROL || (kind == AGX_RES_CONTROL_GRAV && !is_ref);
+  if (!joint_blocks || nv == nvu) return k;
+  const int blk = k / nv, i = k % nv;
+  return i < nvu ? blk * nvu + i : -1;
+}
+
+int fill_cons(const agx_constraint_row *rows, int n, int nv, int nvu, const DevModel &m, DevCons &d, bool terminal) {
   std::memset(&d, 0, sizeof(d));
   int off = 0;
   for (int r = 0; r < n; ++r) {
@@ -179,10 +273,14 @@ int fill_cons(const agx_constraint_row *rows, int n, int nv, const DevModel &m, 
     if (!c.lower || !c.upper) return fail("agx_ocp_create: constraint bounds missing");
     const int i = d.n++;
     d.kind[i] = c.kind; d.frame[i] = c.frame; d.frame_b[i] = c.frame_b; d.off[i] = off; d.nr[i] = nr;
-    for (int k = 0; k < nref; ++k) d.ref[i][k] = c.ref ? c.ref[k] : 0.0;
+    for (int k = 0; k < nref; ++k) {
+      const int ku = user_component(c.kind, k, nv, nvu, true);
+      d.ref[i][k] = (c.ref && ku >= 0) ? c.ref[ku] : 0.0;
+    }
     for (int k = 0; k < nr; ++k) {
-      d.lb[off + k] = c.lower[k]; d.ub[off + k] = c.upper[k];
-      if (!(c.lower[k] <= c.upper[k])) return fail("agx_ocp_create: constraint with lower > upper");
+      const int ku = user_component(c.kind, k, nv, nvu, false);  // pad joints: unbounded components
+      d.lb[off + k] = ku >= 0 ? c.lower[ku] : -INFINITY; d.ub[off + k] = ku >= 0 ? c.upper[ku] : INFINITY;
+      if (!(d.lb[off + k] <= d.ub[off + k])) return fail("agx_ocp_create: constraint with lower > upper");
     }
     if (c.kind == AGX_RES_COLLISION) {
       if (c.frame < 0 || c.frame >= m.nframes || c.frame_b < 0 || c.frame_b >= m.nframes || !agx::frame_has_geometry(m, c.frame) ||
@@ -206,20 +304,24 @@ int fill_cons(const agx_constraint_row *rows, int n, int nv, const DevModel &m, 
 }
 
 // ---- dispatch over the compiled (NV, CHAIN) instantiations --------------------
-// The library is built as one translation unit per group of sizes (AGX_GROUP = 0..3, compiled in
+// The library is built as one translation unit per group of capacities (AGX_GROUP = 0: 7 joints, 1: 30 and 32, compiled in
 // parallel by backend.build(), namespace and entry points suffixed per group, csrc/agx_front.py
 // generates the forwarding entry points) or, without AGX_GROUP, as a single translation unit.
 #if defined(AGX_ONLY_NV7) || (defined(AGX_GROUP) && AGX_GROUP == 0)  // AGX_ONLY_NV7: development builds, short compile
 #define AGX_FOR_NV(MACRO) MACRO(7)
 #elif defined(AGX_ONLY_NV30) || (defined(AGX_GROUP) && AGX_GROUP == 1)
-#define AGX_FOR_NV(MACRO) MACRO(30)
-#elif defined(AGX_GROUP) && AGX_GROUP == 2
-#define AGX_FOR_NV(MACRO) MACRO(1) MACRO(2) MACRO(3)
-#elif defined(AGX_GROUP) && AGX_GROUP == 3
-#define AGX_FOR_NV(MACRO) MACRO(4) MACRO(6)
+#define AGX_FOR_NV(MACRO) MACRO(30) MACRO(32)
 #else
-#define AGX_FOR_NV(MACRO) MACRO(1) MACRO(2) MACRO(3) MACRO(4) MACRO(6) MACRO(7) MACRO(30)
+#define AGX_FOR_NV(MACRO) MACRO(7) MACRO(30) MACRO(32)
 #endif
+
+int pad_capacity(int nv) {
+  int best = 0;
+#define AGX_CAP(N) if (N >= nv && (best == 0 || N < best)) best = N;
+  AGX_FOR_NV(AGX_CAP)
+#undef AGX_CAP
+  return best;
+}
 
 template <typename F>
 int dispatch(int nv, bool chain, F &&f) {
@@ -231,7 +333,7 @@ int dispatch(int nv, bool chain, F &&f) {
     AGX_FOR_NV(AGX_CASE)
 #undef AGX_CASE
   }
-  return fail("no kernel instantiation for nv = " + std::to_string(nv) + " (compiled: 1,2,3,4,6,7,30)");
+  return fail("no kernel instantiation for nv = " + std::to_string(nv) + " (compiled capacities: 7, 30, 32)");
 }
 
 int ensure_canonical_tiles(agx_ocp *o) {
@@ -854,10 +956,13 @@ int agx_model_create(const agx_model_desc *d, agx_model **out) {
   if (!d || !out) return fail("agx_model_create: null argument");
   if (d->nv < 1 || d->nv > AGX_MAX_NV) return fail("agx_model_create: nv out of range");
   if (d->nframes < 0 || d->nframes > AGX_MAX_FRAMES) return fail("agx_model_create: too many frames");
+  const int cap = pad_capacity(d->nv);
+  if (cap == 0) return fail("agx_model_create: no compiled capacity holds nv = " + std::to_string(d->nv));
   agx_model *m = new agx_model();
+  m->nvu = d->nv;
   DevModel &h = m->h;
   std::memset(&h, 0, sizeof(h));
-  h.nv = d->nv;
+  h.nv = cap;
   h.nframes = d->nframes;
   h.is_chain = 1;
   for (int i = 0; i < d->nv; ++i) {
@@ -873,6 +978,17 @@ int agx_model_create(const agx_model_desc *d, agx_model **out) {
     std::memcpy(h.com[i], d->com + 3 * i, sizeof(double) * 3);
     std::memcpy(h.inertia[i], d->inertia + 9 * i, sizeof(double) * 9);
     h.armature[i] = d->armature ? d->armature[i] : 0.0;
+  }
+  // pad joints (robot_model.py:231-257 takes any URDF and any set of locked joints; the kernels come in a few capacities): massless,
+  // unit armature, identity placement -- appended to a serial chain (the eight-lane kernel needs one), children of the universe in a tree
+  for (int i = d->nv; i < cap; ++i) {
+    h.parent[i] = h.is_chain ? i - 1 : -1;
+    h.anc[i] = (1u << i) | (h.parent[i] >= 0 ? h.anc[h.parent[i]] : 0u);
+    for (int j = 0; j <= i; ++j)
+      if ((h.anc[i] >> j) & 1u) h.desc[j] |= (1u << i);
+    h.placement[i][0] = h.placement[i][4] = h.placement[i][8] = 1.0;
+    h.axis[i][2] = 1.0;
+    h.armature[i] = 1.0;
   }
   h.gravity[0] = d->gravity ? d->gravity[0] : 0.0;
   h.gravity[1] = d->gravity ? d->gravity[1] : 0.0;
@@ -955,8 +1071,36 @@ int agx_ocp_create(const agx_model *m, const agx_ocp_desc *d, int batch, int dev
   o->ho.tol = d->termination_tolerance;
   o->ho.mu_dyn = d->mu_dynamic;
   o->ho.mu_con = d->mu_constraint;
-  if (fill_cons(d->running_constraints, d->n_running_constraints, o->nv, m->h, o->ho.cons[0], false) ||
-      fill_cons(d->terminal_constraints, d->n_terminal_constraints, o->nv, m->h, o->ho.cons[1], true)) { delete o; return -1; }
+  o->nvu = m->nvu;
+  o->padded = o->nvu != o->nv;
+  o->stride_u = agx_ref_stride(d, o->nvu);
+  if (o->padded) {
+    // reference-tile maps: row r of a layout sits at off_u[r] in the caller's tile, at off[r] in the internal one; the joint
+    // blocks of State / Control references and activation weights grow from nvu to nv entries (pad weights 1: the pad
+    // residuals are identically zero, the weight only keeps the pad block of the Hessians well conditioned)
+    for (int lay = 0; lay < 2; ++lay) {
+      const DevRows &R = o->ho.rows[lay];
+      o->refmap[lay].assign(o->stride, -1);
+      o->reffill[lay].assign(o->stride, 0.0);
+      int off_u = 0;
+      for (int r = 0; r < R.n; ++r) {
+        const int kind = R.kind[r], nref_u = agx_row_nref(kind, o->nvu), nr_u = agx_row_nr(kind, o->nvu);
+        o->refmap[lay][R.off[r]] = off_u;
+        for (int k = 0; k < R.nref[r]; ++k) {
+          const int ku = user_component(kind, k, o->nv, o->nvu, true);
+          o->refmap[lay][R.off[r] + 1 + k] = ku >= 0 ? off_u + 1 + ku : -1;
+        }
+        for (int k = 0; k < R.nr[r]; ++k) {
+          const int ku = user_component(kind, k, o->nv, o->nvu, false);
+          o->refmap[lay][R.off[r] + 1 + R.nref[r] + k] = ku >= 0 ? off_u + 1 + nref_u + ku : -1;
+          if (ku < 0) o->reffill[lay][R.off[r] + 1 + R.nref[r] + k] = 1.0;
+        }
+        off_u += 1 + nref_u + nr_u;
+      }
+    }
+  }
+  if (fill_cons(d->running_constraints, d->n_running_constraints, o->nv, o->nvu, m->h, o->ho.cons[0], false) ||
+      fill_cons(d->terminal_constraints, d->n_terminal_constraints, o->nv, o->nvu, m->h, o->ho.cons[1], true)) { delete o; return -1; }
   o->has_con = o->ho.cons[0].nc + o->ho.cons[1].nc > 0;
   o->general = o->ho.rows[0].general || o->ho.rows[1].general;
   if (o->general && o->has_con) { delete o; return fail("agx_ocp_create: constraints together with ControlGrav / FrameVelocity cost rows are not implemented"); }
@@ -1162,6 +1306,11 @@ int agx_ocp_set_refs(agx_ocp *o, const double *ref_tile, const int32_t *frame_id
   if (set_device(o)) return -1;
   if (o->refs_pending) { HIPCHK(hipEventSynchronize(o->ev_refs)); o->refs_pending = false; }  // superseded
   const size_t n = (size_t)o->B * (o->T + 1);
+  if (o->padded) {  // the caller's tile is laid out for nvu joints
+    o->stage.resize(n * o->stride);
+    pad_ref_tile(o, o->stage.data(), ref_tile, o->B, o->T);
+    ref_tile = o->stage.data();
+  }
   HIPCHK(hipMemcpyAsync(o->d_ref, ref_tile, sizeof(double) * n * o->stride, hipMemcpyHostToDevice, o->stream));
   if (frame_ids) HIPCHK(hipMemcpyAsync(o->d_frames, frame_ids, sizeof(int) * n * AGX_MAX_ROWS, hipMemcpyHostToDevice, o->stream));
   HIPCHK(hipStreamSynchronize(o->stream));  // the caller may reuse its buffers
@@ -1177,7 +1326,18 @@ int agx_ocp_set_refs_device(agx_ocp *o, const double *d_ref_tile, const int32_t 
   if (!o || !d_ref_tile) return fail("agx_ocp_set_refs_device: null argument");
   if (set_device(o)) return -1;
   const size_t n = (size_t)o->B * (o->T + 1);
-  if (adopt) {
+  if (o->padded) {  // a device tile in the caller's layout: through the host (padded models are not the fast path)
+    std::vector<double> tmp(n * o->stride_u);
+    HIPCHK(hipMemcpyAsync(tmp.data(), d_ref_tile, sizeof(double) * tmp.size(), hipMemcpyDeviceToHost, o->stream));
+    HIPCHK(hipStreamSynchronize(o->stream));
+    o->stage.resize(n * o->stride);
+    pad_ref_tile(o, o->stage.data(), tmp.data(), o->B, o->T);
+    HIPCHK(hipMemcpyAsync(o->d_ref, o->stage.data(), sizeof(double) * n * o->stride, hipMemcpyHostToDevice, o->stream));
+    if (d_frame_ids) HIPCHK(hipMemcpyAsync(o->d_frames, d_frame_ids, sizeof(int) * n * AGX_MAX_ROWS, hipMemcpyDeviceToDevice, o->stream));
+    HIPCHK(hipStreamSynchronize(o->stream));
+    o->rv.base = o->d_ref;
+    o->rv.frames = d_frame_ids ? o->d_frames : nullptr;
+  } else if (adopt) {
     o->rv.base = d_ref_tile;
     o->rv.frames = d_frame_ids;
   } else {
@@ -1211,9 +1371,15 @@ int agx_ocp_set_refs_async(agx_ocp *o, const double *ref_tile, const int32_t *fr
   if (frame_ids && !o->d_frames_back) HIPCHK(hipMalloc((void **)&o->d_frames_back, sizeof(int) * n * AGX_MAX_ROWS));
   if (o->refs_pending) HIPCHK(hipEventSynchronize(o->ev_refs));  // a second upload before any solve: replaces the first
   // the back tile is free: the solve that read it has returned (solves are synchronous to the host)
+  if (o->padded) {  // repacked through the handle's staging vector: the copy has to finish before this call returns
+    o->stage.resize(n * o->stride);
+    pad_ref_tile(o, o->stage.data(), ref_tile, o->B, o->T);
+    ref_tile = o->stage.data();
+  }
   HIPCHK(hipMemcpyAsync(o->d_ref_back, ref_tile, sizeof(double) * n * o->stride, hipMemcpyHostToDevice, o->copy_stream));
   if (frame_ids) HIPCHK(hipMemcpyAsync(o->d_frames_back, frame_ids, sizeof(int) * n * AGX_MAX_ROWS, hipMemcpyHostToDevice, o->copy_stream));
   HIPCHK(hipEventRecord(o->ev_refs, o->copy_stream));
+  if (o->padded) HIPCHK(hipStreamSynchronize(o->copy_stream));
   o->refs_pending = true;
   o->refs_pending_frames = frame_ids != nullptr;
   return 0;
@@ -1235,6 +1401,13 @@ int agx_ocp_download_async(agx_ocp *o, double *xs, double *us, double *K) {
   if (set_device(o)) return -1;
   if (ensure_copy_stream(o)) return -1;
   const size_t B = o->B, T = o->T, nx = o->nx, nu = o->nu;
+  if (o->padded) {  // repacked on the host: the synchronous route
+    if (xs && down(o, xs, o->d_xs, B * (T + 1), 2)) return -1;
+    if (us && down(o, us, o->d_us, B * T, 1)) return -1;
+    if (K && down_gains(o, K, o->d_Kout, B * T)) return -1;
+    HIPCHK(hipStreamSynchronize(o->stream));
+    return 0;
+  }
   const size_t n_xs = B * (T + 1) * nx, n_us = B * T * nu, n_K = B * T * nu * nx;
   if (!o->d_snap) HIPCHK(hipMalloc((void **)&o->d_snap, sizeof(double) * (n_xs + n_us + n_K)));
   if (o->dl_pending) HIPCHK(hipEventSynchronize(o->ev_dl));  // the previous download still reads the snapshot
@@ -1262,7 +1435,7 @@ int agx_ocp_download_wait(agx_ocp *o) {
 int agx_ocp_upload_x0(agx_ocp *o, const double *x0) {
   if (!o || !x0) return fail("agx_ocp_upload_x0: null argument");
   if (set_device(o)) return -1;
-  HIPCHK(hipMemcpyAsync(o->d_x0, x0, sizeof(double) * o->B * o->nx, hipMemcpyHostToDevice, o->stream));
+  if (up(o, o->d_x0, x0, o->B, 2)) return -1;
   HIPCHK(hipStreamSynchronize(o->stream));
   return 0;
 }
@@ -1270,8 +1443,8 @@ int agx_ocp_upload_x0(agx_ocp *o, const double *x0) {
 int agx_ocp_upload_warmstart(agx_ocp *o, const double *xs_ws, const double *us_ws) {
   if (!o || !xs_ws || !us_ws) return fail("agx_ocp_upload_warmstart: null argument");
   if (set_device(o)) return -1;
-  HIPCHK(hipMemcpyAsync(o->d_xs, xs_ws, sizeof(double) * o->B * (o->T + 1) * o->nx, hipMemcpyHostToDevice, o->stream));
-  HIPCHK(hipMemcpyAsync(o->d_us, us_ws, sizeof(double) * o->B * o->T * o->nu, hipMemcpyHostToDevice, o->stream));
+  if (up(o, o->d_xs, xs_ws, (size_t)o->B * (o->T + 1), 2)) return -1;
+  if (up(o, o->d_us, us_ws, (size_t)o->B * o->T, 1)) return -1;
   HIPCHK(hipStreamSynchronize(o->stream));
   return 0;
 }
@@ -1286,9 +1459,10 @@ int agx_ocp_download(agx_ocp *o, double *xs, double *us, double *K, agx_status *
   if (!o) return fail("null handle");
   if (set_device(o)) return -1;
   const size_t B = o->B, T = o->T, nx = o->nx, nu = o->nu;
-  if (xs) HIPCHK(hipMemcpyAsync(xs, o->d_xs, sizeof(double) * B * (T + 1) * nx, hipMemcpyDeviceToHost, o->stream));
-  if (us) HIPCHK(hipMemcpyAsync(us, o->d_us, sizeof(double) * B * T * nu, hipMemcpyDeviceToHost, o->stream));
-  if (K) HIPCHK(hipMemcpyAsync(K, o->d_Kout, sizeof(double) * B * T * nu * nx, hipMemcpyDeviceToHost, o->stream));
+  (void)nx; (void)nu;
+  if (xs && down(o, xs, o->d_xs, B * (T + 1), 2)) return -1;
+  if (us && down(o, us, o->d_us, B * T, 1)) return -1;
+  if (K && down_gains(o, K, o->d_Kout, B * T)) return -1;
   std::vector<DevState> hs;
   if (st) {
     hs.resize(B);
@@ -1336,6 +1510,21 @@ int agx_ocp_first_packed(agx_ocp *o, const double **host, int *stride) {
     HIPCHK(hipMemcpyAsync(o->h_first, o->d_first, sizeof(double) * n, hipMemcpyDeviceToHost, o->stream));
     HIPCHK(hipStreamSynchronize(o->stream));
   }
+  if (o->padded) {  // [us0 | K0 | x1 | status] of the caller's nvu joints
+    const int nv = o->nv, nvu = o->nvu, FSu = nvu + nvu * 2 * nvu + 2 * nvu + 8;
+    o->h_first_u.resize((size_t)o->B * FSu);
+    for (int b = 0; b < o->B; ++b) {
+      const double *r = o->h_first + (size_t)b * FS;
+      double *w = o->h_first_u.data() + (size_t)b * FSu;
+      unpad_rows(w, r, 1, 1, nvu, nv);
+      for (int i = 0; i < nvu; ++i) unpad_rows(w + nvu + (size_t)i * 2 * nvu, r + nv + (size_t)i * 2 * nv, 1, 2, nvu, nv);
+      unpad_rows(w + nvu + nvu * 2 * nvu, r + nv + nv * 2 * nv, 1, 2, nvu, nv);
+      std::memcpy(w + nvu + nvu * 2 * nvu + 2 * nvu, r + nv + nv * 2 * nv + 2 * nv, sizeof(double) * 8);
+    }
+    *host = o->h_first_u.data();
+    if (stride) *stride = FSu;
+    return 0;
+  }
   *host = o->h_first;
   if (stride) *stride = FS;
   return 0;
@@ -1345,7 +1534,7 @@ int agx_ocp_download_first(agx_ocp *o, double *us0, double *K0, double *x1, agx_
   const double *h = nullptr;
   int FS = 0;
   if (agx_ocp_first_packed(o, &h, &FS)) return -1;
-  const int nu = o->nu, nx = o->nx, nk = nu * nx;
+  const int nu = o->nvu, nx = 2 * o->nvu, nk = nu * nx;
   for (int b = 0; b < o->B; ++b) {
     const double *r = h + (size_t)b * FS;
     if (us0) std::memcpy(us0 + (size_t)b * nu, r, sizeof(double) * nu);
@@ -1406,8 +1595,7 @@ int agx_ocp_integrate(agx_ocp *o, int n, const double *x, const double *u, doubl
   const size_t bytes = sizeof(double) * n * (2 * o->nx + o->nu);
   if (ensure_scratch(o, bytes)) return -1;
   double *dx = o->d_scratch, *du = dx + (size_t)n * o->nx, *dn = du + (size_t)n * o->nu;
-  HIPCHK(hipMemcpyAsync(dx, x, sizeof(double) * n * o->nx, hipMemcpyHostToDevice, o->stream));
-  HIPCHK(hipMemcpyAsync(du, u, sizeof(double) * n * o->nu, hipMemcpyHostToDevice, o->stream));
+  if (up(o, dx, x, n, 2) || up(o, du, u, n, 1)) return -1;
   int rc = dispatch(o->nv, o->chain, [&](auto NVc, auto CHc) -> int {
     constexpr int NV = decltype(NVc)::value;
     constexpr bool CH = decltype(CHc)::value;
@@ -1419,7 +1607,7 @@ int agx_ocp_integrate(agx_ocp *o, int n, const double *x, const double *u, doubl
     return 0;
   });
   if (rc) return rc;
-  HIPCHK(hipMemcpyAsync(xnext, dn, sizeof(double) * n * o->nx, hipMemcpyDeviceToHost, o->stream));
+  if (down(o, xnext, dn, n, 2)) return -1;
   HIPCHK(hipStreamSynchronize(o->stream));
   return 0;
 }
@@ -1430,9 +1618,7 @@ int agx_model_rnea(agx_ocp *o, int n, const double *q, const double *v, const do
   const size_t cnt = (size_t)n * o->nv;
   if (ensure_scratch(o, sizeof(double) * 4 * cnt)) return -1;
   double *dq = o->d_scratch, *dv = dq + cnt, *da = dv + cnt, *dt = da + cnt;
-  HIPCHK(hipMemcpyAsync(dq, q, sizeof(double) * cnt, hipMemcpyHostToDevice, o->stream));
-  HIPCHK(hipMemcpyAsync(dv, v, sizeof(double) * cnt, hipMemcpyHostToDevice, o->stream));
-  HIPCHK(hipMemcpyAsync(da, a, sizeof(double) * cnt, hipMemcpyHostToDevice, o->stream));
+  if (up(o, dq, q, n, 1) || up(o, dv, v, n, 1) || up(o, da, a, n, 1)) return -1;
   int rc = dispatch(o->nv, o->chain, [&](auto NVc, auto CHc) -> int {
     constexpr int NV = decltype(NVc)::value;
     constexpr bool CH = decltype(CHc)::value;
@@ -1441,7 +1627,7 @@ int agx_model_rnea(agx_ocp *o, int n, const double *q, const double *v, const do
     return 0;
   });
   if (rc) return rc;
-  HIPCHK(hipMemcpyAsync(tau, dt, sizeof(double) * cnt, hipMemcpyDeviceToHost, o->stream));
+  if (down(o, tau, dt, n, 1)) return -1;
   HIPCHK(hipStreamSynchronize(o->stream));
   return 0;
 }
@@ -1453,7 +1639,7 @@ int agx_model_frame_placement(agx_ocp *o, int n, int frame, const double *q, dou
   const size_t cnt = (size_t)n * o->nv;
   if (ensure_scratch(o, sizeof(double) * (cnt + (size_t)n * 12))) return -1;
   double *dq = o->d_scratch, *dout = dq + cnt;
-  HIPCHK(hipMemcpyAsync(dq, q, sizeof(double) * cnt, hipMemcpyHostToDevice, o->stream));
+  if (up(o, dq, q, n, 1)) return -1;
   int rc = dispatch(o->nv, o->chain, [&](auto NVc, auto CHc) -> int {
     constexpr int NV = decltype(NVc)::value;
     constexpr bool CH = decltype(CHc)::value;
@@ -1474,7 +1660,7 @@ int agx_model_frame_jacobian(agx_ocp *o, int n, int frame, int local, const doub
   const size_t cnt = (size_t)n * o->nv;
   if (ensure_scratch(o, sizeof(double) * (cnt + 6 * cnt))) return -1;
   double *dq = o->d_scratch, *dout = dq + cnt;
-  HIPCHK(hipMemcpyAsync(dq, q, sizeof(double) * cnt, hipMemcpyHostToDevice, o->stream));
+  if (up(o, dq, q, n, 1)) return -1;
   int rc = dispatch(o->nv, o->chain, [&](auto NVc, auto CHc) -> int {
     constexpr int NV = decltype(NVc)::value;
     constexpr bool CH = decltype(CHc)::value;
@@ -1483,7 +1669,7 @@ int agx_model_frame_jacobian(agx_ocp *o, int n, int frame, int local, const doub
     return 0;
   });
   if (rc) return rc;
-  HIPCHK(hipMemcpyAsync(J, dout, sizeof(double) * 6 * cnt, hipMemcpyDeviceToHost, o->stream));
+  if (down(o, J, dout, (size_t)n * 6, 1)) return -1;
   HIPCHK(hipStreamSynchronize(o->stream));
   return 0;
 }
@@ -1504,7 +1690,12 @@ int agx_ocp_get_residuals(agx_ocp *o, int row, double *out) {
     return 0;
   });
   if (rc) return rc;
-  HIPCHK(hipMemcpyAsync(out, o->d_scratch, sizeof(double) * cnt, hipMemcpyDeviceToHost, o->stream));
+  {
+    const int kind = o->ho.rows[0].kind[row];
+    const bool joint_blocks = kind == AGX_RES_STATE || kind == AGX_RES_CONTROL || kind == AGX_RES_CONTROL_GRAV;
+    if (o->padded && joint_blocks) { if (down(o, out, o->d_scratch, (size_t)o->B * o->T, nr / o->nv)) return -1; }
+    else HIPCHK(hipMemcpyAsync(out, o->d_scratch, sizeof(double) * cnt, hipMemcpyDeviceToHost, o->stream));
+  }
   HIPCHK(hipStreamSynchronize(o->stream));
   return 0;
 }
@@ -1513,6 +1704,34 @@ int agx_ocp_calc_diff(agx_ocp *o, double *tiles) {
   if (!o) return fail("null handle");
   if (set_device(o)) return -1;
   if (launch_calc_diff(o, false)) return -1;
+  if (tiles && o->padded) {
+    // canonical tiles Fx | Fu | f | Lx | Lu | Lxx | Lxu | Luu | cost of the caller's nvu joints out of the capacity-sized ones
+    const size_t nodes = (size_t)o->B * (o->T + 1);
+    const int nv = o->nv, nvu = o->nvu, NX = 2 * nv, NU = nv, nxu = 2 * nvu, nuu = nvu, TU = AGX_TILE_DOUBLES(nvu);
+    o->stage.resize(nodes * o->tile);
+    HIPCHK(hipMemcpyAsync(o->stage.data(), o->d_tiles, sizeof(double) * o->stage.size(), hipMemcpyDeviceToHost, o->stream));
+    HIPCHK(hipStreamSynchronize(o->stream));
+    auto xm = [&](int i) { return i < nvu ? i : nv + (i - nvu); };
+    for (size_t n = 0; n < nodes; ++n) {
+      const double *c = o->stage.data() + n * o->tile;
+      double *u = tiles + n * TU;
+      const double *cFx = c, *cFu = cFx + NX * NX, *cf = cFu + NX * NU, *cLx = cf + NX, *cLu = cLx + NX, *cLxx = cLu + NU,
+                   *cLxu = cLxx + NX * NX, *cLuu = cLxu + NX * NU, *ccost = cLuu + NU * NU;
+      double *uFx = u, *uFu = uFx + nxu * nxu, *uf = uFu + nxu * nuu, *uLx = uf + nxu, *uLu = uLx + nxu, *uLxx = uLu + nuu,
+             *uLxu = uLxx + nxu * nxu, *uLuu = uLxu + nxu * nuu, *ucost = uLuu + nuu * nuu;
+      for (int i = 0; i < nxu; ++i) {
+        for (int j = 0; j < nxu; ++j) { uFx[i * nxu + j] = cFx[xm(i) * NX + xm(j)]; uLxx[i * nxu + j] = cLxx[xm(i) * NX + xm(j)]; }
+        for (int j = 0; j < nuu; ++j) { uFu[i * nuu + j] = cFu[xm(i) * NU + j]; uLxu[i * nuu + j] = cLxu[xm(i) * NU + j]; }
+        uf[i] = cf[xm(i)]; uLx[i] = cLx[xm(i)];
+      }
+      for (int i = 0; i < nuu; ++i) {
+        uLu[i] = cLu[i];
+        for (int j = 0; j < nuu; ++j) uLuu[i * nuu + j] = cLuu[i * NU + j];
+      }
+      *ucost = *ccost;
+    }
+    return 0;
+  }
   if (tiles) HIPCHK(hipMemcpyAsync(tiles, o->d_tiles, sizeof(double) * o->B * (o->T + 1) * (size_t)o->tile, hipMemcpyDeviceToHost, o->stream));
   HIPCHK(hipStreamSynchronize(o->stream));
   return 0;
@@ -1529,10 +1748,11 @@ int agx_ocp_direction(agx_ocp *o, double *K, double *k, double *dx, double *du, 
   if (launch_step(o, 0, 1, 0)) return -1;
   if (launch_gains(o)) return -1;
   const size_t B = o->B, T = o->T, nx = o->nx, nu = o->nu;
-  if (K) HIPCHK(hipMemcpyAsync(K, o->d_Kout, sizeof(double) * B * T * nu * nx, hipMemcpyDeviceToHost, o->stream));
-  if (k) HIPCHK(hipMemcpyAsync(k, o->d_kws, sizeof(double) * B * T * nu, hipMemcpyDeviceToHost, o->stream));
-  if (dx) HIPCHK(hipMemcpyAsync(dx, o->d_dx, sizeof(double) * B * (T + 1) * nx, hipMemcpyDeviceToHost, o->stream));
-  if (du) HIPCHK(hipMemcpyAsync(du, o->d_du, sizeof(double) * B * T * nu, hipMemcpyDeviceToHost, o->stream));
+  (void)nx; (void)nu;
+  if (K && down_gains(o, K, o->d_Kout, B * T)) return -1;
+  if (k && down(o, k, o->d_kws, B * T, 1)) return -1;
+  if (dx && down(o, dx, o->d_dx, B * (T + 1), 2)) return -1;
+  if (du && down(o, du, o->d_du, B * T, 1)) return -1;
   std::vector<DevState> hs(B);
   HIPCHK(hipMemcpyAsync(hs.data(), o->d_state, sizeof(DevState) * B, hipMemcpyDeviceToHost, o->stream));
   HIPCHK(hipStreamSynchronize(o->stream));
@@ -1643,15 +1863,16 @@ int agx_traj_sine_create(agx_ocp *o, int n_points, double dt, const double *q0, 
   HIPCHK(hipMalloc((void **)&o->d_pts, sizeof(double) * B * n_points * (4 * nv + 12)));
   HIPCHK(hipMalloc((void **)&o->d_sine, sizeof(double) * (4 * B * nv + B)));
   double *d = o->d_sine;
-  HIPCHK(hipMemcpyAsync(d, q0, sizeof(double) * B * nv, hipMemcpyHostToDevice, o->stream));
-  HIPCHK(hipMemcpyAsync(d + B * nv, amp, sizeof(double) * B * nv, hipMemcpyHostToDevice, o->stream));
-  HIPCHK(hipMemcpyAsync(d + 2 * B * nv, pulsation, sizeof(double) * B * nv, hipMemcpyHostToDevice, o->stream));
-  HIPCHK(hipMemcpyAsync(d + 3 * B * nv, scale_duration, sizeof(double) * B * nv, hipMemcpyHostToDevice, o->stream));
+  // pad joints: amplitude 0 (they stay at rest), scale duration 1 (it divides)
+  if (up(o, d, q0, B, 1) || up(o, d + B * nv, amp, B, 1) || up(o, d + 2 * B * nv, pulsation, B, 1) || up(o, d + 3 * B * nv, scale_duration, B, 1, 1.0)) return -1;
   HIPCHK(hipMemcpyAsync(d + 4 * B * nv, t0, sizeof(double) * B, hipMemcpyHostToDevice, o->stream));
   agx::SineParams sp;
   std::memset(&sp, 0, sizeof(sp));
   sp.q0 = d; sp.amp = d + B * nv; sp.puls = d + 2 * B * nv; sp.scale = d + 3 * B * nv; sp.t0 = d + 4 * B * nv;
-  for (size_t i = 0; i < nv; ++i) { sp.w_q[i] = w_q[i]; sp.w_qdot[i] = w_qdot[i]; sp.w_effort[i] = w_effort[i]; }
+  for (size_t i = 0; i < nv; ++i) {  // pad joints: weight 1 on an identically zero residual
+    const bool real = i < (size_t)o->nvu;
+    sp.w_q[i] = real ? w_q[i] : 1.0; sp.w_qdot[i] = real ? w_qdot[i] : 1.0; sp.w_effort[i] = real ? w_effort[i] : 1.0;
+  }
   for (int i = 0; i < 6; ++i) sp.w_pose[i] = w_pose[i];
   sp.dt = dt; sp.n_points = n_points; sp.frame = frame;
   o->n_points = n_points;
@@ -1683,13 +1904,14 @@ int agx_traj_generic_create(agx_ocp *o, int n_points, const double *q, const dou
   HIPCHK(hipMalloc((void **)&o->d_pts, sizeof(double) * B * n_points * (4 * nv + 12)));
   HIPCHK(hipMalloc((void **)&o->d_sine, sizeof(double) * 3 * n));
   double *d = o->d_sine;
-  HIPCHK(hipMemcpyAsync(d, q, sizeof(double) * n, hipMemcpyHostToDevice, o->stream));
-  HIPCHK(hipMemcpyAsync(d + n, dq, sizeof(double) * n, hipMemcpyHostToDevice, o->stream));
-  HIPCHK(hipMemcpyAsync(d + 2 * n, ddq, sizeof(double) * n, hipMemcpyHostToDevice, o->stream));
+  if (up(o, d, q, B * (size_t)n_points, 1) || up(o, d + n, dq, B * (size_t)n_points, 1) || up(o, d + 2 * n, ddq, B * (size_t)n_points, 1)) return -1;
   agx::SineParams sp;
   std::memset(&sp, 0, sizeof(sp));
   sp.gq = d; sp.gdq = d + n; sp.gddq = d + 2 * n;
-  for (size_t i = 0; i < nv; ++i) { sp.w_q[i] = w_q[i]; sp.w_qdot[i] = w_qdot[i]; sp.w_effort[i] = w_effort[i]; }
+  for (size_t i = 0; i < nv; ++i) {  // pad joints: weight 1 on an identically zero residual
+    const bool real = i < (size_t)o->nvu;
+    sp.w_q[i] = real ? w_q[i] : 1.0; sp.w_qdot[i] = real ? w_qdot[i] : 1.0; sp.w_effort[i] = real ? w_effort[i] : 1.0;
+  }
   for (int i = 0; i < 6; ++i) sp.w_pose[i] = w_pose[i];
   sp.dt = 0.0; sp.n_points = n_points; sp.frame = frame;
   o->n_points = n_points;
@@ -1729,7 +1951,7 @@ int agx_traj_cartesian_sine_create(agx_ocp *o, int n_points, double dt, const do
   double *d = o->d_sine, *dpar = d + 3 * n, *dpose = dpar + npar;
   int *dfail = reinterpret_cast<int *>(dpose + npose);
   HIPCHK(hipMemsetAsync(d + 2 * n, 0, sizeof(double) * n, o->stream));  // ddq = 0
-  HIPCHK(hipMemcpyAsync(dpar, q0, sizeof(double) * B * nv, hipMemcpyHostToDevice, o->stream));
+  if (up(o, dpar, q0, B, 1)) return -1;
   HIPCHK(hipMemcpyAsync(dpar + B * nv, amp, sizeof(double) * B * 3, hipMemcpyHostToDevice, o->stream));
   HIPCHK(hipMemcpyAsync(dpar + B * nv + B * 3, pulsation, sizeof(double) * B * 3, hipMemcpyHostToDevice, o->stream));
   agx::CartSineParams cp;
@@ -1740,7 +1962,10 @@ int agx_traj_cartesian_sine_create(agx_ocp *o, int n_points, double dt, const do
   agx::SineParams sp;
   std::memset(&sp, 0, sizeof(sp));
   sp.gq = d; sp.gdq = d + n; sp.gddq = d + 2 * n;
-  for (size_t i = 0; i < nv; ++i) { sp.w_q[i] = w_q[i]; sp.w_qdot[i] = w_qdot[i]; sp.w_effort[i] = w_effort[i]; }
+  for (size_t i = 0; i < nv; ++i) {  // pad joints: weight 1 on an identically zero residual
+    const bool real = i < (size_t)o->nvu;
+    sp.w_q[i] = real ? w_q[i] : 1.0; sp.w_qdot[i] = real ? w_qdot[i] : 1.0; sp.w_effort[i] = real ? w_effort[i] : 1.0;
+  }
   for (int i = 0; i < 6; ++i) sp.w_pose[i] = w_pose[i];
   sp.dt = 0.0; sp.n_points = n_points; sp.frame = frame;
   sp.gpose = dpose;
@@ -1828,10 +2053,11 @@ int agx_traj_get_point(agx_ocp *o, int k, double *q, double *v, double *a, doubl
   HIPCHK(hipStreamSynchronize(o->stream));
   for (size_t b = 0; b < B; ++b) {
     const double *p = &h[b * w];
-    if (q) std::memcpy(q + b * nv, p, sizeof(double) * nv);
-    if (v) std::memcpy(v + b * nv, p + nv, sizeof(double) * nv);
-    if (a) std::memcpy(a + b * nv, p + 2 * nv, sizeof(double) * nv);
-    if (u) std::memcpy(u + b * nv, p + 3 * nv, sizeof(double) * nv);
+    const size_t nvu = o->nvu;  // the sample's joint blocks hold nv (capacity) entries, the caller's nvu
+    if (q) std::memcpy(q + b * nvu, p, sizeof(double) * nvu);
+    if (v) std::memcpy(v + b * nvu, p + nv, sizeof(double) * nvu);
+    if (a) std::memcpy(a + b * nvu, p + 2 * nv, sizeof(double) * nvu);
+    if (u) std::memcpy(u + b * nvu, p + 3 * nv, sizeof(double) * nvu);
     if (pose) std::memcpy(pose + b * 12, p + 4 * nv, sizeof(double) * 12);
   }
   return 0;
@@ -1854,7 +2080,7 @@ int agx_traj_warmstart_from_reference(agx_ocp *o) {
 int agx_ocp_download_x0(agx_ocp *o, double *x0) {
   if (!o || !x0) return fail("agx_ocp_download_x0: null argument");
   if (set_device(o)) return -1;
-  HIPCHK(hipMemcpyAsync(x0, o->d_x0, sizeof(double) * o->B * o->nx, hipMemcpyDeviceToHost, o->stream));
+  if (down(o, x0, o->d_x0, o->B, 2)) return -1;
   HIPCHK(hipStreamSynchronize(o->stream));
   return 0;
 }
@@ -1867,7 +2093,7 @@ int agx_ocp_feedback_rollout(agx_ocp *o, int n_substeps, double dt_sub, const do
   if (disturbance) {
     if (ensure_scratch(o, sizeof(double) * o->B * o->nu)) return -1;
     d_dist = o->d_scratch;
-    HIPCHK(hipMemcpyAsync(d_dist, disturbance, sizeof(double) * o->B * o->nu, hipMemcpyHostToDevice, o->stream));
+    if (up(o, d_dist, disturbance, o->B, 1)) return -1;
   }
   return dispatch(o->nv, o->chain, [&](auto NVc, auto CHc) -> int {
     constexpr int NV = decltype(NVc)::value;

@@ -310,7 +310,7 @@ __device__ __forceinline__ double wg_node(WgNode<NV> &L, const DevModel &m, cons
   typedef QT<NV> Q;
   typedef AUX<NV> A;
   static_assert(Q::LD == LDM && A::LD == LDM, "tile row stride of large models");
-  static_assert(sizeof(WgNode<NV>) <= 54608, "three workgroups per CU (160 KiB of LDS)");
+  static_assert(sizeof(WgNode<NV>) <= (NV <= 30 ? 54608 : 65536), "three workgroups per CU (160 KiB of LDS) up to 30 joints, two above");
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int ti = wave >> 1, tj = wave & 1, l15 = lane & 15, l4 = lane >> 4;
   const double dt = in.dt, sc = TERM ? 1.0 : dt;

@@ -287,6 +287,26 @@ def chain_table(nv: int, seed: int = 0, armature=0.1, name=None) -> RobotTable:
     )
 
 
+def tree_table(nv: int, seed: int = 0, armature=0.1, branching=0.35, name=None) -> RobotTable:
+    """Seeded random kinematic TREE (test model for arbitrary model sizes, e.g. a Panda with unlocked fingers or a mobile
+    manipulator, factory/robot_model.py:231-257 upstream): joint i hangs on its predecessor or, with probability `branching`,
+    on a random earlier joint.  Frames: one per joint plus a tool on the last joint and one on a mid-tree joint."""
+    rng = np.random.default_rng(seed)
+    base = chain_table(nv, seed=seed + 1000, armature=armature)
+    parent = np.empty(nv, dtype=np.int32)
+    for i in range(nv):
+        parent[i] = i - 1 if (i < 2 or rng.uniform() > branching) else int(rng.integers(0, i - 1))
+    if nv > 2 and np.array_equal(parent, np.arange(nv) - 1):
+        parent[nv - 1] = 0  # make sure it is not a serial chain
+    frame_names = list(base.frame_names) + ["tool_b"]
+    frame_parent = np.concatenate([base.frame_parent, [nv // 2]]).astype(np.int32)
+    frame_placement = np.concatenate([base.frame_placement, se3(rpy(-0.2, 0.4, 0.1), [0.03, 0.04, -0.06])[None, :]])
+    import dataclasses
+
+    return dataclasses.replace(base, name=name or f"tree{nv}", parent=parent, frame_names=frame_names, frame_parent=frame_parent,
+                               frame_placement=frame_placement)
+
+
 def pendulum_table(length=1.0, mass=1.0, armature=0.0) -> RobotTable:
     """Point mass on a massless rod rotating about world Y: tau = m l^2 qdd + m g l sin(q)."""
     return RobotTable(

@@ -1,0 +1,142 @@
+"""Model sizes at run time: the kernels are compiled for a few capacities (7 joints: eight lanes per node; 30 and 32:
+one workgroup per node) and a model with any number of joints up to 32 runs at the smallest capacity that holds it,
+padded with massless joints that couple to nothing (agx_model_create, csrc/agimus_hip.hip).  The reference takes any
+URDF and any set of locked joints (factory/robot_model.py:231-257): a Panda with its two finger joints unlocked has
+nv = 9, a mobile manipulator more.  Every case goes through the C ABI in the caller's own layout (nv joints) and is
+compared with the CPU checker, which is generic in nv."""
+import numpy as np
+import pytest
+
+from agimus_controller_amd import _abi, workloads
+from agimus_controller_amd.factory import robot_tables as rt
+from oracle.oracle import Oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(a, b):
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-300))
+
+
+def _model(nv, kind):
+    if kind == "panda_fingers":
+        # the Panda with two more joints at the hand (the finger joints robot_model.py locks by default): chain of 9
+        p = rt.panda_table(0.1)
+        f = rt.chain_table(2, seed=5, armature=0.1)
+        import dataclasses
+
+        def cat(a, b):
+            return np.concatenate([np.asarray(a), np.asarray(b)])
+
+        frame_parent = np.asarray(p.frame_parent).copy()
+        return dataclasses.replace(
+            p, name="panda_fingers", joint_names=list(p.joint_names) + ["finger_joint1", "finger_joint2"],
+            parent=np.arange(-1, 8, dtype=np.int32), placement=cat(p.placement, f.placement), axis=cat(p.axis, f.axis),
+            mass=cat(p.mass, 0.05 * f.mass), com=cat(p.com, 0.2 * f.com), inertia=cat(p.inertia, 1e-3 * f.inertia),
+            armature=cat(p.armature, f.armature), effort_limit=cat(p.effort_limit, [20.0, 20.0]),
+            lower_position_limit=cat(p.lower_position_limit, [-0.5, -0.5]), upper_position_limit=cat(p.upper_position_limit, [0.5, 0.5]),
+            velocity_limit=cat(p.velocity_limit, [1.0, 1.0]), frame_parent=frame_parent)
+    if kind == "chain":
+        return rt.chain_table(nv, seed=20 + nv)
+    return rt.tree_table(nv, seed=40 + nv)
+
+
+CASES = [(5, "chain"), (5, "tree"), (9, "panda_fingers"), (12, "tree"), (24, "tree"), (31, "chain"), (32, "tree")]
+
+
+@pytest.mark.parametrize("nv,kind", CASES)
+def test_primitives_and_derivative_tiles(hip_backend, nv, kind):
+    """RNEA, frame placement / Jacobian, integrate and the canonical derivative tiles (1e-10) in the caller's layout."""
+    table = _model(nv, kind)
+    assert table.nv == nv
+    frame = len(table.frame_names) - 1
+    B, T = 3, 4
+    po, ref, x0, xs, us = workloads.random_goal_problem(table, T, 0.01, B, seed=nv, frame=frame, timesteps=[0.01, 0.01, 0.02, 0.02])
+    h, o = hip_backend.HipOcp(table, po, B), Oracle(table, po, B)
+    rng = np.random.default_rng(nv)
+    q, v, a = rng.uniform(-1.0, 1.0, (3, 5, nv))
+    assert rel(h.rnea(q, v, a), o.rnea(q, v, a).reshape(5, nv)) < 1e-11
+    assert rel(h.frame_placement(frame, q), o.frame_placement(frame, q)) < 1e-12
+    x = np.concatenate([q, v], axis=1)
+    assert rel(h.integrate(x, 3 * a), o.integrate(x, 3 * a).reshape(5, 2 * nv)) < 1e-10
+    h.set_refs(ref)
+    h.upload_warmstart(xs, us)
+    got, want = h.calc_diff(), o.calc_diff(ref, None, xs, us)
+    assert got.shape == want.shape == (B, T + 1, _abi.tile_doubles(nv))
+    for field, s in _abi.tile_slices(nv).items():
+        scale = max(np.abs(want[..., s]).max(), 1e-300)
+        assert np.abs(got[..., s] - want[..., s]).max() <= 1e-10 * scale + 1e-13, field
+    h.close()
+
+
+@pytest.mark.parametrize("nv,kind", CASES)
+def test_full_solve_and_shift(hip_backend, nv, kind):
+    """SQP solve (same iterations, xs / us to 1e-8, gains to 1e-7 relative), first-node download, warm-start shift with mixed dt."""
+    table = _model(nv, kind)
+    frame = len(table.frame_names) - 1
+    B, T = 2, 6
+    ts = [0.01] * 4 + [0.02] * 2
+    po, ref, x0, xs, us = workloads.random_goal_problem(table, T, 0.01, B, seed=100 + nv, frame=frame, timesteps=ts)
+    h, o = hip_backend.HipOcp(table, po, B), Oracle(table, po, B)
+    h.set_refs(ref)
+    xs_h, us_h, K_h, st_h = h.solve(x0, xs, us, 8)
+    xs_o, us_o, K_o, st_o = o.solve(ref, None, x0, xs, us, 8)
+    assert xs_h.shape == (B, T + 1, 2 * nv) and us_h.shape == (B, T, nv) and K_h.shape == (B, T, nv, 2 * nv)
+    assert np.array_equal(st_h["iter"], st_o["iter"]) and np.array_equal(st_h["solved"], st_o["solved"])
+    np.testing.assert_allclose(xs_h, xs_o, rtol=1e-8, atol=1e-10)
+    np.testing.assert_allclose(us_h, us_o, rtol=1e-8, atol=1e-8)
+    assert rel(K_h, K_o) < 1e-7
+    np.testing.assert_allclose(st_h["kkt"], st_o["kkt"], rtol=1e-5, atol=1e-10)
+    us0, K0, x1, st1 = h.download_first()
+    np.testing.assert_array_equal(us0, us_h[:, 0])
+    np.testing.assert_array_equal(K0, K_h[:, 0])
+    np.testing.assert_array_equal(x1, xs_h[:, 1])
+    h.shift_warmstart()
+    xs_s, us_s, _, _ = h.download(want_K=False)
+    xs_so, us_so = o.shift_warmstart(xs_h, us_h)
+    np.testing.assert_allclose(xs_s, xs_so, rtol=1e-10, atol=1e-12)
+    np.testing.assert_allclose(us_s, us_so, rtol=1e-10, atol=1e-12)
+    h.close()
+
+
+def test_resident_sine_trajectory_nine_joints(hip_backend):
+    """The device-side reference generator and the resident MPC step for a padded model (nv = 9 at capacity 30)."""
+    table = _model(9, "panda_fingers")
+    tcp = table.frame_id("panda_hand_tcp")
+    B, T, dt = 3, 10, 0.01
+    running, terminal = workloads.goal_reaching_rows(tcp)
+    po = _abi.PackedOcp(9, [dt] * T, running, terminal)
+    h, o = hip_backend.HipOcp(table, po, B), Oracle(table, po, B)
+    q0, amp, puls, scale, t0 = workloads.sine_batch_params(B, nv=9, seed0=3, q0=np.zeros(9), lower=table.lower_position_limit,
+                                                           upper=table.upper_position_limit)
+    w = workloads.SINE_WEIGHTS
+    h.sine_trajectory(T + 8, dt, q0, amp, puls, scale, t0, w["w_q"], w["w_qdot"], w["w_effort"], w["w_pose"], tcp)
+    q, v, a, u, pose = h.traj_point(3)
+    assert q.shape == (B, 9) and u.shape == (B, 9)
+    np.testing.assert_allclose(u, o.rnea(q, v, a).reshape(B, 9), rtol=1e-10, atol=1e-10)
+    np.testing.assert_allclose(pose, o.frame_placement(tcp, q), rtol=1e-11, atol=1e-12)
+    h.mpc_step(0, 10, first=True)
+    us0, K0, x1, st = h.download_first()
+    assert us0.shape == (B, 9) and K0.shape == (B, 9, 18) and np.all(st["solved"] == 1)
+    h.mpc_step(1, 10, first=False)
+    assert np.all(h.download_first()[3]["solved"] == 1)
+    h.close()
+
+
+def test_constraints_on_a_five_joint_chain(hip_backend):
+    """ConstraintModelControlLimit / state bounds through the ADMM loop for a padded model: the pad components are unbounded."""
+    table = rt.chain_table(5, seed=77)
+    B, T = 2, 8
+    po0, ref, x0, xs, us = workloads.random_goal_problem(table, T, 0.02, B, seed=8)
+    lim = np.full(5, 6.0)
+    con = [_abi.ConstraintSpec(_abi.RES_CONTROL, lower=-lim, upper=lim, name="ctrl_limit")]
+    po = _abi.PackedOcp(5, [0.02] * T, po0.running, po0.terminal, max_qp_iters=100, running_constraints=con)
+    h, o = hip_backend.HipOcp(table, po, B), Oracle(table, po, B)
+    h.set_refs(ref)
+    xs_h, us_h, K_h, st_h = h.solve(x0, xs, us, 6)
+    xs_o, us_o, K_o, st_o = o.solve(ref, None, x0, xs, us, 6)
+    assert np.array_equal(st_h["iter"], st_o["iter"]) and np.array_equal(st_h["qp_iters"], st_o["qp_iters"])
+    np.testing.assert_allclose(xs_h, xs_o, rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(us_h, us_o, rtol=1e-5, atol=1e-5)
+    assert np.abs(us_h).max() <= 6.0 + 1e-3
+    h.close()
