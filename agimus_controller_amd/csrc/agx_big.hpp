@@ -412,7 +412,10 @@ __global__ void __launch_bounds__(128) k_ls_accept(const DevOcp *__restrict__ op
   }
   __syncthreads();
   const bool ok = flag != 0;
-  if (!ok && !last) return;
+  if (!ok && !last) {
+    if (tid == 0) S.flags |= 4;  // a step length was rejected in this solve
+    return;
+  }
   if (ok) {
     double *X = xs + (long long)b * (T + 1) * NX, *U = us + (long long)b * T * NU;
     const double *DX = dxs + (long long)b * (T + 1) * NX, *DU = dus + (long long)b * T * NU;

@@ -1117,7 +1117,7 @@ __global__ void __launch_bounds__(128) k_sqp_head(const DevOcp *__restrict__ op,
     if (conv) { S.solved = 1; S.done = 1; S.iter = iter; atomicAdd(n_done, 1); }
     else if ((mode & 1) && !(mode & 4)) {
       S.tiles_ok = 0;
-      if (dir_fail) sqp_iteration_end(S, false, 1.0 / 512.0, iter, max_iter, n_done);
+      if (dir_fail) { S.flags |= 4; sqp_iteration_end(S, false, 1.0 / 512.0, iter, max_iter, n_done); }
       else {
         what = 1;
         S.searching = 1;
@@ -1182,6 +1182,7 @@ __global__ void __launch_bounds__(128) k_sqp_accept(const DevOcp *__restrict__ o
       sqp_iteration_end(S, true, alpha, iter, max_iter, n_done);
     } else if (n + 1 < 10) {
       what = 2;
+      S.flags |= 4;  // a step length was rejected in this solve (the line search backtracked)
       S.ls_n = n + 1;
       double pr = S.preg, dr = S.dreg;
       bool stop;

@@ -44,6 +44,23 @@ __device__ __forceinline__ double row_ror8(double x) {
   const int lo = __double2loint(x), hi = __double2hiint(x);
   return __hiloint2double(__builtin_amdgcn_mov_dpp(hi, 0x128, 0xf, 0xf, false), __builtin_amdgcn_mov_dpp(lo, 0x128, 0xf, 0xf, false));
 }
+// Value of lane 16 G + (my column) for every lane: the 16 lanes of row group G broadcast to the four groups with gfx950's
+// v_permlane16_swap / v_permlane32_swap (VALU) instead of ds_bpermute through the LDS crossbar: swap(x, x) leaves
+// [x0 x0 x2 x2] / [x1 x1 x3 x3] (16-lane rows), the second swap copies the half that holds group G over the other one.
+// Tried for the pivot row of the elimination (7 fetches per node, -DAGX_MX_PERMLANE) and NOT used: four swaps per double, each
+// behind the two wait states the ISA wants after a VALU write of its operands, cost the chain more than the two
+// ds_bpermute pairs they replace, whose latency overlaps the reciprocal (measured: sweeps + 6 %, batch-1 step + 10 %).
+template <int G>
+__device__ __forceinline__ int bcast_group_b32(int x) {
+  const auto a = __builtin_amdgcn_permlane16_swap(x, x, false, false);
+  const int y = (G & 1) ? a[1] : a[0];
+  const auto b = __builtin_amdgcn_permlane32_swap(y, y, false, false);
+  return (G & 2) ? b[1] : b[0];
+}
+template <int G>
+__device__ __forceinline__ double bcast_group(double x) {
+  return __hiloint2double(bcast_group_b32<G>(__double2hiint(x)), bcast_group_b32<G>(__double2loint(x)));
+}
 // 1 / x to full precision with a dependent chain of 1 + 3 operations instead of 1 + 4 (fast_rcp): with e = 1 - x y0,
 // y0 (1 + e)(1 + e^2) = y0 (1 + e + e^2 + e^3), e^2 formed next to the first correction.  The pivots are on the
 // critical path of the sweep 7 times per node.
@@ -247,7 +264,11 @@ __device__ __forceinline__ void riccati_mx_body(const int b, const DevOcp *__res
 #else
         const double rp = chain_rcp(piv);
 #endif
-        const double rW = __shfl(Ww[s], 16 * gk + j, 64), rX = __shfl(Wx[s], 16 * gk + j, 64);
+#ifdef AGX_MX_PERMLANE  // measured slower (round 3): direction sweep 0.209 -> 0.222 ms, batch-1 step 0.325 -> 0.358 ms
+        const double rW = bcast_group<gk>(Ww[s]), rX = bcast_group<gk>(Wx[s]);
+#else
+        const double rW = __shfl(Ww[s], 16 * gk + j, 64), rX = __shfl(Wx[s], 16 * gk + j, 64);  // pivot row: lane (gk, j) to every group
+#endif
         // column k of my rows, with the pivot row's own entry zeroed (it is left untouched): off the reciprocal's chain
         const double c0 = row_bcast<k>(Ww[0]) * (s == 0 ? nz[gk] : 1.0), c1 = row_bcast<k>(Ww[1]) * (s == 1 ? nz[gk] : 1.0);
         const double f0 = c0 * rp, f1 = c1 * rp;

@@ -151,7 +151,7 @@ typedef struct agx_status {
   int32_t iter;     /* solver.iter                                              */
   int32_t qp_iters; /* solver.qp_iters                                          */
   int32_t solved;   /* return value of solver.solve()                           */
-  int32_t flags;    /* bit0: non-finite result, bit1: line search failed        */
+  int32_t flags;    /* bit0: non-finite result / discarded direction, bit1: a line search failed (all ten step lengths), bit2: a step length was rejected (the search backtracked) */
 } agx_status;
 
 /* Doubles per node in the derivative tile written by the node-parallel pass:

@@ -1402,6 +1402,7 @@ void solve_one(const Model &m, const Ocp &o, const double *ref, const int32_t *f
     double alpha = 1.0, used = 1.0;
     for (int n = 0; n < 10; ++n, alpha *= 0.5) {
       used = alpha;
+      if (n > 0) st->flags |= 4;  // a step length was rejected in this solve (agx_status.flags bit 2)
       for (size_t i = 0; i < (size_t)(T + 1) * nx; ++i) w.xs_try[i] = xs[i] + alpha * w.dir.dx[i];
       for (size_t i = 0; i < (size_t)T * nu; ++i) w.us_try[i] = us[i] + alpha * w.dir.du[i];
       double cost_try = 0.0, gap_try = 0.0, con_try = 0.0;

@@ -419,12 +419,12 @@ def _obstacle_entering_problem():
 
 def test_checker_discards_the_direction_when_quu_is_not_positive_definite():
     """the CPU checker on the case above: LLT failure -> direction discarded (flags bit 0), step rejected
-    (bit 1), regularisation x10 per iteration; the multipliers stay finite and the solve gets going
+    (bit 1; bit 2: step lengths were rejected), regularisation x10 per iteration; the multipliers stay finite and the solve gets going
     again once the regularisation is large enough."""
     table, po, ref, x0, xs, us, B = _obstacle_entering_problem()
     o = _oracle(table, po, B)
     xs2, us2, K2, st2 = o.solve(ref, None, x0, xs, us, 2)
-    assert st2["flags"][0] == 3 and st2["qp_iters"][0] == 1 and np.array_equal(xs2[0], xs[0])
+    assert st2["flags"][0] == 7 and st2["qp_iters"][0] == 1 and np.array_equal(xs2[0], xs[0])
     assert np.isnan(st2["kkt"][0])  # no KKT residual for a discarded direction
     assert st2["flags"][1] == 0 and st2["solved"][1] == 1
     xs10, us10, K10, st10 = _oracle(table, po, B).solve(ref, None, x0, xs, us, 10)
@@ -459,7 +459,7 @@ def test_hip_breakdown_of_the_factorisation_is_handled_like_the_checker():
             np.testing.assert_allclose(r_h[3]["merit"], r_o[3]["merit"], rtol=1e-9)
             np.testing.assert_allclose(r_h[0], r_o[0], rtol=1e-6, atol=1e-7)
             np.testing.assert_allclose(r_h[1], r_o[1], rtol=1e-5, atol=1e-5)
-            assert r_o[3]["flags"][0] == 3 and np.array_equal(r_o[0][0], xs[0]) and np.array_equal(r_h[0][0], xs[0])
+            assert r_o[3]["flags"][0] == 7 and np.array_equal(r_o[0][0], xs[0]) and np.array_equal(r_h[0][0], xs[0])
         else:
             # The recovery (100 ADMM iterations on a nearly singular QP) amplifies round-off: the checker built with AVX2 and
             # with AVX-512 vectorisation differs from itself by 2e-2 relative in the KKT value and 8e-3 in xs after the 10
