@@ -416,9 +416,8 @@ int launch_calc_qp(agx_ocp *o, bool running_only = false, bool term_only = false
       // large models: one workgroup per node, running and terminal nodes in one launch (agx_big_k1.hpp)
       (void)lanes; (void)running_only;
       if (term_only) return 0;  // the launch of the running nodes (profiled path) already covered the terminal ones
-      if (phase) return fail("launch_calc_qp: large models search with k_ls_trial_wg");
-      hipLaunchKernelGGL((agx::k_calc_qp_wg<NV>), dim3((int)(units + o->B)), dim3(256), 0, o->stream, o->d_model, o->d_ocp, o->d_dt, o->d_xs,
-                         o->d_us, o->rv, o->d_qt, o->d_aux, o->d_state);
+      hipLaunchKernelGGL((agx::k_calc_qp_wg<NV>), dim3((int)(units + o->B)), dim3(256), 0, o->stream, o->d_model, o->d_ocp, o->d_dt, xs_in,
+                         us_in, o->rv, o->d_qt, o->d_aux, o->d_state, phase);
     } else if (!lanes) {
       if (!term_only)
         hipLaunchKernelGGL((agx::k_calc_qp<NV, CH>), dim3((int)((units + 63) / 64)), dim3(64), 0, o->stream, o->d_model, o->d_ocp,
@@ -473,12 +472,10 @@ int launch_riccati(agx_ocp *o, int forward, bool pair = false, int iter = 0, con
   });
 }
 
-// K3 (node shares of the KKT residual, cost, gaps; du) and the head of the step: instance totals, convergence test and --
-// nv <= 7 -- the first trial iterate of the line search (the caller runs the trial rounds: line_search_rounds); large
-// models search right here with their value-only node kernel.
+// K3 (node shares of the KKT residual, cost, gaps; du) and the head of the step: instance totals, convergence test and the
+// first trial iterate of the line search (the caller runs the trial rounds: line_search_rounds).
 int launch_step(agx_ocp *o, int iter, int max_iter, int mode, bool with_node_kkt = true, bool with_step = true) {
   if (o->T + 1 > 512) return fail("step kernel supports horizons up to 511 nodes");
-  if (o->nv > 7 && !o->d_trial) HIPCHK(hipMalloc((void **)&o->d_trial, sizeof(double) * (size_t)o->B * (o->T + 1)));
   return dispatch(o->nv, o->chain, [&](auto NVc, auto CHc) -> int {
     constexpr int NV = decltype(NVc)::value;
     constexpr bool CH = decltype(CHc)::value;
@@ -504,29 +501,8 @@ int launch_step(agx_ocp *o, int iter, int max_iter, int mode, bool with_node_kkt
                            o->d_dx, o->d_w, o->d_du, o->d_nodestat, o->d_state);
     }
     if (!with_step) { HIPCHK(hipGetLastError()); return 0; }
-    if constexpr (NV <= 7) {
-      hipLaunchKernelGGL((agx::k_sqp_head<NV>), dim3(o->B), dim3(128), 0, o->stream, o->d_ocp, o->d_xs, o->d_us, o->d_dx, o->d_du, xs_t, us_t,
-                         o->d_nodestat, o->d_state, iter, max_iter, mode, o->d_ndone);
-    } else {
-      // large models: convergence test in k_step, line search node parallel
-      const bool split = (mode & 1) && !(mode & 4);
-      if (split) HIPCHK(hipMemsetAsync(o->d_ndone + 2, 0, sizeof(int), o->stream));  // instances in the line search: counted by k_step
-      hipLaunchKernelGGL((agx::k_step<NV>), dim3(o->B), dim3(128), 0, o->stream, o->d_ocp, o->d_nodestat, o->d_state, iter,
-                         split ? (mode | 8) : mode, o->d_ndone);
-      if (split) {
-        double alpha = 1.0;
-        for (int n = 0; n < 10; ++n, alpha *= 0.5) {
-          if (n == 0)
-            hipLaunchKernelGGL((agx::k_ls_trial_wg<NV, false>), dim3((int)nodes), dim3(256), 0, o->stream, o->d_model, o->d_ocp, o->d_dt,
-                               o->d_xs, o->d_us, o->rv, o->d_dx, o->d_du, o->d_trial, o->d_state, alpha, o->d_ndone + 2);
-          else
-            hipLaunchKernelGGL((agx::k_ls_trial_wg<NV, true>), dim3((int)(nodes < 1536 ? nodes : 1536)), dim3(256), 0, o->stream, o->d_model,
-                               o->d_ocp, o->d_dt, o->d_xs, o->d_us, o->rv, o->d_dx, o->d_du, o->d_trial, o->d_state, alpha, o->d_ndone + 2);
-          hipLaunchKernelGGL((agx::k_ls_accept<NV>), dim3(o->B), dim3(128), 0, o->stream, o->d_ocp, o->d_xs, o->d_us, o->d_dx, o->d_du,
-                             o->d_trial, o->d_state, alpha, n == 9 ? 1 : 0, iter, max_iter, o->d_ndone);
-        }
-      }
-    }
+    hipLaunchKernelGGL((agx::k_sqp_head<NV>), dim3(o->B), dim3(128), 0, o->stream, o->d_ocp, o->d_xs, o->d_us, o->d_dx, o->d_du, xs_t, us_t,
+                       o->d_nodestat, o->d_state, iter, max_iter, mode, o->d_ndone);
     HIPCHK(hipGetLastError());
     return 0;
   });
@@ -547,28 +523,31 @@ int launch_gains(agx_ocp *o, int gmode = 0) {
       hipLaunchKernelGGL((agx::k_riccati<NV, true>), dim3(o->B), dim3(64), 0, o->stream, o->d_ocp, o->d_dt, o->d_qt, o->d_aux, o->d_Kws,
                          o->d_kws, o->d_dx, o->d_w, o->d_du, o->d_Kout, o->d_state, 0, gmode);
     } else {
-      // large models: sigma-augmented tiles, LDS sweep, gains to u-space -- for every instance
+      // large models: sigma-augmented tiles, sweep (instances selected by gmode, as riccati_body), gains to u-space for
+      // the instances the sweep took
       const long long nodes = (long long)o->B * (o->T + 1);
+      const int gsel = gmode == 0 ? 1 : gmode;
       hipLaunchKernelGGL((agx::k_sigma_tile_big<NV>), dim3((int)nodes), dim3(256), 0, o->stream, o->d_ocp, o->d_qt, o->d_qt2, o->d_aux);
       bool swept = false;
       if constexpr (NV > 16) if (o->riccati_mfma) {
         hipLaunchKernelGGL((agx::k_riccati_mfma<NV>), dim3(o->B), dim3(256), 0, o->stream, o->d_ocp, o->d_dt, o->d_qt2, o->d_Kws, o->d_kws,
-                           o->d_dx, o->d_w, o->d_state, 0, 1);
+                           o->d_dx, o->d_w, o->d_state, 0, gsel);
         swept = true;
       }
       if (!swept)
       hipLaunchKernelGGL((agx::k_riccati_big<NV>), dim3(o->B), dim3(256), 0, o->stream, o->d_ocp, o->d_dt, o->d_qt2, o->d_Kws, o->d_kws,
-                         o->d_dx, o->d_w, o->d_state, 0, 1);
+                         o->d_dx, o->d_w, o->d_state, 0, gsel);
       if constexpr (NV > 16) {
         if (o->gains_mfma) {  // the dense feedback-gain GEMM on the matrix cores
-          hipLaunchKernelGGL((agx::k_gains_to_u_mfma<NV>), dim3(o->B * o->T), dim3(64), 0, o->stream, o->d_ocp, o->d_aux, o->d_Kws, o->d_Kout);
+          hipLaunchKernelGGL((agx::k_gains_to_u_mfma<NV>), dim3(o->B * o->T), dim3(64), 0, o->stream, o->d_ocp, o->d_aux, o->d_Kws, o->d_Kout,
+                             o->d_state);
           HIPCHK(hipGetLastError());
           return 0;
         }
       }
       const long long units = (long long)o->B * o->T * 64;
       hipLaunchKernelGGL((agx::k_gains_to_u_big<NV>), dim3((int)((units + 255) / 256)), dim3(256), 0, o->stream, o->d_ocp, o->d_aux,
-                         o->d_Kws, o->d_Kout);
+                         o->d_Kws, o->d_Kout, o->d_state);
     }
     HIPCHK(hipGetLastError());
     return 0;
@@ -774,19 +753,16 @@ int line_search_rounds(agx_ocp *o, int it, int max_iter, bool *need_k1, int *n_d
       constexpr int NV = decltype(NVc)::value;
       constexpr bool CH = decltype(CHc)::value;
       (void)CH;
-      if constexpr (NV > 7) return fail("line_search_rounds: nv <= 7");
-      else {
-        if (o->has_con) {
-          const long long nodes = (long long)o->B * (o->T + 1);
-          hipLaunchKernelGGL((agx::k_con_eval<NV, CH>), dim3((int)((nodes + 63) / 64)), dim3(64), 0, o->stream, o->d_model, o->d_ocp, xs_t, us_t,
-                             o->d_cg, o->d_cjac, o->d_nodestat, o->d_state, 1);
-        }
-        if (prof_mark(o, 2, true)) return -1;
-        hipLaunchKernelGGL((agx::k_sqp_accept<NV>), dim3(o->B), dim3(128), 0, o->stream, o->d_ocp, o->d_xs, o->d_us, o->d_dx, o->d_du, xs_t, us_t,
-                           o->d_qt, o->d_nodestat, o->d_state, it, max_iter, o->d_ndone);
-        HIPCHK(hipGetLastError());
-        return prof_mark(o, 2, false);
+      if constexpr (NV <= 7) if (o->has_con) {
+        const long long nodes = (long long)o->B * (o->T + 1);
+        hipLaunchKernelGGL((agx::k_con_eval<NV, CH>), dim3((int)((nodes + 63) / 64)), dim3(64), 0, o->stream, o->d_model, o->d_ocp, xs_t, us_t,
+                           o->d_cg, o->d_cjac, o->d_nodestat, o->d_state, 1);
       }
+      if (prof_mark(o, 2, true)) return -1;
+      hipLaunchKernelGGL((agx::k_sqp_accept<NV>), dim3(o->B), dim3(128), 0, o->stream, o->d_ocp, o->d_xs, o->d_us, o->d_dx, o->d_du, xs_t, us_t,
+                         o->d_qt, o->d_nodestat, o->d_state, it, max_iter, o->d_ndone);
+      HIPCHK(hipGetLastError());
+      return prof_mark(o, 2, false);
     });
     if (rc) return rc;
     const unsigned long long seq = ++o->seq;
@@ -823,12 +799,9 @@ int solve_resident(agx_ocp *o, int max_iter, double max_time, bool prologue_done
     if (reset_state(o)) return -1;
     hipLaunchKernelGGL(agx::k_pin_x0, dim3((o->B * o->nx + 255) / 256), dim3(256), 0, o->stream, o->d_xs, o->d_x0, o->B, o->T, o->nx);
   }
-  const bool small = o->nv <= 7;  // line search by derivative passes at the trial points (k_sqp_head / k_sqp_accept)
-  // Large models: the derivative pass of iteration it+1 is enqueued BEFORE the host waits for iteration it's "everyone
-  // finished" word (it skips finished instances).  nv <= 7: the same for the pass that only instances with stale tiles need.
-  const bool ahead = o->queue_ahead && !o->prof && max_time <= 0.0 && !small;
-  bool k1_queued = false;
-  bool need_k1 = true;  // nv <= 7: the first iteration, and iterations after one that ended with every trial rejected
+  // Every iteration after the first finds its tiles already there (the accepted trial of the line search left them); a
+  // derivative pass of its own is needed at the start and after an iteration that ended with every step length rejected.
+  bool need_k1 = true;
   // the exit fix-up of the gains is launched only if an instance can have finished (or the loop can
   // have ended) in an iteration whose direction sweep was not paired with the gains sweep
   bool need_fixup = false;
@@ -837,15 +810,14 @@ int solve_resident(agx_ocp *o, int max_iter, double max_time, bool prologue_done
     const bool pair = o->speculate && it >= 1 && !o->has_con && o->nv <= 7;  // large models: gains only on exit
     // derivative pass: running and terminal nodes in one launch; under agx_ocp_profile the running
     // nodes get their own launch so that the kernel the roofline is quoted on is timed alone
-    if (!k1_queued && (!small || need_k1)) {
-      if (o->prof && (!small || it == 0)) {
+    if (need_k1) {
+      if (o->prof && it == 0) {
         if (prof_mark(o, 0, true)) return -1;
         if (launch_calc_qp(o, true, false)) return -1;
         if (prof_mark(o, 0, false)) return -1;
         if (launch_calc_qp(o, false, true)) return -1;
       } else if (launch_calc_qp(o, false, false)) return -1;
     }
-    k1_queued = false;
     need_k1 = false;
     if (prof_mark(o, 1, true)) return -1;
     // from the second iteration on (where warm-started MPC steps converge) the gains sweep rides along
@@ -861,35 +833,14 @@ int solve_resident(agx_ocp *o, int max_iter, double max_time, bool prologue_done
     if (launch_step(o, it, max_iter, 1, !o->has_con, true)) return -1;
     if (prof_mark(o, 2, false)) return -1;
     int n_done = 0;
-    if (small) {
-      // The trial passes overwrite the tiles of this iterate.  Where the loop may end right after this iteration without a
-      // paired gains sweep (iteration cap, time limit, quorum), the sweep that yields the reported gains runs first --
-      // for the instances the head has not finished (those keep their tiles for the fix-up on exit).
-      if (!pair && !o->has_con && (last || max_time > 0.0 || o->quorum_sqp < 1.0)) {
-        if (launch_gains(o, 4)) return -1;
-      }
-      if (line_search_rounds(o, it, max_iter, &need_k1, &n_done)) return -1;
-      if (last) { need_fixup = need_fixup || !pair; break; }
-    } else {
-      if (last) { need_fixup = need_fixup || !pair; break; }
-      // early exit once every instance has finished (one 4-byte read back)
-      const unsigned long long seq = ++o->seq;
-      if (o->poll) {
-        if (publish(o, 0, 1, o->d_ndone, seq)) return -1;
-      } else {
-        o->h_ndone[0] = 0;
-        HIPCHK(hipMemcpyAsync(o->h_ndone, o->d_ndone, sizeof(int), hipMemcpyDeviceToHost, o->stream));
-        HIPCHK(hipEventRecord(o->ev_done, o->stream));
-      }
-      if (ahead) {
-        if (launch_calc_qp(o, false, false)) return -1;
-        k1_queued = true;
-      }
-      // waits for the finished count only, not for the pass queued behind it
-      if (o->poll) { if (wait_stamp(o, 1, seq)) return -1; }
-      else HIPCHK(hipEventSynchronize(o->ev_done));
-      n_done = (int)__atomic_load_n(o->h_ndone, __ATOMIC_ACQUIRE);
+    // The trial passes overwrite the tiles of this iterate.  Where the loop may end right after this iteration without a
+    // paired gains sweep (iteration cap, time limit, quorum), the sweep that yields the reported gains runs first --
+    // for the instances the head has not finished (those keep their tiles for the fix-up on exit).
+    if (!pair && !o->has_con && (last || max_time > 0.0 || o->quorum_sqp < 1.0)) {
+      if (launch_gains(o, 4)) return -1;
     }
+    if (line_search_rounds(o, it, max_iter, &need_k1, &n_done)) return -1;
+    if (last) { need_fixup = need_fixup || !pair; break; }
     if (!pair && n_done > prev_done) need_fixup = true;
     prev_done = n_done;
     if (n_done >= quorum_count(o->B, o->quorum_sqp)) {

@@ -19,7 +19,7 @@ template <int NV>
 __global__ void __launch_bounds__(256) k_riccati_big(const DevOcp *__restrict__ op, const double *__restrict__ dts,
                                                      const double *__restrict__ qts, double *__restrict__ Kws,
                                                      double *__restrict__ kws, double *__restrict__ dxs,
-                                                     double *__restrict__ wss, const DevState *__restrict__ st, int forward,
+                                                     double *__restrict__ wss, DevState *__restrict__ st, int forward,
                                                      int gains_pass) {
   constexpr int NX = 2 * NV, R = 3 * NV, GC = 3 * NV, CS = 3 * NV + 2;
   typedef QT<NV> Q;
@@ -32,9 +32,18 @@ __global__ void __launch_bounds__(256) k_riccati_big(const DevOcp *__restrict__ 
   __shared__ double rowbuf[2][3 * NV + 8], colbuf[2][3 * NV + 8];
   const DevOcp &o = *op;
   const int T = o.T, b = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
-  const DevState &S = st[b];
+  DevState &S = st[b];
   if (!gains_pass && (S.done || S.admm_conv)) return;
-  const double dreg = gains_pass ? (S.solved ? S.dreg : S.gains_dreg) : S.dreg;
+  // gains_pass selects the instances of the sigma sweep like gmode of riccati_body: 1 everyone (agx_ocp_direction, timing),
+  // 2 the fix-up on exit (instances whose last direction has no gains yet), 4 the unfinished instances before the line search of
+  // an iteration the loop may end with (current regularisation).  ls_acc tells k_gains_to_u_* which instances were swept.
+  if (gains_pass) {
+    const bool run = gains_pass == 1 || (gains_pass == 4 && !S.done) || (gains_pass == 2 && S.gains_iter != S.dir_iter);
+    __syncthreads();  // everyone has read the state before it is written
+    if (threadIdx.x == 0) { S.ls_acc = run ? 1 : 0; if (run && gains_pass != 1) S.gains_iter = S.dir_iter; }
+    if (!run) return;
+  }
+  const double dreg = (gains_pass && gains_pass != 4) ? (S.solved ? S.dreg : S.gains_dreg) : S.dreg;
   const double *qb = qts + (long long)b * (T + 1) * Q::SIZE;
   double *Kw = Kws + (long long)b * T * NV * NX, *kw = kws + (long long)b * T * NV;
   // value function of the terminal node
@@ -381,76 +390,11 @@ __global__ void __launch_bounds__(256) k_sigma_tile_big(const DevOcp *__restrict
   }
 }
 
-// ---------------------------------------------------------------------------
-// Line search for large models, split so that the trial evaluation is node parallel:
-//   k_ls_trial_wg(alpha)  (agx_big_k1.hpp) one workgroup per node: merit share of the node at xs + alpha dx, us + alpha du
-//   k_ls_accept(alpha)    one workgroup per instance: merit_try < merit ? commit the step : keep trying
-// run for alpha = 1, 1/2, ... 2^-9; instances that accepted (or finished) drop out.
-// ---------------------------------------------------------------------------
-template <int NV>
-__global__ void __launch_bounds__(128) k_ls_accept(const DevOcp *__restrict__ op, double *__restrict__ xs, double *__restrict__ us,
-                                                   const double *__restrict__ dxs, const double *__restrict__ dus,
-                                                   const double *__restrict__ trial, DevState *__restrict__ st, double alpha,
-                                                   int last, int iter, int max_iter, int *__restrict__ n_done) {
-  constexpr int NX = 2 * NV, NU = NV;
-  __shared__ double red[2];
-  __shared__ int flag;
-  const DevOcp &o = *op;
-  const int T = o.T, b = blockIdx.x, tid = threadIdx.x, nw = blockDim.x >> 6;
-  DevState &S = st[b];
-  if (n_done[2] == 0) return;  // nobody is searching any more
-  if (S.done || S.ls_acc) return;
-  double part = 0.0;
-  for (int t = tid; t <= T; t += blockDim.x) part += trial[(long long)b * (T + 1) + t];
-  part = wave_sum(part);
-  if ((tid & 63) == 0) red[tid >> 6] = part;
-  __syncthreads();
-  if (tid == 0) {
-    double tot = 0.0;
-    for (int w = 0; w < nw; ++w) tot += red[w];
-    flag = (S.merit > tot) ? 1 : 0;
-  }
-  __syncthreads();
-  const bool ok = flag != 0;
-  if (!ok && !last) {
-    if (tid == 0) S.flags |= 4;  // a step length was rejected in this solve
-    return;
-  }
-  if (ok) {
-    double *X = xs + (long long)b * (T + 1) * NX, *U = us + (long long)b * T * NU;
-    const double *DX = dxs + (long long)b * (T + 1) * NX, *DU = dus + (long long)b * T * NU;
-    for (int e = tid; e < (T + 1) * NX; e += blockDim.x) X[e] += alpha * DX[e];
-    for (int e = tid; e < T * NU; e += blockDim.x) U[e] += alpha * DU[e];
-  }
-  if (tid == 0) {
-    // same epilogue as k_step: regularisation schedule on the step length, iteration bookkeeping
-    if (!ok) S.flags |= 2;
-    double pr = S.preg, dr = S.dreg;
-    S.gains_preg = pr; S.gains_dreg = dr;
-    if (alpha > 0.5) { pr = fmax(pr / 10.0, kRegMin); dr = fmax(dr / 10.0, kRegMin); }
-    bool stop = false;
-    if (alpha <= 0.01) {
-      pr = fmin(pr * 10.0, kRegMax);
-      dr = fmin(dr * 10.0, kRegMax);
-      if (pr == kRegMax) stop = true;
-    }
-    S.preg = pr; S.dreg = dr;
-    S.ls_acc = 1;
-    atomicSub(n_done + 2, 1);
-    if (stop) {
-      S.done = 1;
-      S.iter = iter + 1;
-      atomicAdd(n_done, 1);
-    } else if (iter + 1 == max_iter) {
-      S.iter = max_iter;
-    }
-  }
-}
-
 // K = M Kw - taux for large nv: 64 lanes per node, lane j < 2 nv = column of K
 template <int NV>
 __global__ void __launch_bounds__(256) k_gains_to_u_big(const DevOcp *__restrict__ op, const double *__restrict__ auxs,
-                                                        const double *__restrict__ Kws, double *__restrict__ Kout) {
+                                                        const double *__restrict__ Kws, double *__restrict__ Kout,
+                                                        const DevState *__restrict__ st) {
   constexpr int NX = 2 * NV;
   typedef AUX<NV> A;
   const DevOcp &o = *op;
@@ -460,6 +404,7 @@ __global__ void __launch_bounds__(256) k_gains_to_u_big(const DevOcp *__restrict
   const int j = (int)(unit & 63);
   if (node >= (long long)o.B * T || j >= NX) return;
   const int b = (int)(node / T), t = (int)(node % T);
+  if (!st[b].ls_acc) return;  // the sigma sweep in front of this launch skipped the instance: its Kws hold direction gains
   const double *ax = auxs + ((long long)b * (T + 1) + t) * A::SIZE;
   const double *Kw = Kws + node * NV * NX;
   double *K = Kout + node * NV * NX;
@@ -478,7 +423,8 @@ __global__ void __launch_bounds__(256) k_gains_to_u_big(const DevOcp *__restrict
 typedef double agx_d4 __attribute__((ext_vector_type(4)));
 template <int NV>
 __global__ void __launch_bounds__(64) k_gains_to_u_mfma(const DevOcp *__restrict__ op, const double *__restrict__ auxs,
-                                                        const double *__restrict__ Kws, double *__restrict__ Kout) {
+                                                        const double *__restrict__ Kws, double *__restrict__ Kout,
+                                                        const DevState *__restrict__ st) {
   static_assert(NV > 16 && NV <= 32, "tiling below assumes 16 < nv <= 32");
   constexpr int NX = 2 * NV;
   typedef AUX<NV> A;
@@ -486,6 +432,7 @@ __global__ void __launch_bounds__(64) k_gains_to_u_mfma(const DevOcp *__restrict
   const int T = o.T, lane = threadIdx.x;
   const long long node = blockIdx.x;  // b * T + t
   const int b = (int)(node / T), t = (int)(node % T);
+  if (!st[b].ls_acc) return;  // not swept by the sigma pass in front of this launch
   const double *ax = auxs + ((long long)b * (T + 1) + t) * A::SIZE;
   const double *Kw = Kws + node * NV * NX;
   double *K = Kout + node * NV * NX;

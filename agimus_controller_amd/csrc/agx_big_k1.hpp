@@ -709,7 +709,7 @@ template <int NV>
 __global__ void __launch_bounds__(256, AGX_WG_MINWAVES) k_calc_qp_wg(const DevModel *__restrict__ mp, const DevOcp *__restrict__ op,
                                                     const double *__restrict__ dts, const double *__restrict__ xs,
                                                     const double *__restrict__ us, RefView rv, double *__restrict__ qts,
-                                                    double *__restrict__ auxs, const DevState *__restrict__ st) {
+                                                    double *__restrict__ auxs, const DevState *__restrict__ st, int phase) {
   constexpr int NX = 2 * NV;
   __shared__ WgNode<NV> L;
   const DevOcp &o = *op;
@@ -717,55 +717,16 @@ __global__ void __launch_bounds__(256, AGX_WG_MINWAVES) k_calc_qp_wg(const DevMo
   const long long unit = blockIdx.x, n_run = (long long)o.B * T;
   const bool term = unit >= n_run;
   const int b = term ? (int)(unit - n_run) : (int)(unit / T), t = term ? T : (int)(unit % T);
-  if (st[b].done) return;
+  if (!k1_active(st[b], phase)) return;  // phase 1: the trial points of the instances in the line search (k_sqp_head / k_sqp_accept)
   const long long node = (long long)b * (T + 1) + t;
   WgIn in;
   in.x = xs + node * NX; in.dx = nullptr; in.xn = in.x + NX; in.dxn = nullptr;
   in.u = us + ((long long)b * T + t) * NV; in.du = nullptr;
-  in.alpha = 0.0; in.preg = st[b].preg; in.mu_dyn = o.mu_dyn;
+  in.alpha = 0.0; in.preg = k1_preg(st[b], phase); in.mu_dyn = o.mu_dyn;
   in.ref = ref_at(rv, b, t, T); in.stride = o.stride; in.frames = frames_at(rv, b, t, T);
   double *qt = qts + node * QT<NV>::SIZE, *ax = auxs + node * AUX<NV>::SIZE;
   if (term) { in.dt = 0.0; wg_node<NV, true, true>(L, *mp, o.rows[1], in, qt, ax); }
   else { in.dt = dts[t]; wg_node<NV, false, true>(L, *mp, o.rows[0], in, qt, ax); }
-}
-
-// Line-search trial for large models: merit share of every node at (xs + alpha dx, us + alpha du).
-// Ten step lengths are launched per SQP iteration and nearly always only the first finds anyone searching
-// (n_pending: counted by k_step, released by k_ls_accept).  The first is launched with one workgroup per node; the
-// others (STRIDE) with a small grid that strides over the nodes, so that an empty launch dispatches 1.5 k workgroups
-// instead of 26 k -- as its own instantiation: the loop costs the one-node-per-workgroup kernel 7 % when compiled in.
-template <int NV, bool STRIDE>
-__global__ void __launch_bounds__(256) k_ls_trial_wg(const DevModel *__restrict__ mp, const DevOcp *__restrict__ op,
-                                                     const double *__restrict__ dts, const double *__restrict__ xs,
-                                                     const double *__restrict__ us, RefView rv, const double *__restrict__ dxs,
-                                                     const double *__restrict__ dus, double *__restrict__ trial,
-                                                     const DevState *__restrict__ st, double alpha,
-                                                     const int *__restrict__ n_pending) {
-  constexpr int NX = 2 * NV;
-  __shared__ WgNode<NV> L;
-  const DevOcp &o = *op;
-  const int T = o.T;
-  if (*n_pending == 0) return;
-  const long long n_nodes = STRIDE ? (long long)o.B * (T + 1) : (long long)blockIdx.x + 1;
-  for (long long node = blockIdx.x; node < n_nodes; node += gridDim.x) {
-    const int b = (int)(node / (T + 1)), t = (int)(node % (T + 1));
-    const DevState &S = st[b];
-    if (S.done || S.ls_acc) {
-      if (STRIDE) continue;  // uniform over the workgroup
-      return;
-    }
-    WgIn in;
-    in.x = xs + node * NX; in.dx = dxs + node * NX; in.xn = in.x + NX; in.dxn = in.dx + NX;
-    in.u = us + ((long long)b * T + t) * NV; in.du = dus + ((long long)b * T + t) * NV;
-    in.alpha = alpha; in.preg = 0.0; in.mu_dyn = o.mu_dyn;
-    in.ref = ref_at(rv, b, t, T); in.stride = o.stride; in.frames = frames_at(rv, b, t, T);
-    double part;
-    if (t == T) { in.dt = 0.0; part = wg_node<NV, true, false>(L, *mp, o.rows[1], in, nullptr, nullptr); }
-    else { in.dt = dts[t]; part = wg_node<NV, false, false>(L, *mp, o.rows[0], in, nullptr, nullptr); }
-    if (threadIdx.x == 0) trial[node] = part;
-    if (!STRIDE) return;
-    __syncthreads();  // the node's LDS is reused by the next one
-  }
 }
 
 // One semi-implicit Euler step (OCPBaseCroco.integrate, ocp_base_croco.py:184-189): forward dynamics only, one
@@ -834,7 +795,7 @@ template <int NV>
 __global__ void __launch_bounds__(256) k_riccati_mfma(const DevOcp *__restrict__ op, const double *__restrict__ dts,
                                                       const double *__restrict__ qts, double *__restrict__ Kws,
                                                       double *__restrict__ kws, double *__restrict__ dxs,
-                                                      double *__restrict__ wss, const DevState *__restrict__ st, int forward,
+                                                      double *__restrict__ wss, DevState *__restrict__ st, int forward,
                                                       int gains_pass) {
   static_assert(NV > 16 && NV <= 32 && NV % 2 == 0, "tiling below: 2 nv <= 64 result rows, nv / 2 right-hand sides per wave");
   constexpr int NX = 2 * NV, LV = NX + 1, LQ = NV + 1, NR = NV / 2 + 1;  // right-hand sides per wave: NV / 2 columns of Qwx (+ qw on wave 3)
@@ -844,9 +805,18 @@ __global__ void __launch_bounds__(256) k_riccati_mfma(const DevOcp *__restrict__
   const DevOcp &o = *op;
   const int T = o.T, b = blockIdx.x, tid = threadIdx.x, nt = 256, lane = tid & 63, wave = tid >> 6;
   const int l15 = lane & 15, l4 = lane >> 4;
-  const DevState &S = st[b];
+  DevState &S = st[b];
   if (!gains_pass && (S.done || S.admm_conv)) return;
-  const double dreg = gains_pass ? (S.solved ? S.dreg : S.gains_dreg) : S.dreg;
+  // gains_pass selects the instances of the sigma sweep like gmode of riccati_body: 1 everyone (agx_ocp_direction, timing),
+  // 2 the fix-up on exit (instances whose last direction has no gains yet), 4 the unfinished instances before the line search of
+  // an iteration the loop may end with (current regularisation).  ls_acc tells k_gains_to_u_* which instances were swept.
+  if (gains_pass) {
+    const bool run = gains_pass == 1 || (gains_pass == 4 && !S.done) || (gains_pass == 2 && S.gains_iter != S.dir_iter);
+    __syncthreads();  // everyone has read the state before it is written
+    if (threadIdx.x == 0) { S.ls_acc = run ? 1 : 0; if (run && gains_pass != 1) S.gains_iter = S.dir_iter; }
+    if (!run) return;
+  }
+  const double dreg = (gains_pass && gains_pass != 4) ? (S.solved ? S.dreg : S.gains_dreg) : S.dreg;
   const double *qb = qts + (long long)b * (T + 1) * Q::SIZE;
   double *Kw = Kws + (long long)b * T * NV * NX, *kw = kws + (long long)b * T * NV;
   {  // value function of the terminal node

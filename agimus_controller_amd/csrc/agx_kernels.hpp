@@ -28,7 +28,7 @@ struct DevState {
   double rho_sparse;             // persists across solves (SolverCSQP reset_rho = false); 0 = not initialised
   double con;                    // l1 norm of the constraint violation at the last evaluation
   int admm_conv, admm_iter;      // QP converged in this SQP iteration / ADMM iterations done
-  int ls_acc;                    // split line search (large models): step accepted in this SQP iteration
+  int ls_acc;                    // (unused; kept for the layout)
   int admm_refactor;             // ADMM: the Hessian part of the augmented tiles changed (first iteration / new rho)
   int dir_fail;                  // the last backward sweep met a non-positive / non-finite pivot (Quu not positive definite)
   // line search by derivative passes at the trial points (nv <= 7: k_sqp_head / k_sqp_accept)
@@ -1009,7 +1009,7 @@ AGX_UNROLL_NV
 // ---------------------------------------------------------------------------
 // K4: the step of one SQP iteration (SolverCSQP::solve after computeDirection).
 //
-// nv <= 7 (k_sqp_head / k_sqp_accept): THE LINE-SEARCH TRIAL IS THE NEXT DERIVATIVE PASS.  Upstream a trial evaluates
+// THE LINE-SEARCH TRIAL IS THE NEXT DERIVATIVE PASS (k_sqp_head / k_sqp_accept, every model size).  Upstream a trial evaluates
 // problem.calc at (xs + alpha dx, us + alpha du) and the accepted point is evaluated again, with derivatives, at the start of
 // the next iteration.  Here k_sqp_head writes the trial iterate, the node-parallel derivative kernel (K1, and k_con_eval of
 // constrained problems) runs AT THE TRIAL POINT, over the tiles of the current iterate, which nobody needs any more
@@ -1019,9 +1019,7 @@ AGX_UNROLL_NV
 // length goes through the same two launches (the host learns from a counter that somebody is still searching).  With
 // alpha = 1 accepted -- every step of a warm-started MPC loop -- an SQP iteration costs ONE node evaluation instead of two,
 // and no kernel holds a one-lane-per-node evaluation of a node any more (the step kernel of constrained problems used to:
-// 512 VGPRs, 450 spilled registers).
-//
-// large models (k_step + k_ls_trial_wg / k_ls_accept, agx_big.hpp): convergence test here, value-only trials node parallel.
+// 512 VGPRs, 450 spilled registers; large models ran ten value-only trial launches per iteration).
 // ---------------------------------------------------------------------------
 // crocoddyl / mim_solvers regularisation schedule on the step length (th_stepdec 0.5, th_stepinc 0.01, factor 10)
 __device__ __forceinline__ void reg_schedule(double used, double &pr, double &dr, bool &stop) {
@@ -1203,46 +1201,6 @@ __global__ void __launch_bounds__(128) k_sqp_accept(const DevOcp *__restrict__ o
     for (int e = tid; e < T * NU; e += blockDim.x) us[ou + e] = us_t[ou + e];
   } else if (flag == 2) {
     write_trial_iterate<NV>(o, b, s_alpha, xs, us, dxs, dus, xs_t, us_t);
-  }
-}
-
-// Large models: instance totals and the convergence test; the line search runs in k_ls_trial_wg / k_ls_accept (mode bit3),
-// which count the searching instances in n_done[2].  mode bits as k_sqp_head.
-template <int NV>
-__global__ void __launch_bounds__(128) k_step(const DevOcp *__restrict__ op, const double *__restrict__ nodestat,
-                                              DevState *__restrict__ st, int iter, int mode, int *__restrict__ n_done) {
-  __shared__ double red[8];
-  const DevOcp &o = *op;
-  const int T = o.T, b = blockIdx.x, tid = threadIdx.x;
-  DevState &S = st[b];
-  if (S.done) return;
-  double kkt = 0.0, csum = 0.0, gsum = 0.0;
-  for (int t = tid; t <= T; t += blockDim.x) {
-    const double *ns = nodestat + ((long long)b * (T + 1) + t) * 4;
-    kkt = fmax(kkt, ns[0]);
-    csum += ns[1];
-    gsum += ns[2];
-  }
-  kkt = wave_max(kkt);
-  csum = wave_sum(csum);
-  gsum = wave_sum(gsum);
-  if ((tid & 63) == 0) { red[tid >> 6] = kkt; red[2 + (tid >> 6)] = csum; red[4 + (tid >> 6)] = gsum; }
-  __syncthreads();
-  if (tid == 0) {
-    double kk = fmax(red[0], red[1]);
-    const double cc = red[2] + red[3], gg = red[4] + red[5];
-    if (S.dir_fail) kk = __builtin_nan("");
-    S.kkt = kk; S.cost = cc; S.gap = gg; S.con = 0.0; S.merit = cc + o.mu_dyn * gg;
-    S.qp_iters = 1;
-    S.admm_conv = 0;
-    S.ls_acc = 0;
-    if (!(mode & 4)) S.dir_iter = iter;
-    if (!(kk == kk)) S.flags |= 1;
-    const bool conv = (kk <= o.tol) && (mode & 1) && !(mode & 4);
-    if (conv) { S.solved = 1; S.done = 1; S.iter = iter; atomicAdd(n_done, 1); }
-    // n_done[2] counts the instances that still look for a step length, so that the trial / accept launches behind this
-    // one can leave at their first instruction once it is zero
-    if (!conv && (mode & 8) && (mode & 1)) atomicAdd(n_done + 2, 1);
   }
 }
 
