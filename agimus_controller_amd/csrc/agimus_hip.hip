@@ -91,7 +91,7 @@ struct agx_ocp {
   // iterate (solved = 0 / qp_iters = max_qp_iters) and continue from it at the next MPC step, as a lone controller
   // that ran into max_solve_time would.  1.0 = wait for everyone (the default).
   double quorum_sqp = 1.0, quorum_qp = 1.0;
-  bool queue_ahead = true;  // AGX_QUEUE_AHEAD=0: next derivative pass only after the host saw the finished count (profiling: no empty launches)
+  bool no_empty = false;  // AGX_NO_EMPTY_LAUNCHES=1 (profiling): the host asks after the head of the step whether anybody searches and skips the trial launches otherwise, so that per-kernel averages are those of working launches
   double *d_ref = nullptr;  // owned tile [B][T+1][stride]
   // asynchronous reference upload (agx_ocp_set_refs_async): second tile / frame table filled by the copy stream while the
   // solver works on the first; the next solve waits for the copy's event and swaps the two
@@ -839,7 +839,12 @@ int solve_resident(agx_ocp *o, int max_iter, double max_time, bool prologue_done
     if (!pair && !o->has_con && (last || max_time > 0.0 || o->quorum_sqp < 1.0)) {
       if (launch_gains(o, 4)) return -1;
     }
-    if (line_search_rounds(o, it, max_iter, &need_k1, &n_done)) return -1;
+    bool searching = true;
+    if (o->prof || o->no_empty) {  // timing / profiling runs: no launches that find nothing to do
+      if (read_int(o, o->d_ndone, 0, 1, &n_done)) return -1;
+      searching = n_done < o->B;
+    }
+    if (searching && line_search_rounds(o, it, max_iter, &need_k1, &n_done)) return -1;
     if (last) { need_fixup = need_fixup || !pair; break; }
     if (!pair && n_done > prev_done) need_fixup = true;
     prev_done = n_done;
@@ -1006,7 +1011,7 @@ int agx_ocp_create(const agx_model *m, const agx_ocp_desc *d, int batch, int dev
   if (const char *e = getenv("AGX_RICCATI_MFMA")) o->riccati_mfma = (e[0] != '0');
   if (const char *e = getenv("AGX_RICCATI_MX")) o->riccati_mx = (e[0] != '0');
   if (const char *e = getenv("AGX_FUSED_KKT")) o->fuse_kkt = (e[0] != '0');
-  if (const char *e = getenv("AGX_QUEUE_AHEAD")) o->queue_ahead = (e[0] != '0');
+  if (const char *e = getenv("AGX_NO_EMPTY_LAUNCHES")) o->no_empty = (e[0] != '0');
   if (const char *e = getenv("AGX_K1_FUSED")) o->k1_fused = (e[0] != '0');
   o->T = d->horizon; o->B = batch; o->device = device;
   o->tile = AGX_TILE_DOUBLES(o->nv);

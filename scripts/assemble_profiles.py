@@ -1,5 +1,5 @@
 """Turns the raw output of scripts/collect_profiles.sh (gpurun_out/prof_<workload>/) into the committed summaries under
-profiles/:  r02_kernel_stats_<workload>.txt, r02_pmc_<workload>.txt and the HBM byte counts bench.py cites
+profiles/:  r03_kernel_stats_<workload>.txt, r03_pmc_<workload>.txt and the HBM byte counts bench.py cites
 (profiles/pmc_traffic.json: bytes per launch of the derivative kernel, bytes per MPC step of all kernels).
 HBM bytes = WRITE_SIZE + 2 x FETCH_SIZE, both in KiB per dispatch (MI355X_MICROARCH.md, HBM section: WRITE_SIZE exact for
 streaming stores, FETCH_SIZE reports half of the bytes of wide coalesced reads on gfx950: doubled = upper bound)."""
@@ -27,17 +27,20 @@ def parse_pmc(path):
     return out
 
 
+ROUND = "r03"
+
+
 def main():
     traffic_file = ROOT / "profiles" / "pmc_traffic.json"
     traffic = json.loads(traffic_file.read_text()) if traffic_file.exists() else {}
     for w in sys.argv[1:]:
         src = ROOT / "gpurun_out" / f"prof_{w}"
         B, T = SHAPE[w]
-        cmd = f"AGX_QUEUE_AHEAD=0 AGX_K1_FUSED=0 rocprofv3 --kernel-trace --stats -- python3 bench.py --workload {w} --no-cpu-baseline --no-batch1 --steps 20 --warmup 3"
-        head = (f"# {cmd}   (MI355X, ROCm 7.2, round 2; scripts/collect_profiles.sh {w})\n"
+        cmd = f"AGX_NO_EMPTY_LAUNCHES=1 AGX_K1_FUSED=0 rocprofv3 --kernel-trace --stats -- python3 bench.py --workload {w} --no-cpu-baseline --no-batch1 --steps 20 --warmup 3"
+        head = (f"# {cmd}   (MI355X, ROCm 7.2, round 3; scripts/collect_profiles.sh {w})\n"
                 f"# B = {B} instances, T = {T}; {N_STEPS} MPC steps in the run; summary of the rocpd database (scripts/rocpd_stats.py).\n"
-                "# AGX_QUEUE_AHEAD=0 suppresses the speculative (empty) derivative-pass launches, AGX_K1_FUSED=0 launches running and terminal nodes separately.\n")
-        (ROOT / "profiles" / f"r02_kernel_stats_{w}.txt").write_text(head + (src / "kernel_stats.txt").read_text())
+                "# AGX_NO_EMPTY_LAUNCHES=1 skips the trial launches of the line search when nobody searches, AGX_K1_FUSED=0 launches running and terminal nodes separately.\n")
+        (ROOT / "profiles" / f"{ROUND}_kernel_stats_{w}.txt").write_text(head + (src / "kernel_stats.txt").read_text())
         fetch, write = parse_pmc(src / "pmc_fetch.txt"), parse_pmc(src / "pmc_write.txt")
         lines = [f"# HBM counters of the same command, separate passes: rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (KiB per dispatch).",
                  "# bytes = WRITE_SIZE + 2 x FETCH_SIZE (gfx950 read-side correction of MI355X_MICROARCH.md: upper bound for narrow reads).",
@@ -61,8 +64,8 @@ def main():
             for name, d in parse_pmc(mf).items():
                 if d.get("SQ_INSTS_VALU_MFMA_MOPS_F64", (0, 0))[0] > 0:
                     lines.append(f"#   {name[:60]:60s} MFMA_MOPS_F64 {d['SQ_INSTS_VALU_MFMA_MOPS_F64'][1]:14.0f}  MFMA_BUSY_CYCLES {d['SQ_VALU_MFMA_BUSY_CYCLES'][1]:14.0f}  SQ_BUSY_CYCLES {d['SQ_BUSY_CYCLES'][1]:14.0f}")
-        (ROOT / "profiles" / f"r02_pmc_{w}.txt").write_text("\n".join(lines) + "\n")
-    traffic["_source"] = "profiles/r02_pmc_<workload>.txt"
+        (ROOT / "profiles" / f"{ROUND}_pmc_{w}.txt").write_text("\n".join(lines) + "\n")
+    traffic["_source"] = f"profiles/{ROUND}_pmc_<workload>.txt"
     traffic["_comment"] = ("HBM bytes from separate rocprofv3 --pmc passes: WRITE_SIZE + 2 x FETCH_SIZE (gfx950 read-side correction, upper bound), "
                            "KiB = 1024 B; '<kernel>:<workload>,B,T' = per launch of the derivative kernel, 'step:<workload>,B,T' = all kernels of one MPC step")
     traffic_file.write_text(json.dumps(traffic, indent=1) + "\n")

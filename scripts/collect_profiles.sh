@@ -4,8 +4,9 @@
 # kernel-trace statistics and the two HBM PMC passes of one bench workload, in separate rocprofv3 runs (counters
 # never together with other trace domains), the program right after `--`.  The humanoid workload adds the fp64
 # matrix-core counter pass.
-# AGX_QUEUE_AHEAD=0: no speculative (empty) derivative-pass launches, so per-kernel averages are those
-# of real launches only.  AGX_K1_FUSED=0: the running-node derivative kernel as its own launch.
+# AGX_NO_EMPTY_LAUNCHES=1: the trial launches of the line search are skipped when the head of the step finished every
+# instance, so per-kernel averages are those of working launches only.  AGX_K1_FUSED=0: the running-node derivative kernel as
+# its own launch.
 set -e
 W=${1:-sine}
 shift || true
@@ -13,7 +14,7 @@ ROOT=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$ROOT/gpurun_out/prof_$W
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-export AGX_QUEUE_AHEAD=0
+export AGX_NO_EMPTY_LAUNCHES=1
 export AGX_K1_FUSED=0   # running / terminal nodes as separate launches: the kernel the roofline is quoted on appears alone
 ARGS="--workload $W --no-cpu-baseline --no-batch1 --steps 20 --warmup 3 $@"
 rocprofv3 --kernel-trace --stats -d $OUT/trace -- python3 $ROOT/bench.py $ARGS > $OUT/trace.log 2>&1
