@@ -1065,8 +1065,7 @@ int agx_ocp_create(const agx_model *m, const agx_ocp_desc *d, int batch, int dev
   o->ho.eps_abs = d->eps_abs;
   o->ho.eps_rel = d->eps_rel;
   o->ho.use_filter = d->use_filter_line_search ? 1 : 0;
-  if (o->ho.use_filter && o->nv > 7) { delete o; return fail("agx_ocp_create: the filter line search is implemented for nv <= 7"); }
-  if (o->ho.use_filter && (o->ho.rows[0].general || o->ho.rows[1].general)) { delete o; return fail("agx_ocp_create: the filter line search with ControlGrav / FrameVelocity rows is not implemented"); }
+  // (the filter test lives in k_sqp_accept, which serves every model size and every kind of cost row)
   if (o->has_con && o->nv > 7) { delete o; return fail("agx_ocp_create: constraints need the register Riccati kernel (nv <= 7)"); }
   {
     auto n_frame_rows = [](const DevRows &r) {

@@ -137,3 +137,22 @@ def test_hip_general_rows_tiles_direction_and_solve(hip_backend, model, ref_fram
     off = table.nv + 2 * table.nv + 6
     np.testing.assert_allclose(res[0, 2], rvec[off:off + 6], atol=1e-10)
     h.close()
+
+
+
+@pytest.mark.gpu
+def test_filter_line_search_with_general_rows(hip_backend):
+    """use_filter_line_search = True together with ControlGrav / FrameVelocity rows (refused until round 3: the filter test
+    now lives in the accept kernel every path shares)."""
+    table = rt.panda_table(0.1)
+    B, T = 3, 8
+    po0, ref, x0, xs, us = general_problem(table, T, B, 31)
+    po = _abi.PackedOcp(7, [0.01] * T, po0.running, po0.terminal, use_filter_line_search=True)
+    h, o = hip_backend.HipOcp(table, po, B), Oracle(table, po, B)
+    h.set_refs(ref)
+    xs_h, us_h, K_h, st_h = h.solve(x0, xs, us, 8)
+    xs_o, us_o, K_o, st_o = o.solve(ref, None, x0, xs, us, 8)
+    assert np.array_equal(st_h["iter"], st_o["iter"]) and np.array_equal(st_h["flags"], st_o["flags"])
+    np.testing.assert_allclose(xs_h, xs_o, rtol=1e-8, atol=1e-10)
+    np.testing.assert_allclose(us_h, us_o, rtol=1e-8, atol=1e-8)
+    h.close()

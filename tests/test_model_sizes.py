@@ -140,3 +140,22 @@ def test_constraints_on_a_five_joint_chain(hip_backend):
     np.testing.assert_allclose(us_h, us_o, rtol=1e-5, atol=1e-5)
     assert np.abs(us_h).max() <= 6.0 + 1e-3
     h.close()
+
+
+@pytest.mark.parametrize("nv,kind", [(9, "panda_fingers"), (24, "tree")])
+def test_filter_line_search_for_large_models(hip_backend, nv, kind):
+    """use_filter_line_search = True (ocp_param_base.py:64) on the workgroup-per-node path: the accept kernel is the same for
+    every model size."""
+    table = _model(nv, kind)
+    frame = len(table.frame_names) - 1
+    B, T = 2, 6
+    po0, ref, x0, xs, us = workloads.random_goal_problem(table, T, 0.01, B, seed=300 + nv, frame=frame)
+    po = _abi.PackedOcp(nv, [0.01] * T, po0.running, po0.terminal, use_filter_line_search=True)
+    h, o = hip_backend.HipOcp(table, po, B), Oracle(table, po, B)
+    h.set_refs(ref)
+    xs_h, us_h, K_h, st_h = h.solve(x0, xs, us, 6)
+    xs_o, us_o, K_o, st_o = o.solve(ref, None, x0, xs, us, 6)
+    assert np.array_equal(st_h["iter"], st_o["iter"]) and np.array_equal(st_h["flags"], st_o["flags"])
+    np.testing.assert_allclose(xs_h, xs_o, rtol=1e-8, atol=1e-10)
+    np.testing.assert_allclose(us_h, us_o, rtol=1e-8, atol=1e-8)
+    h.close()
