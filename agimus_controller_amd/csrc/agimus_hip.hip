@@ -1373,9 +1373,13 @@ int agx_ocp_download_async(agx_ocp *o, double *xs, double *us, double *K) {
   if (K) HIPCHK(hipMemcpyAsync(o->d_snap + n_xs + n_us, o->d_Kout, sizeof(double) * n_K, hipMemcpyDeviceToDevice, o->stream));
   HIPCHK(hipEventRecord(o->ev_snap, o->stream));
   HIPCHK(hipStreamWaitEvent(o->copy_stream, o->ev_snap, 0));
-  if (xs) HIPCHK(hipMemcpyAsync(xs, o->d_snap, sizeof(double) * n_xs, hipMemcpyDeviceToHost, o->copy_stream));
-  if (us) HIPCHK(hipMemcpyAsync(us, o->d_snap + n_xs, sizeof(double) * n_us, hipMemcpyDeviceToHost, o->copy_stream));
-  if (K) HIPCHK(hipMemcpyAsync(K, o->d_snap + n_xs + n_us, sizeof(double) * n_K, hipMemcpyDeviceToHost, o->copy_stream));
+  if (xs && us && K && us == xs + n_xs && K == us + n_us) {  // one contiguous destination (xs | us | K): one transfer
+    HIPCHK(hipMemcpyAsync(xs, o->d_snap, sizeof(double) * (n_xs + n_us + n_K), hipMemcpyDeviceToHost, o->copy_stream));
+  } else {
+    if (xs) HIPCHK(hipMemcpyAsync(xs, o->d_snap, sizeof(double) * n_xs, hipMemcpyDeviceToHost, o->copy_stream));
+    if (us) HIPCHK(hipMemcpyAsync(us, o->d_snap + n_xs, sizeof(double) * n_us, hipMemcpyDeviceToHost, o->copy_stream));
+    if (K) HIPCHK(hipMemcpyAsync(K, o->d_snap + n_xs + n_us, sizeof(double) * n_K, hipMemcpyDeviceToHost, o->copy_stream));
+  }
   HIPCHK(hipEventRecord(o->ev_dl, o->copy_stream));
   o->dl_pending = true;
   return 0;

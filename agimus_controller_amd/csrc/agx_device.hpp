@@ -1175,18 +1175,9 @@ AGX_DEV double violation_l1(const DevCons &c, const double *g) {
   for (int k = 0; k < c.nc; ++k) v += fmax(c.lb[k] - g[k], 0.0) + fmax(g[k] - c.ub[k], 0.0);
   return v;
 }
-// Deliberately NOT inlined.  Inlined into the line search of k_step<..., CON> (a 512-VGPR kernel with > 450 spilled
-// registers) the violation came out wrong with hipcc 7.2 as soon as the collision witness selection above stopped
-// going through scratch (round 2: trial merits off, different step lengths than the checker; bisected on the GPU to
-// exactly this call being inlined or not -- same source, correct out of line; -amdgpu-spill-vgpr-to-agpr=0 did not
-// help).  Not understood beyond that; out of line it is also ~400 spilled registers less in the step kernel.
-template <int NV, bool CHAIN>
-__device__ __attribute__((noinline)) double constraint_violation(const DevModel &m, const DevCons &c, const double *x, const double *u) {
-  if (c.nc == 0) return 0.0;
-  double g[AGX_MAX_NC];
-  constraints_eval<NV, CHAIN, false>(m, c, x, u, g, nullptr);
-  return violation_l1(c, g);
-}
+// (Until round 2 a `constraint_violation(m, c, x, u)` wrapper lived here, `noinline` because the constrained step kernel
+// evaluated trial merits wrongly with it inlined -- DESIGN.md section 8.  The line search now takes the violation of a trial
+// point from k_con_eval run at that point; nothing evaluates constraints lane by lane inside a step kernel any more.)
 // ADMM penalty of one constraint component (SolverCSQP::apply_rho_update)
 AGX_DEV double admm_rho(double lb, double ub, double rho_sparse) {
   if (lb == -INFINITY && ub == INFINITY) return 1e-6;

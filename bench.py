@@ -624,7 +624,15 @@ def main():
             # solver's stream, drained into page-locked arrays by the copy stream while the next step is being solved
             # (agx_ocp_download_async); every step's results are complete on the host before the step after next starts
             nfull = 6
-            res = [tuple(backend.pinned_array(sh) for sh in ((B, T + 1, 2 * nv), (B, T, nv), (B, T, nv, 2 * nv))) for _ in range(2)]
+            shapes = ((B, T + 1, 2 * nv), (B, T, nv), (B, T, nv, 2 * nv))
+            sizes = [int(np.prod(sh)) for sh in shapes]
+
+            def result_block():  # xs | us | K in ONE page-locked block: one transfer per step
+                blk = backend.pinned_array((sum(sizes),))
+                offs = np.cumsum([0] + sizes)
+                return tuple(blk[offs[i]:offs[i + 1]].reshape(shapes[i]) for i in range(3))
+
+            res = [result_block() for _ in range(2)]
             hip.sync()
             t1 = time.perf_counter()
             for i, k in enumerate(range(k_next, k_next + nfull)):
