@@ -41,7 +41,7 @@ def _model(nv, kind):
     return rt.tree_table(nv, seed=40 + nv)
 
 
-CASES = [(5, "chain"), (5, "tree"), (9, "panda_fingers"), (12, "tree"), (24, "tree"), (31, "chain"), (32, "tree")]
+CASES = [(5, "chain"), (5, "tree"), (8, "chain"), (9, "panda_fingers"), (12, "tree"), (16, "tree"), (24, "tree"), (31, "chain"), (32, "tree")]
 
 
 @pytest.mark.parametrize("nv,kind", CASES)
