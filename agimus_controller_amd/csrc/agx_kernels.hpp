@@ -937,6 +937,7 @@ __global__ void __launch_bounds__(64) k_riccati_pair(const DevOcp *__restrict__ 
 
 }  // namespace agx
 #include "agx_riccati_mx.hpp"  // the same sweep in the MFMA operand layout (default for NV <= 7)
+#include "agx_riccati_mx2.hpp" // ... cut into segments swept in parallel, exact boundary value functions (small batches)
 namespace agx {
 
 // ---------------------------------------------------------------------------

@@ -1,0 +1,94 @@
+"""The exact two-level Riccati sweep of small batches (csrc/agx_riccati_mx2.hpp: segments in parallel, boundary value
+functions through the segments' (J, A, Cm) elements) against the one-wave sweep it replaces below a batch threshold, and
+against the CPU checker.  Handles pick the sweep at creation (AGX_MX2_SEGMENTS overrides the choice by batch)."""
+import os
+
+import numpy as np
+import pytest
+
+from agimus_controller_amd import _abi, workloads
+from agimus_controller_amd.factory import robot_tables as rt
+from oracle.oracle import Oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def _handle(hip_backend, table, po, B, segments):
+    old = os.environ.get("AGX_MX2_SEGMENTS")
+    os.environ["AGX_MX2_SEGMENTS"] = str(segments)
+    try:
+        return hip_backend.HipOcp(table, po, B)
+    finally:
+        if old is None:
+            del os.environ["AGX_MX2_SEGMENTS"]
+        else:
+            os.environ["AGX_MX2_SEGMENTS"] = old
+
+
+def rel(a, b):
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-300))
+
+
+@pytest.mark.parametrize("T,S,nv", [(100, 10, 7), (37, 5, 7), (64, 16, 7), (50, 4, 5), (23, 3, 3)])
+def test_direction_of_the_two_level_sweep_equals_the_one_wave_sweep(hip_backend, T, S, nv):
+    """Same QP tiles, both sweeps: feed-forward, direction and KKT residual agree to 1e-10 (the gains of every node come out
+    of the same recursion; only the value functions at the segment boundaries take another, exact, route)."""
+    table = rt.panda_table(0.1) if nv == 7 else rt.chain_table(nv, seed=3)
+    frame = len(table.frame_names) - 1
+    B = 3
+    ts = [0.01] * (T // 2) + [0.02] * (T - T // 2)
+    po, ref, x0, xs, us = workloads.random_goal_problem(table, T, 0.01, B, seed=T + S, frame=frame, timesteps=ts)
+    xs[:, 0] = x0
+    out = []
+    for seg in (0, S):
+        h = _handle(hip_backend, table, po, B, seg)
+        h.set_refs(ref)
+        h.upload_warmstart(xs, us)
+        out.append(h.direction())
+        h.close()
+    (K0, k0, dx0, du0, kkt0), (K1, k1, dx1, du1, kkt1) = out
+    assert rel(k1, k0) < 1e-10 and rel(dx1, dx0) < 1e-10 and rel(du1, du0) < 1e-10
+    np.testing.assert_allclose(kkt1, kkt0, rtol=1e-9)
+    np.testing.assert_array_equal(K1, K0)  # (agx_ocp_direction takes the reported gains from the one-wave exit sweep in both)
+
+
+def test_mpc_steps_with_the_two_level_sweeps_match_the_one_wave_path_and_the_checker(hip_backend):
+    """Resident MPC steps (the paired direction / sigma sweeps of later iterations included): first-node results of both
+    paths agree to 1e-9, iteration counts are equal, and the first step agrees with the checker."""
+    table = rt.panda_table(0.1)
+    tcp = table.frame_id("panda_hand_tcp")
+    B, T, dt = 4, 60, 0.01
+    running, terminal = workloads.goal_reaching_rows(tcp)
+    po = _abi.PackedOcp(7, [dt] * T, running, terminal)
+    p = workloads.sine_batch_params(B, lower=table.lower_position_limit, upper=table.upper_position_limit)
+    w = workloads.SINE_WEIGHTS
+    res = []
+    for seg in (0, 10):
+        h = _handle(hip_backend, table, po, B, seg)
+        h.sine_trajectory(T + 12, dt, *p, w["w_q"], w["w_qdot"], w["w_effort"], w["w_pose"], tcp)
+        steps = []
+        for k in range(5):
+            h.mpc_step(k, 10, first=(k == 0))
+            us0, K0, x1, st = h.download_first(copy=True)
+            steps.append((us0.copy(), K0.copy(), x1.copy(), st["iter"].copy(), st["solved"].copy()))
+        xs, us, K, _ = h.download()
+        res.append((steps, xs, us, K))
+        h.close()
+    for (a, b) in zip(res[0][0], res[1][0]):
+        assert np.array_equal(a[3], b[3]) and np.array_equal(a[4], b[4])
+        assert rel(b[0], a[0]) < 1e-9 and rel(b[1], a[1]) < 1e-8 and rel(b[2], a[2]) < 1e-9
+    assert rel(res[1][1], res[0][1]) < 1e-9 and rel(res[1][3], res[0][3]) < 1e-8
+
+
+def test_golden_fixture_with_the_two_level_sweep(hip_backend, golden):
+    """The reference's golden case (33 SQP iterations from a cold start) with the segmented sweeps forced on (T = 9: three
+    segments of three nodes would be below the minimum, so the case is run at S = 2)."""
+    table, po, ref, x0, xs0, us0 = workloads.golden_problem()
+    h = _handle(hip_backend, table, po, 1, 2)
+    h.set_refs(ref)
+    xs, us, K, st = h.solve(x0, xs0, us0, 100)
+    assert st["solved"][0] == 1
+    np.testing.assert_allclose(xs[0], golden["states"], rtol=0, atol=1e-8)
+    np.testing.assert_allclose(us[0], golden["feed_forward_terms"], rtol=0, atol=1e-7)
+    np.testing.assert_allclose(K[0], golden["ricatti_gains"], rtol=0, atol=1e-7)
+    h.close()
