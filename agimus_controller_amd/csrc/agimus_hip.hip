@@ -88,7 +88,7 @@ struct agx_ocp {
   // Exact two-level sweep (agx_riccati_mx2.hpp): the horizon in mx2_S segments swept in parallel; 0 = the one-wave sweep.
   // Chosen from the batch at creation (small batches leave most of the chip idle), AGX_MX2_SEGMENTS=n overrides (0: off).
   int mx2_S = 0;
-  double *d_mx2_elem = nullptr, *d_mx2_bnd = nullptr;  // [2][B][S][3][256] segment elements, [2][B][S][256] boundary value functions
+  double *d_mx2_elem = nullptr, *d_mx2_bnd = nullptr, *d_mx2_cl = nullptr;  // [2][B][S][3][256] segment elements, [2][B][S][256] boundary value functions, [B][S][256] transitions under the gains
   bool k1_fused = true;     // AGX_K1_FUSED=0: running and terminal nodes of the derivative pass as two launches (profiling)
   // Batch policy (agx_ocp_set_quorum): the SQP loop of a batch step ends once this fraction of the instances has
   // finished, the ADMM loop of an SQP iteration once this fraction of the QPs has converged; the others keep their
@@ -452,14 +452,15 @@ int launch_riccati(agx_ocp *o, int forward, bool pair = false, int iter = 0, con
       if (!o->d_mx2_elem) {
         HIPCHK(hipMalloc((void **)&o->d_mx2_elem, sizeof(double) * 2 * (size_t)o->B * S * 768));
         HIPCHK(hipMalloc((void **)&o->d_mx2_bnd, sizeof(double) * 2 * (size_t)o->B * S * 256));
+        HIPCHK(hipMalloc((void **)&o->d_mx2_cl, sizeof(double) * (size_t)o->B * S * 256));
       }
       hipLaunchKernelGGL((agx::k_riccati_mx2_elem<NV>), dim3(P2 * o->B * S), dim3(64), 0, o->stream, o->d_ocp, o->d_dt, o->d_qt, o->d_aux,
-                         o->d_Kws, o->d_kws, o->d_Kout, o->d_state, o->d_mx2_elem, o->d_mx2_bnd, S, pair ? 1 : 0, 0, 1, iter);
+                         o->d_Kws, o->d_kws, o->d_Kout, o->d_state, o->d_mx2_elem, o->d_mx2_bnd, o->d_mx2_cl, S, pair ? 1 : 0, 0, 1, iter);
       hipLaunchKernelGGL((agx::k_riccati_mx2_sweep<NV>), dim3(P2 * o->B * (S - 1)), dim3(64), 0, o->stream, o->d_ocp, o->d_dt, o->d_qt, o->d_aux,
-                         o->d_Kws, o->d_kws, o->d_Kout, o->d_state, o->d_mx2_elem, o->d_mx2_bnd, S, pair ? 1 : 0, 0, 1);
+                         o->d_Kws, o->d_kws, o->d_Kout, o->d_state, o->d_mx2_elem, o->d_mx2_bnd, o->d_mx2_cl, S, pair ? 1 : 0, 0, 1);
       if (forward)
-        hipLaunchKernelGGL((agx::k_riccati_mx2_fwd<NV>), dim3(o->B), dim3(64), 0, o->stream, o->d_ocp, o->d_dt, o->d_qt, o->d_Kws, o->d_kws,
-                           o->d_dx, o->d_w, o->d_state);
+        hipLaunchKernelGGL((agx::k_riccati_mx2_fwd<NV>), dim3(o->B * S), dim3(64), 0, o->stream, o->d_ocp, o->d_dt, o->d_qt, o->d_Kws, o->d_kws,
+                           o->d_dx, o->d_w, o->d_state, o->d_mx2_cl, S);
       HIPCHK(hipGetLastError());
       return 0;
     }
@@ -1119,7 +1120,10 @@ int agx_ocp_create(const agx_model *m, const agx_ocp_desc *d, int batch, int dev
   }
   // two-level sweep for small batches of unconstrained problems on the MFMA-layout kernel
   if (o->nv <= 7 && o->riccati_mx && !o->has_con && !o->fuse_kkt) {
-    int S = o->B <= 128 ? 10 : (o->B <= 256 ? 5 : 0);
+    // ten segments while the two sweeps of a paired launch (2 B S waves of 254 VGPRs) fit the 2 048 wave slots of the chip
+    // at two per SIMD; fewer above that; below five segments the 2.4 x arithmetic is not paid back (measured, B = 256: none)
+    int S = std::min(10, 1024 / o->B);
+    if (S < 5) S = 0;
     if (const char *e = getenv("AGX_MX2_SEGMENTS")) S = atoi(e);
     if (S > agx::kMx2MaxSeg) S = agx::kMx2MaxSeg;
     while (S >= 2 && o->T / S < 4) --S;  // segments of at least four nodes
@@ -1213,7 +1217,7 @@ void agx_ocp_destroy(agx_ocp *o) {
   (void)hipSetDevice(o->device);
   if (o->stream) (void)hipStreamSynchronize(o->stream);
   if (o->copy_stream) (void)hipStreamSynchronize(o->copy_stream);
-  void *ptrs[] = {o->d_mx2_elem, o->d_mx2_bnd, o->d_ref_back, o->d_frames_back, o->d_snap, o->d_model, o->d_ocp, o->d_dt, o->d_xs, o->d_us, o->d_x0, o->d_tiles, o->d_Kws, o->d_kws, o->d_Kout, o->d_dx,
+  void *ptrs[] = {o->d_mx2_elem, o->d_mx2_bnd, o->d_mx2_cl, o->d_ref_back, o->d_frames_back, o->d_snap, o->d_model, o->d_ocp, o->d_dt, o->d_xs, o->d_us, o->d_x0, o->d_tiles, o->d_Kws, o->d_kws, o->d_Kout, o->d_dx,
                   o->d_du, o->d_ref, o->d_frames, o->d_state, o->d_ndone, o->d_scratch, o->d_traj, o->d_pts, o->d_sine, o->d_qt, o->d_aux, o->d_w, o->d_nodestat,
                   o->d_qt2, o->d_cg, o->d_cjac, o->d_y, o->d_z, o->d_cx, o->d_admmstat, o->d_fac, o->d_hidx, o->d_trial, o->d_auxg, o->d_shift_nodes, o->d_segP, o->d_Kws_lqr, o->d_kws_lqr};
   for (void *p : ptrs)

@@ -19,7 +19,8 @@
 //     value function: the gains come out of the same recursion as in the one-wave sweep, only the boundary value
 //     functions take another (exact) route.  numpy prototype on the Panda tiles: boundary P, p and all gains to 4e-15
 //     relative, cond(I + P Cm) <= 55, no pivoting needed (smallest relative pivot 0.19).
-//   launch 3: the forward pass (k_riccati_mx2_fwd; one wave per instance).
+//   launch 3 (k_riccati_mx2_fwd, B x S waves): the forward pass, segmented with the transitions  x_end = A x_start + beta  that
+//     the sweeps of launches 1 / 2 accumulate under the TRUE gains: a walk over the boundaries, then the segment's nodes.
 // Chain per sweep at T = 100, S = 10: 10 x 1.4 + 8 x 1.2 + 10 node times instead of 101.  2.4 x the arithmetic: used
 // below a batch threshold only (agimus_hip.hip: mx2_segments).
 //
@@ -422,7 +423,7 @@ __global__ void __launch_bounds__(64, 2) k_riccati_mx2_elem(const DevOcp *__rest
                                                          const double *__restrict__ qts, const double *__restrict__ auxs,
                                                          double *__restrict__ Kws, double *__restrict__ kws, double *__restrict__ Kout,
                                                          DevState *__restrict__ st, double *__restrict__ elem, double *__restrict__ bnd,
-                                                         int S, int pair, int gains_only, int gmode, int iter) {
+                                                         double *__restrict__ cl, int S, int pair, int gains_only, int gmode, int iter) {
   const int T = op->T, B = op->B;
   const int unit = pair ? (int)(blockIdx.x >> 1) : (int)blockIdx.x;
   const bool gains = gains_only || (pair && (blockIdx.x & 1));
@@ -438,7 +439,10 @@ __global__ void __launch_bounds__(64, 2) k_riccati_mx2_elem(const DevOcp *__rest
   if (s == S - 1) {
     if (gains && gmode != 0 && threadIdx.x == 0) St.gains_iter = (gmode == 1) ? iter : St.dir_iter;
     if (gains) riccati_mx_seg<NV, true, false, false>(b, op, dts, qts, auxs, Kws, kws, Kout, dreg, t_lo, t_hi, 1, V, Am, At, Cm, bad);
-    else riccati_mx_seg<NV, false, false, false>(b, op, dts, qts, auxs, Kws, kws, Kout, dreg, t_lo, t_hi, 1, V, Am, At, Cm, bad);
+    else {  // + the transition x_T = A x_start + beta under the gains: the forward pass is segmented too
+      riccati_mx_seg<NV, false, true, false>(b, op, dts, qts, auxs, Kws, kws, Kout, dreg, t_lo, t_hi, 1, V, Am, At, Cm, bad);
+      mx2_store(cl + ((size_t)b * S + s) * 256, Am);
+    }
     mx2_store(bn, V);
     if (!gains) {  // this wave owns the flag; the sweeps of launch 2 only raise it
       const bool any_bad = __any(bad);
@@ -459,7 +463,8 @@ __global__ void __launch_bounds__(64, 2) k_riccati_mx2_sweep(const DevOcp *__res
                                                           const double *__restrict__ qts, const double *__restrict__ auxs,
                                                           double *__restrict__ Kws, double *__restrict__ kws, double *__restrict__ Kout,
                                                           DevState *__restrict__ st, const double *__restrict__ elem,
-                                                          const double *__restrict__ bnd, int S, int pair, int gains_only, int gmode) {
+                                                          const double *__restrict__ bnd, double *__restrict__ cl, int S, int pair,
+                                                          int gains_only, int gmode) {
   const int T = op->T, B = op->B;
   const int unit = pair ? (int)(blockIdx.x >> 1) : (int)blockIdx.x;
   const bool gains = gains_only || (pair && (blockIdx.x & 1));
@@ -479,24 +484,110 @@ __global__ void __launch_bounds__(64, 2) k_riccati_mx2_sweep(const DevOcp *__res
   const int t_lo = mx2_bound(s, S, T), t_hi = mx2_bound(s + 1, S, T);
   if (gains) riccati_mx_seg<NV, true, false, false>(b, op, dts, qts, auxs, Kws, kws, Kout, dreg, t_lo, t_hi, 2, V, Am, At, Cm2, bad);
   else {
-    riccati_mx_seg<NV, false, false, false>(b, op, dts, qts, auxs, Kws, kws, Kout, dreg, t_lo, t_hi, 2, V, Am, At, Cm2, bad);
+    riccati_mx_seg<NV, false, true, false>(b, op, dts, qts, auxs, Kws, kws, Kout, dreg, t_lo, t_hi, 2, V, Am, At, Cm2, bad);
+    mx2_store(cl + ((size_t)b * S + s) * 256, Am);
     if (__any(bad) && threadIdx.x == 0) { St.dir_fail = 1; atomicOr(&St.flags, 1); }
   }
 }
 
-// launch 3: the forward pass of the direction (one wave per instance, as at the end of riccati_mx_body)
+// launch 3: the forward pass, segments in parallel.  Segment s first walks the boundary states x_{b(s'+1)} = A_s' x_{b(s')} + beta_s'
+// (s' < s; the transitions the sweeps left in `cl`), then its own nodes as riccati_forward does: lane (r, c) of the 8 x 8 grid
+// holds Kw[r][c], 2 FMAs + a row sum + one transposing ds_bpermute per node.  The state at a segment's first node is the one
+// of the boundary walk (the segment before it does not write it).
 template <int NV>
 __global__ void __launch_bounds__(64, 2) k_riccati_mx2_fwd(const DevOcp *__restrict__ op, const double *__restrict__ dts,
                                                         const double *__restrict__ qts, const double *__restrict__ Kws,
                                                         const double *__restrict__ kws, double *__restrict__ dxs,
-                                                        double *__restrict__ wss, const DevState *__restrict__ st) {
-  constexpr int NX = 2 * NV;
+                                                        double *__restrict__ wss, const DevState *__restrict__ st,
+                                                        const double *__restrict__ cl, int S) {
+  constexpr int NX = 2 * NV, TS = QT<NV>::SIZE;
+  typedef QT<NV> Q;
   __shared__ double s_dt[kMaxHorizon];
-  const int T = op->T, b = blockIdx.x;
-  const DevState &S = st[b];
-  if (S.done || S.admm_conv) return;
+  const int T = op->T, b = blockIdx.x / S, s = blockIdx.x % S, lane = threadIdx.x;
+  const DevState &St = st[b];
+  if (St.done || St.admm_conv) return;
   stage_dts(s_dt, dts, T);
-  riccati_forward<NV>(b, T, dts, qts + (long long)b * (T + 1) * QT<NV>::SIZE, Kws + (long long)b * T * NV * NX, kws + (long long)b * T * NV, dxs, wss, s_dt);
+  // ---- boundary walk in the tile layout: lane (g, j) holds x_j (every group a copy), x_7 = 1 picks up beta
+  const int j = lane & 15;
+  double x = (j == 7) ? 1.0 : 0.0;
+  for (int s2 = 0; s2 < s; ++s2) {
+    const mx4 A = mx2_load(cl + ((size_t)b * S + s2) * 256);
+    double y[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      double p = A[r] * x;  // row g + 4 r, my column
+      p += dpp_xor1(p); p += dpp_xor2(p); p += dpp_xor4(p); p += row_ror8(p);  // sum over the 16 lanes of the row
+      y[r] = p;
+    }
+    // y_i sits in group i & 3, register i >> 2: back to "lane j holds x_j"
+    const int src = 16 * (j & 3);
+    const double c0 = __shfl(y[0], src, 64), c1 = __shfl(y[1], src, 64), c2 = __shfl(y[2], src, 64), c3 = __shfl(y[3], src, 64);
+    const int rj = j >> 2;
+    x = rj == 0 ? c0 : (rj == 1 ? c1 : (rj == 2 ? c2 : c3));
+    if (j == 7) x = 1.0;
+    if (j == 15 || ((j & 7) >= NV && j != 7)) x = 0.0;
+  }
+  // ---- the segment's nodes on the 8 x 8 lane grid
+  const int t_lo = mx2_bound(s, S, T), t_hi = mx2_bound(s + 1, S, T);
+  const int r = lane >> 3, c = lane & 7;
+  const bool in = (r < NV) && (c < NV);
+  const int rr = r < NV ? r : 0, cc = c < NV ? c : 0;
+  const double inm = in ? 1.0 : 0.0;
+  const double *qb = qts + (long long)b * (T + 1) * TS;
+  const double *Kw = Kws + (long long)b * T * NV * NX, *kw = kws + (long long)b * T * NV;
+  double *dx = dxs + (long long)b * (T + 1) * NX, *ws = wss + (long long)b * T * NV;
+  double dq_r = __shfl(x, rr, 64), dv_r = __shfl(x, 8 + rr, 64), dq_c = __shfl(x, cc, 64), dv_c = __shfl(x, 8 + cc, 64);
+  if (c == 0 && r < NV) { dx[(long long)t_lo * NX + r] = dq_r; dx[(long long)t_lo * NX + NV + r] = dv_r; }
+  auto row_sum = [](double p) { p += dpp_xor1(p); p += dpp_xor2(p); p += dpp_xor4(p); return p; };
+  struct Gain { double kq, kv, kw, fq, fv; };
+  constexpr int DEPTH = 4;
+  auto load_gain = [&](Gain &g, int t) {
+    const double *kr = Kw + ((long long)t * NV + rr) * NX;
+    g.kq = kr[cc];
+    g.kv = kr[NV + cc];
+    g.kw = kw[(long long)t * NV + rr];
+    g.fq = qb[(long long)t * TS + Q::f + rr];
+    g.fv = qb[(long long)t * TS + Q::f + NV + rr];
+  };
+  const bool last_seg = s == S - 1;
+  auto fstep = [&](Gain &g, int t) {
+    const double h = s_dt[t], h2 = h * h;
+    double p = (g.kq * inm) * dq_c + (g.kv * inm) * dv_c;
+    const double kwv = g.kw, fqc = g.fq, fvc = g.fv;
+    p = row_sum(p);
+    const double wv = -(kwv + p);
+    const double nq = dq_r + h * dv_r + h2 * wv + fqc;
+    const double nv2 = dv_r + h * wv + fvc;
+    dq_r = nq; dv_r = nv2;
+    dq_c = __shfl(nq, 8 * cc, 64);
+    dv_c = __shfl(nv2, 8 * cc, 64);
+    if (c == 0 && r < NV) {
+      ws[(long long)t * NV + r] = wv;
+      if (last_seg || t + 1 < t_hi) {  // the first node of the next segment belongs to that segment's boundary walk
+        dx[(long long)(t + 1) * NX + r] = nq;
+        dx[(long long)(t + 1) * NX + NV + r] = nv2;
+      }
+    }
+    prefetch_group_begin();
+    load_gain(g, t + DEPTH < t_hi ? t + DEPTH : t_hi - 1);
+    prefetch_group_end();
+  };
+  int t = t_lo;
+  for (int rem = (t_hi - t_lo) % DEPTH; rem > 0; --rem, ++t) {
+    Gain g1;
+    load_gain(g1, t);
+    fstep(g1, t);
+  }
+  if (t < t_hi) {
+    Gain g[DEPTH];
+#pragma unroll
+    for (int i = 0; i < DEPTH; ++i) load_gain(g[i], t + i);
+    prefetch_queue_settle(g);
+    for (; t < t_hi; t += DEPTH) {
+#pragma unroll
+      for (int i = 0; i < DEPTH; ++i) fstep(g[i], t + i);
+    }
+  }
 }
 
 }  // namespace agx
