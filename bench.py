@@ -548,7 +548,8 @@ def main():
             ms1 = float(lat.mean())
             result["batch1"] = {"ms_per_step": ms1, "median_ms": float(np.median(lat)), "p99_ms": float(lat[int(0.99 * (len(lat) - 1))]),
                                 "steps": int(len(lat)), "value": 1e3 / ms1, "unit": "MPC steps/s",
-                                "workload": "same, batch = 1 (BASELINE.json configs[1]); per-step host wall time incl. D2H"}
+                                "workload": "same, batch = 1 (BASELINE.json configs[1]); per-step host wall time incl. D2H; Riccati sweeps by the exact "
+                                            "two-level scheme of small batches (csrc/agx_riccati_mx2.hpp; AGX_MX2_SEGMENTS=0 restores the one-wave sweep)"}
             h1.close()
         if extra and args.workload in ("sine", "generic") and args.disturb_sigma > 0.0:
             # Disturbed leg: closed loop on the prediction never leaves the easy path (one SQP iteration, alpha = 1).  Here the
