@@ -551,6 +551,27 @@ def main():
                                 "workload": "same, batch = 1 (BASELINE.json configs[1]); per-step host wall time incl. D2H; Riccati sweeps by the exact "
                                             "two-level scheme of small batches (csrc/agx_riccati_mx2.hpp; AGX_MX2_SEGMENTS=0 restores the one-wave sweep)"}
             h1.close()
+            # ... and at batch 128: what one GPU holds when configs[3]'s 1024 instances are sharded over the 8 GPUs of a node
+            h8 = backend.HipOcp(table, po, 128, device=local_rank)
+            p8 = workloads.sine_batch_params(128, lower=table.lower_position_limit, upper=table.upper_position_limit)
+            n8 = 100
+            h8.sine_trajectory(args.warmup + n8 + T + 2, dt, *p8, w["w_q"], w["w_qdot"], w["w_effort"], w["w_pose"], tcp)
+            for k in range(args.warmup):
+                h8.mpc_step(k, args.max_iter, first=(k == 0))
+                h8.download_first(copy=False)
+            h8.sync()
+            lat8 = []
+            for k in range(args.warmup, args.warmup + n8):
+                t1 = time.perf_counter()
+                h8.mpc_step(k, args.max_iter, first=False)
+                h8.download_first(copy=False)
+                lat8.append((time.perf_counter() - t1) * 1e3)
+            lat8 = np.sort(np.array(lat8))
+            result["batch128"] = {"median_ms": float(np.median(lat8)), "p99_ms": float(lat8[int(0.99 * (len(lat8) - 1))]), "steps": int(len(lat8)),
+                                  "value": 128 * 1e3 / float(lat8.mean()), "unit": "MPC steps/s",
+                                  "workload": "same, batch = 128 on one GPU (the per-GPU share of a global batch of 1024 on 8 GPUs: the strong-scaling point; "
+                                              "two-level Riccati sweeps)"}
+            h8.close()
         if extra and args.workload in ("sine", "generic") and args.disturb_sigma > 0.0:
             # Disturbed leg: closed loop on the prediction never leaves the easy path (one SQP iteration, alpha = 1).  Here the
             # measured state is the predicted one plus seeded noise: several SQP iterations per step, rejected step lengths,

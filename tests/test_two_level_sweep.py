@@ -92,3 +92,33 @@ def test_golden_fixture_with_the_two_level_sweep(hip_backend, golden):
     np.testing.assert_allclose(us[0], golden["feed_forward_terms"], rtol=0, atol=1e-7)
     np.testing.assert_allclose(K[0], golden["ricatti_gains"], rtol=0, atol=1e-7)
     h.close()
+
+
+def test_full_size_batch_128_properties(hip_backend):
+    """BASELINE configs[3] as one GPU of eight sees it (batch 128, horizon 100) on the resident sine workload: after MPC steps
+    every instance is solved within the tolerance, and the two-level path agrees with the one-wave path on iterations,
+    first-node results (1e-9) and the whole trajectory."""
+    table = rt.panda_table(0.1)
+    tcp = table.frame_id("panda_hand_tcp")
+    B, T, dt = 128, 100, 0.01
+    running, terminal = workloads.goal_reaching_rows(tcp)
+    po = _abi.PackedOcp(7, [dt] * T, running, terminal, termination_tolerance=1e-3, max_qp_iters=100)
+    p = workloads.sine_batch_params(B, lower=table.lower_position_limit, upper=table.upper_position_limit)
+    w = workloads.SINE_WEIGHTS
+    out = []
+    for seg in (0, 8):
+        h = _handle(hip_backend, table, po, B, seg)
+        h.sine_trajectory(T + 10, dt, *p, w["w_q"], w["w_qdot"], w["w_effort"], w["w_pose"], tcp)
+        its = []
+        for k in range(4):
+            h.mpc_step(k, 10, first=(k == 0))
+            us0, K0, x1, st = h.download_first(copy=True)
+            its.append(st["iter"].copy())
+            assert np.all(st["solved"] == 1) and np.all(st["kkt"] <= 1e-3)
+        xs, us, K, _ = h.download()
+        out.append((its, us0.copy(), K0.copy(), xs, us, K))
+        h.close()
+    assert all(np.array_equal(a, b) for a, b in zip(out[0][0], out[1][0]))
+    assert rel(out[1][1], out[0][1]) < 1e-9 and rel(out[1][2], out[0][2]) < 1e-8
+    assert rel(out[1][3], out[0][3]) < 1e-9 and rel(out[1][4], out[0][4]) < 1e-8 and rel(out[1][5], out[0][5]) < 1e-8
+    assert np.all(np.isfinite(out[1][5]))
