@@ -67,7 +67,6 @@ struct agx_ocp {
   // constrained problems (agx_admm.hpp): augmented tiles, constraint values / collision Jacobians,
   // multipliers y (persistent across solves), slack z, prox centre, per-node residual norms
   bool has_con = false;
-  double *d_trial = nullptr;  // [B][T+1] merit shares of a line-search trial (large models)
   std::vector<int> shift_nodes;  // large models: nodes with dt_i != dt_0 (integrated by the warm-start shift)
   int *d_shift_nodes = nullptr;
   bool general = false;       // ControlGrav / FrameVelocity cost rows: one-lane GEN kernels (agx_general.hpp)
@@ -1118,8 +1117,15 @@ int agx_ocp_create(const agx_model *m, const agx_ocp_desc *d, int batch, int dev
     if (o->stride > agx::kWgRef) { delete o; return fail("agx_ocp_create: reference tile of " + std::to_string(o->stride) + " doubles per node exceeds the large-model limit of " + std::to_string(agx::kWgRef)); }
     if (n_dense(o->ho.rows[0]) > agx::kWgJ || n_dense(o->ho.rows[1]) > agx::kWgJ) { delete o; return fail("agx_ocp_create: more than 16 frame / collision residual components per node (large models)"); }
   }
-  // two-level sweep for small batches of unconstrained problems on the MFMA-layout kernel
-  if (o->nv <= 7 && o->riccati_mx && !o->has_con && !o->fuse_kkt) {
+  // two-level sweep for small batches of unconstrained problems on the MFMA-layout kernel.  Only with Gauss-Newton Hessians of
+  // quadratic activations: then Hww = M (Luu + preg) M is positive definite at every node and no sweep -- neither the ordinary one
+  // nor a segment's zero-terminal one, whose pivots are the smaller ones -- can meet a non-positive pivot.  An Exp / QuadExp cost
+  // row has negative curvature inside its bell: such problems keep the one-wave sweep and its breakdown handling.
+  bool convex_rows = true;
+  for (int lay = 0; lay < 2; ++lay)
+    for (int r = 0; r < o->ho.rows[lay].n; ++r)
+      if (o->ho.rows[lay].active[r] && o->ho.rows[lay].act[r] != AGX_ACT_WEIGHTED_QUAD) convex_rows = false;
+  if (o->nv <= 7 && o->riccati_mx && !o->has_con && !o->fuse_kkt && convex_rows) {
     // ten segments while the two sweeps of a paired launch (2 B S waves of 254 VGPRs) fit the 2 048 wave slots of the chip
     // at two per SIMD; fewer above that; below five segments the 2.4 x arithmetic is not paid back (measured, B = 256: none)
     int S = std::min(10, 1024 / o->B);
@@ -1219,7 +1225,7 @@ void agx_ocp_destroy(agx_ocp *o) {
   if (o->copy_stream) (void)hipStreamSynchronize(o->copy_stream);
   void *ptrs[] = {o->d_mx2_elem, o->d_mx2_bnd, o->d_mx2_cl, o->d_ref_back, o->d_frames_back, o->d_snap, o->d_model, o->d_ocp, o->d_dt, o->d_xs, o->d_us, o->d_x0, o->d_tiles, o->d_Kws, o->d_kws, o->d_Kout, o->d_dx,
                   o->d_du, o->d_ref, o->d_frames, o->d_state, o->d_ndone, o->d_scratch, o->d_traj, o->d_pts, o->d_sine, o->d_qt, o->d_aux, o->d_w, o->d_nodestat,
-                  o->d_qt2, o->d_cg, o->d_cjac, o->d_y, o->d_z, o->d_cx, o->d_admmstat, o->d_fac, o->d_hidx, o->d_trial, o->d_auxg, o->d_shift_nodes, o->d_segP, o->d_Kws_lqr, o->d_kws_lqr};
+                  o->d_qt2, o->d_cg, o->d_cjac, o->d_y, o->d_z, o->d_cx, o->d_admmstat, o->d_fac, o->d_hidx, o->d_auxg, o->d_shift_nodes, o->d_segP, o->d_Kws_lqr, o->d_kws_lqr};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
   if (o->h_ndone) (void)hipHostFree(o->h_ndone);

@@ -28,7 +28,7 @@ struct DevState {
   double rho_sparse;             // persists across solves (SolverCSQP reset_rho = false); 0 = not initialised
   double con;                    // l1 norm of the constraint violation at the last evaluation
   int admm_conv, admm_iter;      // QP converged in this SQP iteration / ADMM iterations done
-  int ls_acc;                    // (unused; kept for the layout)
+  int ls_acc;                    // large models: the sigma sweep in front of k_gains_to_u_* took this instance (agx_big.hpp)
   int admm_refactor;             // ADMM: the Hessian part of the augmented tiles changed (first iteration / new rho)
   int dir_fail;                  // the last backward sweep met a non-positive / non-finite pivot (Quu not positive definite)
   // line search by derivative passes at the trial points (nv <= 7: k_sqp_head / k_sqp_accept)
