@@ -94,6 +94,7 @@ struct agx_ocp {
   // iterate (solved = 0 / qp_iters = max_qp_iters) and continue from it at the next MPC step, as a lone controller
   // that ran into max_solve_time would.  1.0 = wait for everyone (the default).
   double quorum_sqp = 1.0, quorum_qp = 1.0;
+  bool fold_publish = false;  // small batches (B <= 204, polled hand-off): the head / accept kernels hand the counters to the host themselves (last workgroup to arrive) and the host asks after the head from the second iteration on; AGX_FOLD_PUBLISH=0/1 overrides
   bool no_empty = false;  // AGX_NO_EMPTY_LAUNCHES=1 (profiling): the host asks after the head of the step whether anybody searches and skips the trial launches otherwise, so that per-kernel averages are those of working launches
   double *d_ref = nullptr;  // owned tile [B][T+1][stride]
   // asynchronous reference upload (agx_ocp_set_refs_async): second tile / frame table filled by the copy stream while the
@@ -495,7 +496,18 @@ int launch_riccati(agx_ocp *o, int forward, bool pair = false, int iter = 0, con
 
 // K3 (node shares of the KKT residual, cost, gaps; du) and the head of the step: instance totals, convergence test and the
 // first trial iterate of the line search (the caller runs the trial rounds: line_search_rounds).
-int launch_step(agx_ocp *o, int iter, int max_iter, int mode, bool with_node_kkt = true, bool with_step = true) {
+agx::HostWords host_words(agx_ocp *o, bool line_search_counters, unsigned long long seq) {
+  agx::HostWords hw{nullptr, nullptr, nullptr, nullptr, 0};
+  if (!o->poll || !o->fold_publish || seq == 0) return hw;
+  hw.done = o->h_ndone_dev + 0;
+  if (line_search_counters) { hw.handed = o->h_ndone_dev + 6; hw.stale = o->h_ndone_dev + 7; }
+  hw.seq = o->h_ndone_dev + 1;
+  hw.stamp = seq;
+  return hw;
+}
+
+// `seq` != 0 (small batches): the head's last workgroup hands the finished-instance count to the host under that stamp
+int launch_step(agx_ocp *o, int iter, int max_iter, int mode, bool with_node_kkt = true, bool with_step = true, unsigned long long seq = 0) {
   if (o->T + 1 > 512) return fail("step kernel supports horizons up to 511 nodes");
   return dispatch(o->nv, o->chain, [&](auto NVc, auto CHc) -> int {
     constexpr int NV = decltype(NVc)::value;
@@ -509,7 +521,7 @@ int launch_step(agx_ocp *o, int iter, int max_iter, int mode, bool with_node_kkt
                            o->d_auxg, o->d_dx, o->d_w, o->d_du, o->d_nodestat, o->d_state);
       if (with_step)
         hipLaunchKernelGGL((agx::k_sqp_head<NV>), dim3(o->B), dim3(128), 0, o->stream, o->d_ocp, o->d_xs, o->d_us, o->d_dx, o->d_du, xs_t, us_t,
-                           o->d_nodestat, o->d_state, iter, max_iter, mode, o->d_ndone);
+                           o->d_nodestat, o->d_state, iter, max_iter, mode, o->d_ndone, host_words(o, false, seq));
       HIPCHK(hipGetLastError());
       return 0;
     }
@@ -523,7 +535,7 @@ int launch_step(agx_ocp *o, int iter, int max_iter, int mode, bool with_node_kkt
     }
     if (!with_step) { HIPCHK(hipGetLastError()); return 0; }
     hipLaunchKernelGGL((agx::k_sqp_head<NV>), dim3(o->B), dim3(128), 0, o->stream, o->d_ocp, o->d_xs, o->d_us, o->d_dx, o->d_du, xs_t, us_t,
-                       o->d_nodestat, o->d_state, iter, max_iter, mode, o->d_ndone);
+                       o->d_nodestat, o->d_state, iter, max_iter, mode, o->d_ndone, host_words(o, false, seq));
     HIPCHK(hipGetLastError());
     return 0;
   });
@@ -770,6 +782,7 @@ int line_search_rounds(agx_ocp *o, int it, int max_iter, bool *need_k1, int *n_d
       if (prof_mark(o, 0, false)) return -1;
       if (launch_calc_qp(o, false, true, 1)) return -1;
     } else if (launch_calc_qp(o, false, false, 1)) return -1;
+    const unsigned long long seq = ++o->seq;
     int rc = dispatch(o->nv, o->chain, [&](auto NVc, auto CHc) -> int {
       constexpr int NV = decltype(NVc)::value;
       constexpr bool CH = decltype(CHc)::value;
@@ -781,13 +794,14 @@ int line_search_rounds(agx_ocp *o, int it, int max_iter, bool *need_k1, int *n_d
       }
       if (prof_mark(o, 2, true)) return -1;
       hipLaunchKernelGGL((agx::k_sqp_accept<NV>), dim3(o->B), dim3(128), 0, o->stream, o->d_ocp, o->d_xs, o->d_us, o->d_dx, o->d_du, xs_t, us_t,
-                         o->d_qt, o->d_nodestat, o->d_state, it, max_iter, o->d_ndone);
+                         o->d_qt, o->d_nodestat, o->d_state, it, max_iter, o->d_ndone, host_words(o, true, seq));
       HIPCHK(hipGetLastError());
       return prof_mark(o, 2, false);
     });
     if (rc) return rc;
-    const unsigned long long seq = ++o->seq;
-    if (o->poll) {
+    if (o->poll && o->fold_publish) {
+      if (wait_stamp(o, 1, seq)) return -1;  // stored by the last workgroup of k_sqp_accept
+    } else if (o->poll) {
       hipLaunchKernelGGL(agx::k_publish3, dim3(1), dim3(1), 0, o->stream, o->d_ndone, o->h_ndone_dev + 0, o->h_ndone_dev + 6, o->h_ndone_dev + 7,
                          o->h_ndone_dev + 1, seq);
       HIPCHK(hipGetLastError());
@@ -851,7 +865,8 @@ int solve_resident(agx_ocp *o, int max_iter, double max_time, bool prologue_done
     if (prof_mark(o, 1, false)) return -1;
     const bool last = it + 1 == max_iter;
     if (prof_mark(o, 2, true)) return -1;
-    if (launch_step(o, it, max_iter, 1, !o->has_con, true)) return -1;
+    const unsigned long long seq_head = ++o->seq;
+    if (launch_step(o, it, max_iter, 1, !o->has_con, true, seq_head)) return -1;
     if (prof_mark(o, 2, false)) return -1;
     int n_done = 0;
     // The trial passes overwrite the tiles of this iterate.  Where the loop may end right after this iteration without a
@@ -860,8 +875,15 @@ int solve_resident(agx_ocp *o, int max_iter, double max_time, bool prologue_done
     if (!pair && !o->has_con && (last || max_time > 0.0 || o->quorum_sqp < 1.0)) {
       if (launch_gains(o, 4)) return -1;
     }
+    // Small batches: from the second iteration on a warm-started step usually ends at the head, whose last workgroup has
+    // handed the finished count over: the host asks before it launches trial passes that would find nobody searching (in the
+    // first iteration it does not wait: somebody nearly always searches, and the trial pass starts right behind the head).
     bool searching = true;
-    if (o->prof || o->no_empty) {  // timing / profiling runs: no launches that find nothing to do
+    if (o->poll && o->fold_publish && it >= 1) {
+      if (wait_stamp(o, 1, seq_head)) return -1;
+      n_done = (int)__atomic_load_n(o->h_ndone, __ATOMIC_ACQUIRE);
+      searching = n_done < o->B;
+    } else if (o->prof || o->no_empty) {  // timing / profiling runs: no launches that find nothing to do
       if (read_int(o, o->d_ndone, 0, 1, &n_done)) return -1;
       searching = n_done < o->B;
     }
@@ -1033,6 +1055,8 @@ int agx_ocp_create(const agx_model *m, const agx_ocp_desc *d, int batch, int dev
   if (const char *e = getenv("AGX_RICCATI_MX")) o->riccati_mx = (e[0] != '0');
   if (const char *e = getenv("AGX_FUSED_KKT")) o->fuse_kkt = (e[0] != '0');
   if (const char *e = getenv("AGX_NO_EMPTY_LAUNCHES")) o->no_empty = (e[0] != '0');
+  o->fold_publish = batch <= 204;
+  if (const char *e = getenv("AGX_FOLD_PUBLISH")) o->fold_publish = (e[0] != '0');
   if (const char *e = getenv("AGX_K1_FUSED")) o->k1_fused = (e[0] != '0');
   o->T = d->horizon; o->B = batch; o->device = device;
   o->tile = AGX_TILE_DOUBLES(o->nv);

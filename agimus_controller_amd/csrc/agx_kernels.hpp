@@ -1068,6 +1068,29 @@ __device__ __forceinline__ void write_trial_iterate(const DevOcp &o, int b, doub
   for (int e = threadIdx.x; e < T * NU; e += blockDim.x) us_t[ou + e] = us[ou + e] + alpha * dus[ou + e];
 }
 
+// Hand-off to the host without a launch of its own (small batches, where every launch is ~ 4 us of a 200 us step): every
+// workgroup of a kernel arrives at a counter when it is done, the last one stores the counters the host waits for, then the
+// sequence stamp, into mapped pinned memory (as k_publish3).  hw.seq == nullptr: nothing -- large batches publish with a
+// one-thread kernel (a thousand workgroups arriving at one counter cost the B = 1024 step more than the launch: measured).
+// One thread per workgroup calls this, after its last write to the counters.
+struct HostWords {
+  unsigned long long *done, *handed, *stale, *seq;  // mapped host words (handed / stale may be null)
+  unsigned long long stamp;
+};
+__device__ __forceinline__ void arrive_and_publish(int *__restrict__ counts, const HostWords &hw) {
+  if (!hw.seq) return;
+  __threadfence();
+  const int a = atomicAdd(counts + 5, 1);
+  if (a != (int)gridDim.x - 1) return;
+  counts[5] = 0;  // the next kernel that arrives here starts from zero (kernels of one stream do not overlap)
+  __threadfence();
+  __hip_atomic_store(hw.done, (unsigned long long)(unsigned)__hip_atomic_load(counts + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  if (hw.handed) __hip_atomic_store(hw.handed, (unsigned long long)(unsigned)__hip_atomic_load(counts + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  if (hw.stale) __hip_atomic_store(hw.stale, (unsigned long long)(unsigned)__hip_atomic_load(counts + 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  __threadfence_system();
+  __hip_atomic_store(hw.seq, hw.stamp, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // Head of the step: instance totals of the per-node KKT / cost / gap / violation shares (k_node_kkt, k_con_eval) in a
 // fixed summation order -> KKT test; a converged instance finishes; the others enter the line search at alpha = 1 (trial
 // iterate written here) -- unless their direction came out of a failed factorisation: that one is never accepted (the CPU
@@ -1079,13 +1102,16 @@ __global__ void __launch_bounds__(128) k_sqp_head(const DevOcp *__restrict__ op,
                                                   const double *__restrict__ dxs, const double *__restrict__ dus,
                                                   double *__restrict__ xs_t, double *__restrict__ us_t,
                                                   const double *__restrict__ nodestat, DevState *__restrict__ st, int iter, int max_iter,
-                                                  int mode, int *__restrict__ n_done) {
+                                                  int mode, int *__restrict__ n_done, HostWords hw) {
   __shared__ double red[8];
   __shared__ int flag;
   const DevOcp &o = *op;
   const int T = o.T, b = blockIdx.x, tid = threadIdx.x;
   DevState &S = st[b];
-  if (S.done) return;
+  if (S.done) {  // (uniform over the workgroup)
+    if (tid == 0) arrive_and_publish(n_done, hw);
+    return;
+  }
   double kkt = 0.0, csum = 0.0, gsum = 0.0, vsum = 0.0;
   for (int t = tid; t <= T; t += blockDim.x) {
     const double *ns = nodestat + ((long long)b * (T + 1) + t) * 4;
@@ -1128,6 +1154,7 @@ __global__ void __launch_bounds__(128) k_sqp_head(const DevOcp *__restrict__ op,
       }
     }
     flag = what;
+    arrive_and_publish(n_done, hw);  // (the host wants the finished count; the trial iterate below is for the next kernel of the stream)
   }
   __syncthreads();
   if (flag) write_trial_iterate<NV>(o, b, 1.0, xs, us, dxs, dus, xs_t, us_t);
@@ -1144,7 +1171,8 @@ __global__ void __launch_bounds__(128) k_sqp_accept(const DevOcp *__restrict__ o
                                                     const double *__restrict__ dxs, const double *__restrict__ dus,
                                                     double *__restrict__ xs_t, double *__restrict__ us_t,
                                                     const double *__restrict__ qts, const double *__restrict__ nodestat,
-                                                    DevState *__restrict__ st, int iter, int max_iter, int *__restrict__ n_done) {
+                                                    DevState *__restrict__ st, int iter, int max_iter, int *__restrict__ n_done,
+                                                    HostWords hw) {
   constexpr int NX = 2 * NV, NU = NV;
   typedef QT<NV> Q;
   __shared__ double red[6];
@@ -1153,7 +1181,10 @@ __global__ void __launch_bounds__(128) k_sqp_accept(const DevOcp *__restrict__ o
   const DevOcp &o = *op;
   const int T = o.T, b = blockIdx.x, tid = threadIdx.x;
   DevState &S = st[b];
-  if (!S.searching) return;
+  if (!S.searching) {
+    if (tid == 0) arrive_and_publish(n_done, hw);
+    return;
+  }
   double pc = 0.0, pg = 0.0, pv = 0.0;
   for (int t = tid; t <= T; t += blockDim.x) {
     const double *qt = qts + ((long long)b * (T + 1) + t) * Q::SIZE;
@@ -1194,6 +1225,7 @@ __global__ void __launch_bounds__(128) k_sqp_accept(const DevOcp *__restrict__ o
       sqp_iteration_end(S, false, alpha, iter, max_iter, n_done);
     }
     flag = what;
+    arrive_and_publish(n_done, hw);  // (counters only: the iterate below is consumed by later kernels of the stream)
   }
   __syncthreads();
   if (flag == 1) {
