@@ -84,6 +84,7 @@ struct agx_ocp {
   bool fuse_kkt = false;     // AGX_FUSED_KKT=1: K3 inside the forward pass of k_riccati_mx instead of its own launch (measured: no gain)
   bool riccati_mx = true;    // AGX_RICCATI_MX=0: nv <= 7 sweeps on the 8 x 8 lane grid (k_riccati) instead of the MFMA operand layout (k_riccati_mx)
   bool riccati_mfma = true;  // AGX_RICCATI_MFMA=0: large models sweep with the LDS Gauss-Jordan kernel (k_riccati_big)
+  bool riccati_blk = true;   // AGX_RICCATI_BLK=0: the matrix-core sweep with the per-wave v_readlane elimination (k_riccati_mfma) instead of the blocked inverse (k_riccati_blk)
   // Exact two-level sweep (agx_riccati_mx2.hpp): the horizon in mx2_S segments swept in parallel; 0 = the one-wave sweep.
   // Chosen from the batch at creation (small batches leave most of the chip idle), AGX_MX2_SEGMENTS=n overrides (0: off).
   int mx2_S = 0;
@@ -481,8 +482,12 @@ int launch_riccati(agx_ocp *o, int forward, bool pair = false, int iter = 0, con
     } else {
       (void)pair; (void)iter;
       if constexpr (NV > 16) if (o->riccati_mfma) {
-        hipLaunchKernelGGL((agx::k_riccati_mfma<NV>), dim3(o->B), dim3(256), 0, o->stream, o->d_ocp, o->d_dt, qt, o->d_Kws, o->d_kws, o->d_dx,
-                           o->d_w, o->d_state, forward, 0);
+        if (o->riccati_blk)
+          hipLaunchKernelGGL((agx::k_riccati_blk<NV>), dim3(o->B), dim3(256), 0, o->stream, o->d_ocp, o->d_dt, qt, o->d_Kws, o->d_kws, o->d_dx,
+                             o->d_w, o->d_state, forward, 0);
+        else
+          hipLaunchKernelGGL((agx::k_riccati_mfma<NV>), dim3(o->B), dim3(256), 0, o->stream, o->d_ocp, o->d_dt, qt, o->d_Kws, o->d_kws, o->d_dx,
+                             o->d_w, o->d_state, forward, 0);
         HIPCHK(hipGetLastError());
         return 0;
       }
@@ -563,8 +568,12 @@ int launch_gains(agx_ocp *o, int gmode = 0) {
       hipLaunchKernelGGL((agx::k_sigma_tile_big<NV>), dim3((int)nodes), dim3(256), 0, o->stream, o->d_ocp, o->d_qt, o->d_qt2, o->d_aux);
       bool swept = false;
       if constexpr (NV > 16) if (o->riccati_mfma) {
-        hipLaunchKernelGGL((agx::k_riccati_mfma<NV>), dim3(o->B), dim3(256), 0, o->stream, o->d_ocp, o->d_dt, o->d_qt2, o->d_Kws, o->d_kws,
-                           o->d_dx, o->d_w, o->d_state, 0, gsel);
+        if (o->riccati_blk)
+          hipLaunchKernelGGL((agx::k_riccati_blk<NV>), dim3(o->B), dim3(256), 0, o->stream, o->d_ocp, o->d_dt, o->d_qt2, o->d_Kws, o->d_kws,
+                             o->d_dx, o->d_w, o->d_state, 0, gsel);
+        else
+          hipLaunchKernelGGL((agx::k_riccati_mfma<NV>), dim3(o->B), dim3(256), 0, o->stream, o->d_ocp, o->d_dt, o->d_qt2, o->d_Kws, o->d_kws,
+                             o->d_dx, o->d_w, o->d_state, 0, gsel);
         swept = true;
       }
       if (!swept)
@@ -1052,6 +1061,7 @@ int agx_ocp_create(const agx_model *m, const agx_ocp_desc *d, int batch, int dev
   if (const char *e = getenv("AGX_SPECULATE_GAINS")) o->speculate = (e[0] != '0');
   if (const char *e = getenv("AGX_GAINS_MFMA")) o->gains_mfma = (e[0] != '0');
   if (const char *e = getenv("AGX_RICCATI_MFMA")) o->riccati_mfma = (e[0] != '0');
+  if (const char *e = getenv("AGX_RICCATI_BLK")) o->riccati_blk = (e[0] != '0');
   if (const char *e = getenv("AGX_RICCATI_MX")) o->riccati_mx = (e[0] != '0');
   if (const char *e = getenv("AGX_FUSED_KKT")) o->fuse_kkt = (e[0] != '0');
   if (const char *e = getenv("AGX_NO_EMPTY_LAUNCHES")) o->no_empty = (e[0] != '0');

@@ -1921,3 +1921,4 @@ __global__ void k_ws_from_ref(double *xs, double *us, double *x0, const double *
 #include "agx_admm.hpp"
 #include "agx_big.hpp"
 #include "agx_big_k1.hpp"
+#include "agx_big_k2.hpp"
