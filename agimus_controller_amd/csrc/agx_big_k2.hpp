@@ -57,6 +57,20 @@ __device__ __forceinline__ void tile_inv_range(agx_v4d &x, const int g, const in
 // inverse of a symmetric positive definite tile (no pivoting), in place
 __device__ __forceinline__ void tile_inverse(agx_v4d &x, const int g, const int j) { tile_inv_range<0, 16>(x, g, j); }
 
+// (Tried and discarded, round 3: the rank-one update of a pivot as ONE MFMA -- for a symmetric tile both operands are the
+// pivot row's own registers -- with the next pivot's reciprocal formed ahead of the update.  Fewer instructions, but the
+// dependent MFMA -> v_readlane -> MFMA chain is longer than the DPP / ds_bpermute one: inversion phase 3.7 -> 5.0 us per
+// node, and treating the tile as exactly symmetric cost the 31-link chain its parity.)
+// Development builds (-DAGX_BLK_STAMP): thread 0 of workgroup 0 sums the time between phase boundaries (100 MHz ticks)
+#ifdef AGX_BLK_STAMP
+#define AGX_BLK_T(i)                                                                     \
+  do {                                                                                   \
+    if (tid == 0 && b == 0) { const long long now_ = wall_clock64(); ph_[i] += now_ - last_; last_ = now_; } \
+  } while (0)
+#else
+#define AGX_BLK_T(i) do { } while (0)
+#endif
+
 template <int NV>
 __global__ void __launch_bounds__(256, 2) k_riccati_blk(const DevOcp *__restrict__ op, const double *__restrict__ dts,
                                                         const double *__restrict__ qts, double *__restrict__ Kws,
@@ -76,6 +90,13 @@ __global__ void __launch_bounds__(256, 2) k_riccati_blk(const DevOcp *__restrict
   const DevOcp &o = *op;
   const int T = o.T, b = blockIdx.x, tid = threadIdx.x, nt = 256, lane = tid & 63, wave = tid >> 6;
   const int l15 = lane & 15, l4 = lane >> 4;
+  // The wave that inverts Qww: the two workgroups a CU holds (512 instances on 256 CUs: blocks i and i + 256 under the
+  // round-robin placement) use different SIMDs for it, so that the two serial inversions do not queue behind each other
+#ifndef AGX_BLK_INV_WAVE
+  const int inv_wave = (blockIdx.x >> 8) & 3;
+#else
+  const int inv_wave = AGX_BLK_INV_WAVE;
+#endif
   DevState &S = st[b];
   if (!gains_pass && (S.done || S.admm_conv)) return;
   // gains_pass: as in k_riccati_mfma
@@ -128,6 +149,9 @@ __global__ void __launch_bounds__(256, 2) k_riccati_blk(const DevOcp *__restrict
   fetch(T - 1);
   if (tid < NX) fl[tid] = pf;
   __syncthreads();
+#ifdef AGX_BLK_STAMP
+  long long ph_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, last_ = wall_clock64();
+#endif
   for (int t = T - 1; t >= 0; --t) {
     const double h = dts[t], h2 = h * h;
     // ---- phase 1 (V read only): vp = vx + (V + dreg) f on four lanes per row; this thread's entries of sym V + dreg
@@ -155,6 +179,7 @@ __global__ void __launch_bounds__(256, 2) k_riccati_blk(const DevOcp *__restrict
       }
     }
     __syncthreads();
+    AGX_BLK_T(1);
     // ---- phase 2: Qww, Qxw, and Qxx over V (element-wise thanks to the (Phi, G) structure of the acceleration-input QP)
 #pragma unroll
     for (int n = 0; n < NE; ++n) {
@@ -183,8 +208,9 @@ __global__ void __launch_bounds__(256, 2) k_riccati_blk(const DevOcp *__restrict
     }
     if (t > 0) fetch(t - 1);  // next node's tile entries are on their way during the factorisation
     __syncthreads();
+    AGX_BLK_T(2);
     // ---- phase 3: Qww^-1 by blocks, in place (the pad rows / columns keep their unit diagonal)
-    if (wave == 0) {
+    if (wave == inv_wave) {
       agx_v4d A11, A12, A22;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
@@ -209,6 +235,7 @@ __global__ void __launch_bounds__(256, 2) k_riccati_blk(const DevOcp *__restrict
       }
     }
     __syncthreads();
+    AGX_BLK_T(3);
     // ---- phase 4: [Kw | kw] = Qww^-1 [Qwx | qw], 16 columns per wave and pass, on the matrix cores: the product with the inverse,
     // then one step of iterative refinement with the matrix itself (x += Qww^-1 (b - Qww x)).  The product alone is not
     // enough: its error is cond(Qww) eps and Qww = M' Luu M + ... squares the condition of the mass matrix (a serial chain of
@@ -260,6 +287,7 @@ __global__ void __launch_bounds__(256, 2) k_riccati_blk(const DevOcp *__restrict
       }
     }
     __syncthreads();
+    AGX_BLK_T(4);
     // ---- phase 5: V <- Qxx - Qxw Kw: wave w owns rows 16 w .. 16 w + 15 of the 64 x 64 result
     agx_v4d acc[4];
 #pragma unroll
@@ -294,6 +322,7 @@ __global__ void __launch_bounds__(256, 2) k_riccati_blk(const DevOcp *__restrict
     for (int e = tid; e < NV * NX; e += nt) Kw[(long long)t * NV * NX + e] = Kl[e / NX][e % NX];
     if (grad && tid < NV) kw[(long long)t * NV + tid] = Kl[tid][NX];
     __syncthreads();  // every read of Qxx / Qxw / Kl is done
+    AGX_BLK_T(5);
     // ---- phase 6: the value function of node t (as computed: the next node symmetrises on reading), the next node's gap
 #pragma unroll
     for (int tj = 0; tj < 4; ++tj)
@@ -307,7 +336,12 @@ __global__ void __launch_bounds__(256, 2) k_riccati_blk(const DevOcp *__restrict
       if (tid < NX) fl[tid] = pf;
     }
     __syncthreads();
+    AGX_BLK_T(6);
   }
+#ifdef AGX_BLK_STAMP
+  if (tid == 0 && b == 0)
+    printf("k_riccati_blk phases (10 ns ticks over %d nodes): p1 %lld p2 %lld p3 %lld p4 %lld p5 %lld p6 %lld\n", T, ph_[1], ph_[2], ph_[3], ph_[4], ph_[5], ph_[6]);
+#endif
   if (gains_pass || !forward) return;
   // ---- forward pass: w = -kw - Kw dx (8 lanes per row, columns strided over them), then the state update
   double *dx = dxs + (long long)b * (T + 1) * NX, *ws = wss + (long long)b * T * NV;
