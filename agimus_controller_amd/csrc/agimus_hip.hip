@@ -96,6 +96,7 @@ struct agx_ocp {
   // that ran into max_solve_time would.  1.0 = wait for everyone (the default).
   double quorum_sqp = 1.0, quorum_qp = 1.0;
   bool fold_publish = false;  // small batches (B <= 204, polled hand-off): the head / accept kernels hand the counters to the host themselves (last workgroup to arrive) and the host asks after the head from the second iteration on; AGX_FOLD_PUBLISH=0/1 overrides
+  int n_cu = 256;         // compute units of the device (grid of the persistent kernels)
   bool no_empty = false;  // AGX_NO_EMPTY_LAUNCHES=1 (profiling): the host asks after the head of the step whether anybody searches and skips the trial launches otherwise, so that per-kernel averages are those of working launches
   double *d_ref = nullptr;  // owned tile [B][T+1][stride]
   // asynchronous reference upload (agx_ocp_set_refs_async): second tile / frame table filled by the copy stream while the
@@ -1069,6 +1070,10 @@ int agx_ocp_create(const agx_model *m, const agx_ocp_desc *d, int batch, int dev
   if (const char *e = getenv("AGX_FOLD_PUBLISH")) o->fold_publish = (e[0] != '0');
   if (const char *e = getenv("AGX_K1_FUSED")) o->k1_fused = (e[0] != '0');
   o->T = d->horizon; o->B = batch; o->device = device;
+  {
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && n > 0) o->n_cu = n;
+  }
   o->tile = AGX_TILE_DOUBLES(o->nv);
   const int ld = o->nv <= 8 ? 8 : 32;
   o->qt_size = 6 * o->nv * ld + 5 * ld + 8;  // QT<NV>::SIZE
