@@ -316,9 +316,9 @@ int fill_cons(const agx_constraint_row *rows, int n, int nv, int nvu, const DevM
 #if defined(AGX_ONLY_NV7) || (defined(AGX_GROUP) && AGX_GROUP == 0)  // AGX_ONLY_NV7: development builds, short compile
 #define AGX_FOR_NV(MACRO) MACRO(7)
 #elif defined(AGX_ONLY_NV30) || (defined(AGX_GROUP) && AGX_GROUP == 1)
-#define AGX_FOR_NV(MACRO) MACRO(30) MACRO(32)
+#define AGX_FOR_NV(MACRO) MACRO(16) MACRO(30) MACRO(32)
 #else
-#define AGX_FOR_NV(MACRO) MACRO(7) MACRO(30) MACRO(32)
+#define AGX_FOR_NV(MACRO) MACRO(7) MACRO(16) MACRO(30) MACRO(32)
 #endif
 
 int pad_capacity(int nv) {
@@ -482,11 +482,13 @@ int launch_riccati(agx_ocp *o, int forward, bool pair = false, int iter = 0, con
                            o->d_Kws, o->d_kws, o->d_dx, o->d_w, o->d_du, o->d_Kout, o->d_state, forward, 0);
     } else {
       (void)pair; (void)iter;
-      if constexpr (NV > 16) if (o->riccati_mfma) {
-        if (o->riccati_blk)
+      if constexpr (NV >= 16) if (o->riccati_mfma) {
+        bool blk = o->riccati_blk;
+        if constexpr (NV == 16) blk = true;  // k_riccati_mfma tiles 16 < nv <= 32 only
+        if (blk)
           hipLaunchKernelGGL((agx::k_riccati_blk<NV>), dim3(o->B), dim3(256), 0, o->stream, o->d_ocp, o->d_dt, qt, o->d_Kws, o->d_kws, o->d_dx,
                              o->d_w, o->d_state, forward, 0);
-        else
+        if constexpr (NV > 16) if (!blk)
           hipLaunchKernelGGL((agx::k_riccati_mfma<NV>), dim3(o->B), dim3(256), 0, o->stream, o->d_ocp, o->d_dt, qt, o->d_Kws, o->d_kws, o->d_dx,
                              o->d_w, o->d_state, forward, 0);
         HIPCHK(hipGetLastError());
@@ -568,11 +570,13 @@ int launch_gains(agx_ocp *o, int gmode = 0) {
       const int gsel = gmode == 0 ? 1 : gmode;
       hipLaunchKernelGGL((agx::k_sigma_tile_big<NV>), dim3((int)nodes), dim3(256), 0, o->stream, o->d_ocp, o->d_qt, o->d_qt2, o->d_aux);
       bool swept = false;
-      if constexpr (NV > 16) if (o->riccati_mfma) {
-        if (o->riccati_blk)
+      if constexpr (NV >= 16) if (o->riccati_mfma) {
+        bool blk = o->riccati_blk;
+        if constexpr (NV == 16) blk = true;
+        if (blk)
           hipLaunchKernelGGL((agx::k_riccati_blk<NV>), dim3(o->B), dim3(256), 0, o->stream, o->d_ocp, o->d_dt, o->d_qt2, o->d_Kws, o->d_kws,
                              o->d_dx, o->d_w, o->d_state, 0, gsel);
-        else
+        if constexpr (NV > 16) if (!blk)
           hipLaunchKernelGGL((agx::k_riccati_mfma<NV>), dim3(o->B), dim3(256), 0, o->stream, o->d_ocp, o->d_dt, o->d_qt2, o->d_Kws, o->d_kws,
                              o->d_dx, o->d_w, o->d_state, 0, gsel);
         swept = true;

@@ -77,8 +77,10 @@ __global__ void __launch_bounds__(256, 2) k_riccati_blk(const DevOcp *__restrict
                                                         double *__restrict__ kws, double *__restrict__ dxs,
                                                         double *__restrict__ wss, DevState *__restrict__ st, int forward,
                                                         int gains_pass) {
-  static_assert(NV > 16 && NV <= 32 && NV % 2 == 0, "2 x 2 tiles of Qww, 4 x 4 tiles of the value function");
-  constexpr int NX = 2 * NV, LV = NX + 1, LQ = 33, NW = 32;
+  static_assert(NV >= 16 && NV <= 32 && NV % 2 == 0, "Qww: one 16 x 16 tile (nv = 16) or 2 x 2; the value function: 2 x 2 or 4 x 4");
+  constexpr int NX = 2 * NV, NWT = (NV + 15) / 16, NW = 16 * NWT;  // tiles / padded size of Qww
+  constexpr int NXT = (NX + 15) / 16, NTW = NXT * NXT / 4;         // tiles per side of the value function, tiles per wave of its update
+  constexpr int LV = NX + 1, LQ = NW + 1;
   typedef QT<NV> Q;
   // V: the value function of node t + 1 as the update left it (not symmetrised, no dreg) until the element-wise pass of node t
   // replaces it by  Qxx = Hxx + Phi' (sym V + dreg) Phi,  the start value of the update's accumulators
@@ -211,27 +213,34 @@ __global__ void __launch_bounds__(256, 2) k_riccati_blk(const DevOcp *__restrict
     AGX_BLK_T(2);
     // ---- phase 3: Qww^-1 by blocks, in place (the pad rows / columns keep their unit diagonal)
     if (wave == inv_wave) {
-      agx_v4d A11, A12, A22;
+      agx_v4d A11;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        A11[r] = Qww[l4 + 4 * r][l15];
-        A12[r] = Qww[l4 + 4 * r][16 + l15];
-        A22[r] = Qww[16 + l4 + 4 * r][16 + l15];
-      }
-      const agx_v4d zero = {0.0, 0.0, 0.0, 0.0};
-      tile_inverse(A11, l4, l15);                              // inv11
-      const agx_v4d W = tile_xty(A11, A12, zero);              // inv11 A12
-      const agx_v4d Wt = tile_xty(A12, A11, zero);             // A12' inv11 = W'
-      agx_v4d Sc = tile_xty<true>(A12, W, A22);                // A22 - A12' W
-      tile_inverse(Sc, l4, l15);                               // invS
-      const agx_v4d B21 = tile_xty<true>(Sc, Wt, zero);        // -invS W'
-      const agx_v4d B11 = tile_xty<true>(Wt, B21, A11);        // inv11 - W B21
+      for (int r = 0; r < 4; ++r) A11[r] = Qww[l4 + 4 * r][l15];
+      tile_inverse(A11, l4, l15);  // inv11
+      if constexpr (NWT == 1) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        Qww[l4 + 4 * r][l15] = B11[r];
-        Qww[16 + l4 + 4 * r][l15] = B21[r];
-        Qww[l15][16 + l4 + 4 * r] = B21[r];
-        Qww[16 + l4 + 4 * r][16 + l15] = Sc[r];
+        for (int r = 0; r < 4; ++r) Qww[l4 + 4 * r][l15] = A11[r];
+      } else {
+        agx_v4d A12, A22;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          A12[r] = Qww[l4 + 4 * r][16 + l15];
+          A22[r] = Qww[16 + l4 + 4 * r][16 + l15];
+        }
+        const agx_v4d zero = {0.0, 0.0, 0.0, 0.0};
+        const agx_v4d W = tile_xty(A11, A12, zero);              // inv11 A12
+        const agx_v4d Wt = tile_xty(A12, A11, zero);             // A12' inv11 = W'
+        agx_v4d Sc = tile_xty<true>(A12, W, A22);                // A22 - A12' W
+        tile_inverse(Sc, l4, l15);                               // invS
+        const agx_v4d B21 = tile_xty<true>(Sc, Wt, zero);        // -invS W'
+        const agx_v4d B11 = tile_xty<true>(Wt, B21, A11);        // inv11 - W B21
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          Qww[l4 + 4 * r][l15] = B11[r];
+          Qww[16 + l4 + 4 * r][l15] = B21[r];
+          Qww[l15][16 + l4 + 4 * r] = B21[r];
+          Qww[16 + l4 + 4 * r][16 + l15] = Sc[r];
+        }
       }
     }
     __syncthreads();
@@ -243,69 +252,72 @@ __global__ void __launch_bounds__(256, 2) k_riccati_blk(const DevOcp *__restrict
     // checker's LLT see.
     for (int tj = wave; tj < (grad ? NT : (NX + 15) / 16); tj += 4) {
       const agx_v4d zero = {0.0, 0.0, 0.0, 0.0};
-      agx_v4d k0 = zero, k1 = zero;
+      agx_v4d kk[NWT], rr[NWT];
       const int xr = 16 * tj + l15, xrc = xr <= NX ? xr : 0;
 #pragma unroll
-      for (int ks = 0; ks < 8; ++ks) {
+      for (int ti = 0; ti < NWT; ++ti) kk[ti] = zero;
+#pragma unroll
+      for (int ks = 0; ks < 4 * NWT; ++ks) {
         const int k = 4 * ks + l4;
         const double bv = (xr <= NX && k < NV) ? Qxw[xrc][k] : 0.0;  // [Qwx | qw][k][xr]
-        k0 = __builtin_amdgcn_mfma_f64_16x16x4f64(Qww[l15][k], bv, k0, 0, 0, 0);
-        k1 = __builtin_amdgcn_mfma_f64_16x16x4f64(Qww[16 + l15][k], bv, k1, 0, 0, 0);
+#pragma unroll
+        for (int ti = 0; ti < NWT; ++ti) kk[ti] = __builtin_amdgcn_mfma_f64_16x16x4f64(Qww[16 * ti + l15][k], bv, kk[ti], 0, 0, 0);
       }
       // residual in the accumulator layout (rows l4 + 4 q of each row tile); the accumulator registers of x are the B operand,
       // k-index l4 + 4 q: the A operand takes the same columns of the matrix
-      agx_v4d r0, r1;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int ra = l4 + 4 * q, rb = 16 + ra;
-        r0[q] = (xr <= NX) ? Qxw[xrc][ra] : 0.0;
-        r1[q] = (xr <= NX && rb < NV) ? Qxw[xrc][rb < NV ? rb : 0] : 0.0;
-      }
+      for (int ti = 0; ti < NWT; ++ti)
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int ka = l4 + 4 * q, kb = 16 + ka;
-        r0 = __builtin_amdgcn_mfma_f64_16x16x4f64(-Qw0[l15][ka], k0[q], r0, 0, 0, 0);
-        r0 = __builtin_amdgcn_mfma_f64_16x16x4f64(-Qw0[l15][kb], k1[q], r0, 0, 0, 0);
-        r1 = __builtin_amdgcn_mfma_f64_16x16x4f64(-Qw0[16 + l15][ka], k0[q], r1, 0, 0, 0);
-        r1 = __builtin_amdgcn_mfma_f64_16x16x4f64(-Qw0[16 + l15][kb], k1[q], r1, 0, 0, 0);
-      }
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int ka = l4 + 4 * q, kb = 16 + ka;
-        k0 = __builtin_amdgcn_mfma_f64_16x16x4f64(Qww[l15][ka], r0[q], k0, 0, 0, 0);
-        k0 = __builtin_amdgcn_mfma_f64_16x16x4f64(Qww[l15][kb], r1[q], k0, 0, 0, 0);
-        k1 = __builtin_amdgcn_mfma_f64_16x16x4f64(Qww[16 + l15][ka], r0[q], k1, 0, 0, 0);
-        k1 = __builtin_amdgcn_mfma_f64_16x16x4f64(Qww[16 + l15][kb], r1[q], k1, 0, 0, 0);
-      }
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int ra = l4 + 4 * q, rb = 16 + ra;
-        if (xr <= NX) {
-          Kl[ra][xr] = k0[q];
-          if (rb < NV) Kl[rb][xr] = k1[q];
+        for (int q = 0; q < 4; ++q) {
+          const int ra = 16 * ti + l4 + 4 * q;
+          rr[ti][q] = (xr <= NX && ra < NV) ? Qxw[xrc][ra < NV ? ra : 0] : 0.0;
         }
-      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int ti = 0; ti < NWT; ++ti)
+#pragma unroll
+          for (int tk = 0; tk < NWT; ++tk)
+            rr[ti] = __builtin_amdgcn_mfma_f64_16x16x4f64(-Qw0[16 * ti + l15][16 * tk + l4 + 4 * q], kk[tk][q], rr[ti], 0, 0, 0);
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int ti = 0; ti < NWT; ++ti)
+#pragma unroll
+          for (int tk = 0; tk < NWT; ++tk)
+            kk[ti] = __builtin_amdgcn_mfma_f64_16x16x4f64(Qww[16 * ti + l15][16 * tk + l4 + 4 * q], rr[tk][q], kk[ti], 0, 0, 0);
+#pragma unroll
+      for (int ti = 0; ti < NWT; ++ti)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int ra = 16 * ti + l4 + 4 * q;
+          if (xr <= NX && ra < NV) Kl[ra][xr] = kk[ti][q];
+        }
     }
     __syncthreads();
     AGX_BLK_T(4);
     // ---- phase 5: V <- Qxx - Qxw Kw: wave w owns rows 16 w .. 16 w + 15 of the 64 x 64 result
-    agx_v4d acc[4];
+    // (tile n of wave w: the (w + 4 n)-th of the NXT x NXT tiles -- column band w of the 4 x 4 tiles, one tile each of the 2 x 2)
+    agx_v4d acc[NTW];
 #pragma unroll
-    for (int tj = 0; tj < 4; ++tj)
+    for (int n = 0; n < NTW; ++n) {
+      const int ti = (wave + 4 * n) / NXT, tj = (wave + 4 * n) % NXT;
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const int i = 16 * wave + l4 + 4 * q, j = 16 * tj + l15;
-        acc[tj][q] = (i < NX && j < NX) ? V[i < NX ? i : 0][j < NX ? j : 0] : 0.0;
+        const int i = 16 * ti + l4 + 4 * q, j = 16 * tj + l15;
+        acc[n][q] = (i < NX && j < NX) ? V[i < NX ? i : 0][j < NX ? j : 0] : 0.0;
       }
+    }
 #pragma unroll
-    for (int ks = 0; ks < 8; ++ks) {
-      const int k = 4 * ks + l4, i = 16 * wave + l15;
-      const double av = (k < NV && i < NX) ? -Qxw[i < NX ? i : 0][k] : 0.0;
+    for (int ks = 0; ks < 4 * NWT; ++ks) {
+      const int k = 4 * ks + l4;
 #pragma unroll
-      for (int tj = 0; tj < 4; ++tj) {
-        const int j = 16 * tj + l15;
+      for (int n = 0; n < NTW; ++n) {
+        const int ti = (wave + 4 * n) / NXT, tj = (wave + 4 * n) % NXT;
+        const int i = 16 * ti + l15, j = 16 * tj + l15;
+        const double av = (k < NV && i < NX) ? -Qxw[i < NX ? i : 0][k < NV ? k : 0] : 0.0;
         const double bv = (k < NV && j < NX) ? Kl[k < NV ? k : 0][j < NX ? j : 0] : 0.0;
-        acc[tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc[tj], 0, 0, 0);
+        acc[n] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc[n], 0, 0, 0);
       }
     }
     double vxn = 0.0;
@@ -325,12 +337,14 @@ __global__ void __launch_bounds__(256, 2) k_riccati_blk(const DevOcp *__restrict
     AGX_BLK_T(5);
     // ---- phase 6: the value function of node t (as computed: the next node symmetrises on reading), the next node's gap
 #pragma unroll
-    for (int tj = 0; tj < 4; ++tj)
+    for (int n = 0; n < NTW; ++n) {
+      const int ti = (wave + 4 * n) / NXT, tj = (wave + 4 * n) % NXT;
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const int i = 16 * wave + l4 + 4 * q, j = 16 * tj + l15;
-        if (i < NX && j < NX) V[i][j] = acc[tj][q];
+        const int i = 16 * ti + l4 + 4 * q, j = 16 * tj + l15;
+        if (i < NX && j < NX) V[i][j] = acc[n][q];
       }
+    }
     if (grad) {
       if ((tid & 3) == 0 && (tid >> 2) < NX) vx[tid >> 2] = vxn;
       if (tid < NX) fl[tid] = pf;
