@@ -235,9 +235,10 @@ int ensure_scratch(agx_ocp *o, size_t bytes) {
   return 0;
 }
 
-void fill_rows(const agx_cost_row *rows, int n, int nv, DevRows &d) {
+void fill_rows(const agx_cost_row *rows, int n, int nv, int nvu, DevRows &d) {
   std::memset(&d, 0, sizeof(d));
   d.n = n;
+  d.nvu = nvu;
   int off = 0;
   for (int r = 0; r < n; ++r) {
     d.kind[r] = rows[r].kind;
@@ -1043,8 +1044,8 @@ int agx_ocp_create(const agx_model *m, const agx_ocp_desc *d, int batch, int dev
         break;
       default: return fail("agx_ocp_create: residual kind " + std::to_string(row.kind) + " is not implemented on the HIP path yet");
     }
-    if (row.activation != AGX_ACT_WEIGHTED_QUAD && row.kind != AGX_RES_COLLISION)
-      return fail("agx_ocp_create: ActivationModelExp / QuadExp are implemented for scalar residuals (collision distance) only");
+    if (row.activation != AGX_ACT_WEIGHTED_QUAD && (row.kind == AGX_RES_CONTROL_GRAV || row.kind == AGX_RES_FRAME_VELOCITY))
+      return fail("agx_ocp_create: ActivationModelExp / QuadExp are not implemented for ControlGrav / FrameVelocity residuals");
     if (row.activation != AGX_ACT_WEIGHTED_QUAD && !(row.alpha > 0.0)) return fail("agx_ocp_create: activation alpha must be positive");
     if ((row.kind == AGX_RES_FRAME_PLACEMENT || row.kind == AGX_RES_FRAME_TRANSLATION || row.kind == AGX_RES_FRAME_ROTATION) &&
         (row.frame < 0 || row.frame >= m->h.nframes))
@@ -1086,8 +1087,8 @@ int agx_ocp_create(const agx_model *m, const agx_ocp_desc *d, int batch, int dev
   o->dt.assign(d->dt, d->dt + d->horizon);
   std::memset(&o->ho, 0, sizeof(o->ho));
   o->ho.T = o->T; o->ho.B = o->B; o->ho.stride = o->stride;
-  fill_rows(d->running_rows, d->n_running_rows, o->nv, o->ho.rows[0]);
-  fill_rows(d->terminal_rows, d->n_terminal_rows, o->nv, o->ho.rows[1]);
+  fill_rows(d->running_rows, d->n_running_rows, o->nv, m->nvu, o->ho.rows[0]);
+  fill_rows(d->terminal_rows, d->n_terminal_rows, o->nv, m->nvu, o->ho.rows[1]);
   o->ho.tol = d->termination_tolerance;
   o->ho.mu_dyn = d->mu_dynamic;
   o->ho.mu_con = d->mu_constraint;
@@ -1143,10 +1144,18 @@ int agx_ocp_create(const agx_model *m, const agx_ocp_desc *d, int batch, int dev
       for (int i = 0; i < r.n; ++i) n += (r.kind[i] == AGX_RES_COLLISION);
       return n;
     };
+    // Exp / QuadExp activations on vector residuals (ocp_croco_generic.py:118-131) are evaluated by the one-lane-per-node kernel
+    auto n_vector_exp_rows = [&]() {
+      int n = 0;
+      for (int lay = 0; lay < 2; ++lay)
+        for (int i = 0; i < o->ho.rows[lay].n; ++i)
+          if (o->ho.rows[lay].active[i] && o->ho.rows[lay].act[i] != AGX_ACT_WEIGHTED_QUAD && o->ho.rows[lay].kind[i] != AGX_RES_COLLISION) ++n;
+      return n;
+    };
     // at most one collision cost row per node type, capsule / sphere / box pair, serial chain: the COLL variant
     o->lanes_coll = n_collision_rows(o->ho.rows[0]) + n_collision_rows(o->ho.rows[1]) > 0;
     o->lanes_ok = o->stride <= agx::kLjRef && n_frame_rows(o->ho.rows[0]) <= 2 && n_frame_rows(o->ho.rows[1]) <= 2 &&
-                  n_collision_rows(o->ho.rows[0]) <= 1 && n_collision_rows(o->ho.rows[1]) <= 1 && !o->general;
+                  n_collision_rows(o->ho.rows[0]) <= 1 && n_collision_rows(o->ho.rows[1]) <= 1 && !o->general && !n_vector_exp_rows();
   }
   if (o->nv > 8) {
     // the workgroup-per-node kernels stage the reference tile and the dense residual rows of a node in LDS

@@ -200,11 +200,34 @@ __device__ __forceinline__ void wg_costs(WgNode<NV> &L, const DevModel &m, const
     const double *rr = tile + 1;
     const double *aw = rr + rows.nref[r];
     const int kind = rows.kind[r];
-    if (kind == AGX_RES_STATE) {
+    const bool quad = rows.act[r] == AGX_ACT_WEIGHTED_QUAD;
+    // sum over the lanes of the wave (Exp / QuadExp activations are functions of |r|^2 of the whole row)
+    auto wave_sum = [](double v) {
+#pragma unroll
+      for (int sft = 1; sft < 64; sft <<= 1) v += __shfl_xor(v, sft, 64);
+      return v;
+    };
+    if (kind == AGX_RES_STATE && !quad) {
+      const double rq = qj - rr[j], rvv = vj - rr[NV + j];
+      const ActVec A = activation_vec(rows.act[r], rows.alpha[r], wave_sum(jl ? rq * rq + rvv * rvv : 0.0));
+      const bool real = j < rows.nvu;  // pad joints: see DevRows::nvu
+      if (lane == 0) cost += wi * A.a;
+      Lq += wi * A.c1 * rq; Lv += wi * A.c1 * rvv;
+      Lvv += real ? wi * (A.c2 + A.c3 * rvv * rvv) : 1.0;
+      dqq += real ? wi * (A.c2 + A.c3 * rq * rq) : 1.0;
+    } else if (kind == AGX_RES_STATE) {
       const double rq = qj - rr[j], rvv = vj - rr[NV + j];
       const double wq = wi * aw[j], wv = wi * aw[NV + j];
       cost += 0.5 * (wq * rq * rq + wv * rvv * rvv);
       Lq += wq * rq; Lv += wv * rvv; Lvv += wv; dqq += wq;
+    } else if (kind == AGX_RES_CONTROL && !quad) {
+      if (!TERM) {
+        const double ru = uj - rr[j];
+        const ActVec A = activation_vec(rows.act[r], rows.alpha[r], wave_sum(jl ? ru * ru : 0.0));
+        if (lane == 0) cost += wi * A.a;
+        Lu += wi * A.c1 * ru;
+        Luu += (j < rows.nvu) ? wi * (A.c2 + A.c3 * ru * ru) : 1.0;
+      }
     } else if (kind == AGX_RES_CONTROL) {
       if (!TERM) {
         const double ru = uj - rr[j], wu = wi * aw[j];
@@ -260,13 +283,24 @@ __device__ __forceinline__ void wg_costs(WgNode<NV> &L, const DevModel &m, const
         }
       }
       double a = 0.0;
+      ActVec A = {0.0, 0.0, 0.0, 0.0};
+      if (!quad) {
+        double n2 = 0.0;
+#pragma unroll
+        for (int e = 0; e < 6; ++e)
+          if (e < nr) n2 += res[e] * res[e];
+        A = activation_vec(rows.act[r], rows.alpha[r], n2);
+        a = wi * A.a;
+      }
 #pragma unroll
       for (int e = 0; e < 6; ++e) {
-        const double we = (e < nr) ? wi * aw[e] : 0.0;
-        a += 0.5 * we * res[e] * res[e];
+        // weights of the Gauss-Newton Hessian (J' diag(we) J) and of the gradient (J' ge) of the row's activation
+        const double we = (e < nr) ? (quad ? wi * aw[e] : wi * (A.c2 + A.c3 * res[e] * res[e])) : 0.0;
+        const double ge = (e < nr) ? (quad ? we * res[e] : wi * A.c1 * res[e]) : 0.0;
+        if (quad) a += 0.5 * we * res[e] * res[e];
         if (DIFF && e < nr) {
           const double jc = on ? Jc[e] : 0.0;
-          Lq += we * res[e] * jc;
+          Lq += ge * jc;
           if (jl) L.w.c.J[nJ + e][j] = jc;
           if (lane == 0) L.w.c.wJ[nJ + e] = we;
         }

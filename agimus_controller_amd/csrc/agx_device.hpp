@@ -50,7 +50,9 @@ struct DevRows {
   int kind[AGX_MAX_ROWS], act[AGX_MAX_ROWS], active[AGX_MAX_ROWS], frame[AGX_MAX_ROWS], frame_b[AGX_MAX_ROWS];
   int off[AGX_MAX_ROWS], nref[AGX_MAX_ROWS], nr[AGX_MAX_ROWS];
   double alpha[AGX_MAX_ROWS], weight[AGX_MAX_ROWS];
-  int general, pad_;  // some active row is a ControlGrav / FrameVelocity residual (agx_general.hpp)
+  int general;  // some active row is a ControlGrav / FrameVelocity residual (agx_general.hpp)
+  int nvu;      // joints of the caller's model: the pad joints of a model below the compiled capacity take no part in an Exp / QuadExp
+                // activation of a State / Control row (their second derivative is set to 1, as the unit weights of the quadratic rows)
 };
 
 // ConstraintListItem rows of one node type:  lb <= g(x, u) <= ub, g stacked over the rows.
@@ -717,6 +719,29 @@ AGX_DEV void activation1(int act, double alpha, double w, double r, double &a, d
   }
 }
 
+// The same activations on a vector residual (ocp_croco_generic.py:118-131 builds them with residual.nr components): the
+// value is a function of |r|^2, the second derivative is kept diagonal as crocoddyl's ActivationDataAbstract stores it:
+//   QuadExp  a = exp(-|r|^2 / alpha),  a_r = -2 a / alpha r_j,         a_rr = (-2 / alpha + 4 r_j^2 / alpha^2) a
+//   Exp      a = exp(-|r| / alpha),    a_r = -a / (alpha |r|) r_j,     a_rr = a / alpha^2
+// returned as a and the coefficients of  a_r = c1 r_j,  a_rr = c2 + c3 r_j^2  (recalled forms: parity unpinned, as activation1).
+struct ActVec { double a, c1, c2, c3; };
+AGX_DEV ActVec activation_vec(int act, double alpha, double n2) {
+  ActVec A;
+  if (act == AGX_ACT_QUAD_EXP) {
+    A.a = exp(-n2 / alpha);
+    A.c1 = -2.0 * A.a / alpha;
+    A.c2 = -2.0 * A.a / alpha;
+    A.c3 = 4.0 * A.a / (alpha * alpha);
+  } else {
+    const double n = sqrt(n2);
+    A.a = exp(-n / alpha);
+    A.c1 = n > 0.0 ? -A.a / (alpha * n) : 0.0;
+    A.c2 = A.a / (alpha * alpha);
+    A.c3 = 0.0;
+  }
+  return A;
+}
+
 // Closest points of two segments (Ericson 5.1.9; capsule / capsule narrow phase behind
 // colmpc.ResidualDistanceCollision): parameters s, t in [0, 1].
 AGX_DEV double clamp01(double x) { return x < 0.0 ? 0.0 : (x > 1.0 ? 1.0 : x); }
@@ -875,7 +900,28 @@ AGX_UNROLL_NV
     const double *rr = tile + 1;
     const double *aw = rr + rows.nref[r];
     const int kind = rows.kind[r];
-    if (kind == AGX_RES_STATE) {
+    const bool quad = rows.act[r] == AGX_ACT_WEIGHTED_QUAD;
+    if (kind == AGX_RES_STATE && !quad) {
+      double n2 = 0.0;
+AGX_UNROLL_NV
+      for (int i = 0; i < NV; ++i) {
+        const double rq = x[i] - rr[i], rv = x[NV + i] - rr[NV + i];
+        n2 += rq * rq + rv * rv;
+      }
+      const ActVec A = activation_vec(rows.act[r], rows.alpha[r], n2);
+      c.cost += wi * A.a;
+      if (DIFF) {
+AGX_UNROLL_NV
+        for (int i = 0; i < NV; ++i) {
+          const double rq = x[i] - rr[i], rv = x[NV + i] - rr[NV + i];
+          const bool real = i < rows.nvu;
+          c.Lq[i] += wi * A.c1 * rq;
+          c.Lv[i] += wi * A.c1 * rv;
+          c.Lqq[i][i] += real ? wi * (A.c2 + A.c3 * rq * rq) : 1.0;
+          c.Lvv[i] += real ? wi * (A.c2 + A.c3 * rv * rv) : 1.0;
+        }
+      }
+    } else if (kind == AGX_RES_STATE) {
       double a = 0.0;
 AGX_UNROLL_NV
       for (int i = 0; i < NV; ++i) {
@@ -889,6 +935,22 @@ AGX_UNROLL_NV
         }
       }
       c.cost += wi * a;
+    } else if (kind == AGX_RES_CONTROL && !quad) {
+      if (!TERM) {
+        double n2 = 0.0;
+AGX_UNROLL_NV
+        for (int i = 0; i < NV; ++i) n2 += (u[i] - rr[i]) * (u[i] - rr[i]);
+        const ActVec A = activation_vec(rows.act[r], rows.alpha[r], n2);
+        c.cost += wi * A.a;
+        if (DIFF) {
+AGX_UNROLL_NV
+          for (int i = 0; i < NV; ++i) {
+            const double ru = u[i] - rr[i];
+            c.Lu[i] += wi * A.c1 * ru;
+            c.Luu[i] += (i < rows.nvu) ? wi * (A.c2 + A.c3 * ru * ru) : 1.0;
+          }
+        }
+      }
     } else if (kind == AGX_RES_CONTROL) {
       if (!TERM) {
         double a = 0.0;
@@ -974,22 +1036,37 @@ AGX_UNROLL_NV
           }
         }
       }
-      double a = 0.0;
+      // weights of the gradient (J' ge) and of the Gauss-Newton Hessian (J' diag(we) J) of the row's activation
+      double a = 0.0, we[6], ge[6];
+      if (quad) {
 #pragma unroll
-      for (int e = 0; e < 6; ++e)
-        if (e < nr) a += 0.5 * aw[e] * res[e] * res[e];
+        for (int e = 0; e < 6; ++e) {
+          if (e < nr) a += 0.5 * aw[e] * res[e] * res[e];
+          we[e] = (e < nr) ? wi * aw[e] : 0.0;
+          ge[e] = we[e] * res[e];
+        }
+      } else {
+        double n2 = 0.0;
+#pragma unroll
+        for (int e = 0; e < 6; ++e)
+          if (e < nr) n2 += res[e] * res[e];
+        const ActVec A = activation_vec(rows.act[r], rows.alpha[r], n2);
+        a = A.a;
+#pragma unroll
+        for (int e = 0; e < 6; ++e) {
+          we[e] = (e < nr) ? wi * (A.c2 + A.c3 * res[e] * res[e]) : 0.0;
+          ge[e] = (e < nr) ? wi * A.c1 * res[e] : 0.0;
+        }
+      }
       c.cost += wi * a;
       if (DIFF) {
-        // J' W r and J' W J with the six residual rows innermost: one update per Hessian element
+        // J' ge and J' W J with the six residual rows innermost: one update per Hessian element
         // (large models keep Lqq in scratch: a read-modify-write per row and element serialises)
-        double we[6];
-#pragma unroll
-        for (int e = 0; e < 6; ++e) we[e] = (e < nr) ? wi * aw[e] : 0.0;
 AGX_UNROLL_NV
         for (int i = 0; i < NV; ++i) {
           double wj[6], gi = 0.0;
 #pragma unroll
-          for (int e = 0; e < 6; ++e) { wj[e] = we[e] * J[e][i]; gi += wj[e] * res[e]; }
+          for (int e = 0; e < 6; ++e) { wj[e] = we[e] * J[e][i]; gi += ge[e] * J[e][i]; }
           c.Lq[i] += gi;
 AGX_UNROLL_NV
           for (int j = 0; j <= i; ++j) {

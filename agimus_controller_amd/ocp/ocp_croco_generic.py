@@ -601,8 +601,8 @@ class DifferentialActionModelFreeFwdDynamics(DifferentialActionModel):
             kind = res.kind
             act_kind = _abi.ACT_WEIGHTED_QUAD if act is None else act.kind
             alpha = 1.0 if act is None or act_kind == _abi.ACT_WEIGHTED_QUAD else act.alpha_value
-            if act_kind != _abi.ACT_WEIGHTED_QUAD and kind != _abi.RES_COLLISION:
-                raise NotImplementedError(f"cost '{item.name}': {type(act).__name__} is implemented for scalar residuals (collision distance) only")
+            if act_kind != _abi.ACT_WEIGHTED_QUAD and kind in (_abi.RES_CONTROL_GRAV, _abi.RES_FRAME_VELOCITY):
+                raise NotImplementedError(f"cost '{item.name}': {type(act).__name__} is not implemented for ControlGrav / FrameVelocity residuals")
             if kind == _abi.RES_COLLISION:
                 fa, fb = res.geometry_frames(data)
                 rows.append(_abi.RowSpec(kind=kind, activation=act_kind, active=bool(item.active), frame=fa, frame_b=fb,

@@ -85,7 +85,9 @@ def random_goal_problem(table, T, dt, B, seed, frame=None, rows="goal", timestep
     rng = np.random.default_rng(seed)
     if frame is None:
         frame = len(table.frame_names) - 1
-    if rows == "goal":
+    if isinstance(rows, tuple):
+        running, terminal = rows  # the caller's own row tables
+    elif rows == "goal":
         running, terminal = goal_reaching_rows(frame)
     elif rows == "collision":
         running, terminal = collision_avoidance_rows(table, frame, alpha=0.05)
@@ -119,6 +121,12 @@ def random_goal_problem(table, T, dt, B, seed, frame=None, rows="goal", timestep
                         R = rt.rpy(*rng.uniform(-1.0, 1.0, 3))
                         rr[b, t, :9] = R.reshape(9)
                         rr[b, t, 9:] = rng.uniform(-0.5, 0.5, 3) + np.array([0.3, 0.0, 0.5])
+            elif r.kind == _abi.RES_FRAME_TRANSLATION:
+                rr[...] = rng.uniform(-0.5, 0.5, rr.shape) + np.array([0.3, 0.0, 0.5])
+            elif r.kind == _abi.RES_FRAME_ROTATION:
+                for b in range(B):
+                    for t in range(n):
+                        rr[b, t, :9] = rt.rpy(*rng.uniform(-1.0, 1.0, 3)).reshape(9)
     x0 = np.concatenate([qc[:, 0, :] + rng.normal(0, 0.02, (B, nv)), rng.normal(0, 0.1, (B, nv))], axis=1)
     xs = np.repeat(x0[:, None, :], T + 1, axis=1) + rng.normal(0, 0.01, (B, T + 1, 2 * nv))
     us = rng.normal(0, 1.0, (B, T, nv))

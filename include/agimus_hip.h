@@ -51,9 +51,11 @@ enum agx_residual_kind {
 /* Activation kinds, ocp_croco_generic.py:93-143.                               */
 enum agx_activation_kind {
   AGX_ACT_WEIGHTED_QUAD = 0, /* a = 1/2 sum w_j r_j^2 (also the default quad, w = 1) */
-  AGX_ACT_EXP = 1,           /* colmpc ActivationModelExp(alpha)                    */
-  AGX_ACT_QUAD_EXP = 2       /* colmpc ActivationModelQuadExp(alpha)                */
+  AGX_ACT_EXP = 1,           /* colmpc ActivationModelExp(nr, alpha):     a = exp(-|r| / alpha)   */
+  AGX_ACT_QUAD_EXP = 2       /* colmpc ActivationModelQuadExp(nr, alpha): a = exp(-|r|^2 / alpha) */
 };
+/* Exp / QuadExp: any residual but ControlGrav / FrameVelocity; |r| over the nr components of the row, diagonal second
+ * derivative; the activation weights of the row's tile are ignored.  Forms recalled, parity against colmpc unpinned. */
 
 /* One CostModelSumItem (ocp_croco_generic.py:578-585) lowered to a table row.
  * Per-node data of the row lives in the reference tile (agx_ocp_set_refs):

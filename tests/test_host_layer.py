@@ -213,6 +213,13 @@ def test_yaml_unknown_class_and_unsupported_components():
     rows = sp.running_model.differential.lower(gen.BuildData(rm.robot_model, 7, rm.collision_model))
     assert rows[-1].kind == _abi.RES_COLLISION and rows[-1].activation == _abi.ACT_QUAD_EXP
     assert (rows[-1].frame, rows[-1].frame_b) == (table.frame_id("panda_link5_capsule_0"), table.frame_id("obstacle"))
+    # ActivationModelExp on a vector residual (ocp_croco_generic.py:118-131 builds it with residual.nr components)
+    vec = yaml.safe_load(REFERENCE_STYLE_YAML)
+    vec["running_model"]["differential"]["costs"].append(
+        {"name": "state_exp", "cost": {"class": "CostModelResidual", "residual": {"class": "ResidualModelState"},
+                                       "activation": {"class": "ActivationModelExp", "alpha": 40.0}}})
+    rows = gen.ShootingProblem(**vec).running_model.differential.lower(gen.BuildData(panda_robot_models().robot_model, 7))
+    assert rows[-1].kind == _abi.RES_STATE and rows[-1].activation == _abi.ACT_EXP and rows[-1].alpha == 40.0
 
 
 def test_add_modules_extends_the_schema():
