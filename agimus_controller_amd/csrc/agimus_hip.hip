@@ -95,6 +95,10 @@ struct agx_ocp {
   // iterate (solved = 0 / qp_iters = max_qp_iters) and continue from it at the next MPC step, as a lone controller
   // that ran into max_solve_time would.  1.0 = wait for everyone (the default).
   double quorum_sqp = 1.0, quorum_qp = 1.0;
+  bool admm_loop_always = false;  // AGX_ADMM_LOOP=2 (tests): k_admm_loop whatever the number of unfinished instances
+  bool admm_loop = true;      // AGX_ADMM_LOOP=0: every ADMM iteration as three launches (sweep, update, reduce) instead of k_admm_loop
+  int n_unfinished = 1 << 30; // instances the SQP loop still works on (host's last count): k_admm_loop serves the tail of a step, when
+                              // few instances are left (with the whole batch active the node-parallel update across the chip is faster)
   bool fold_publish = false;  // small batches (B <= 204, polled hand-off): the head / accept kernels hand the counters to the host themselves (last workgroup to arrive) and the host asks after the head from the second iteration on; AGX_FOLD_PUBLISH=0/1 overrides
   int n_cu = 256;         // compute units of the device (grid of the persistent kernels)
   bool no_empty = false;  // AGX_NO_EMPTY_LAUNCHES=1 (profiling): the host asks after the head of the step whether anybody searches and skips the trial launches otherwise, so that per-kernel averages are those of working launches
@@ -718,14 +722,45 @@ int admm_direction(agx_ocp *o, bool prefactor = false) {
                          o->d_us, o->d_cg, o->d_cjac, o->d_nodestat, o->d_state, 0);
     HIPCHK(hipGetLastError());
     const int max_qp = o->ho.max_qp;
-    for (int iter = 1; iter <= max_qp; ++iter) {
+    // Polls the count of converged QPs; true when the loop ends here (quorum reached: the others are capped at `iter`)
+    auto quorum_reached = [&](int iter, bool *stop) -> int {
+      int n_conv = 0;
+      *stop = false;
+      if (read_int(o, o->d_ndone + 1, 4, 5, &n_conv)) return -1;
+      if (n_conv >= quorum_count(o->B, o->quorum_qp)) {
+        if (n_conv < o->B && iter < max_qp) {  // quorum reached: the others stop here with the iterations they ran
+          hipLaunchKernelGGL(agx::k_admm_cap, dim3((o->B + 255) / 256), dim3(256), 0, o->stream, o->d_state, o->B, iter);
+          HIPCHK(hipGetLastError());
+        }
+        *stop = true;
+      }
+      return 0;
+    };
+    for (int iter = 1; iter <= max_qp;) {
       // augmented Hessians change at the first iteration and after a rho update (k_admm_reduce decides at
       // multiples of kRhoInterval); in between k_admm_update leaves the next gradient behind
+      const bool boundary = iter == 1 || (iter > 2 && (iter - 1) % agx::kRhoInterval == 0);
+      if (!boundary && o->admm_loop && o->admm_segments && (o->admm_loop_always || 4 * o->n_unfinished <= o->B)) {
+        // gradient-only iterations up to the next rho check in one launch per instance (k_admm_loop); with a quorum < 1 in the
+        // chunks of the host's polling schedule, so that which instances are cut does not depend on the workgroups' progress
+        int last = ((iter - 1) / agx::kRhoInterval + 1) * agx::kRhoInterval;
+        if (o->quorum_qp < 1.0) last = std::min(last, ((iter + 3) / 4) * 4);
+        last = std::min(last, max_qp);
+        hipLaunchKernelGGL((agx::k_admm_loop<NV>), dim3(o->B), dim3(64 * agx::kSeg), 0, o->stream, o->d_ocp, o->d_dt, o->d_qt, o->d_qt2, o->d_aux,
+                           o->d_Kws, o->d_kws, o->d_dx, o->d_w, o->d_du, o->d_cx, o->d_cg, o->d_cjac, o->d_y, o->d_z, o->d_nodestat,
+                           o->d_admmstat, o->d_state, o->d_fac, o->d_segP, iter, last, o->d_ndone + 1);
+        HIPCHK(hipGetLastError());
+        iter = last + 1;
+        bool stop;
+        if (quorum_reached(last, &stop)) return -1;
+        if (stop) break;
+        continue;
+      }
       const bool pre = prefactor && iter == 1;  // Hessian and factors of this iteration exist: gradient only
-      if (iter == 1 || (iter > 2 && (iter - 1) % agx::kRhoInterval == 0))
+      if (boundary)
         hipLaunchKernelGGL((agx::k_admm_tile<NV>), dim3(g8b), dim3(128), 0, o->stream, o->d_ocp, o->d_qt, o->d_qt2, o->d_aux, o->d_cx,
                            o->d_du, o->d_cjac, o->d_y, o->d_z, o->d_state, pre ? 1 : 0);
-      const bool may_refactor = !pre && (iter == 1 || (iter > 2 && (iter - 1) % agx::kRhoInterval == 0));
+      const bool may_refactor = !pre && boundary;
       hipLaunchKernelGGL((agx::k_riccati_admm<NV>), dim3(o->B), dim3(64 * agx::kSeg), 0, o->stream, o->d_ocp, o->d_dt, o->d_qt2, o->d_aux,
                          o->d_Kws, o->d_kws, o->d_dx, o->d_w, o->d_du, o->d_Kout, o->d_state, o->d_fac,
                          o->admm_segments ? (const double *)o->d_segP : (const double *)nullptr, pre ? 1 : 0);
@@ -738,16 +773,11 @@ int admm_direction(agx_ocp *o, bool prefactor = false) {
                          o->d_ndone + 1);
       HIPCHK(hipGetLastError());
       if (iter % 4 == 0 || iter == max_qp) {
-        int n_conv = 0;
-        if (read_int(o, o->d_ndone + 1, 4, 5, &n_conv)) return -1;
-        if (n_conv >= quorum_count(o->B, o->quorum_qp)) {
-          if (n_conv < o->B && iter < max_qp) {  // quorum reached: the others stop here with the iterations they ran
-            hipLaunchKernelGGL(agx::k_admm_cap, dim3((o->B + 255) / 256), dim3(256), 0, o->stream, o->d_state, o->B, iter);
-            HIPCHK(hipGetLastError());
-          }
-          break;
-        }
+        bool stop;
+        if (quorum_reached(iter, &stop)) return -1;
+        if (stop) break;
       }
+      ++iter;
     }
     // the gains the solver reports: those of the last ADMM backward pass, in u-space
     const long long units = (long long)o->B * o->T * 16;
@@ -858,6 +888,7 @@ int solve_resident(agx_ocp *o, int max_iter, double max_time, bool prologue_done
   int prev_done = 0;
   for (int it = 0; it < max_iter; ++it) {
     const bool pair = o->speculate && it >= 1 && !o->has_con && o->nv <= 7;  // large models: gains only on exit
+    o->n_unfinished = o->B - prev_done;
     // derivative pass: running and terminal nodes in one launch; under agx_ocp_profile the running
     // nodes get their own launch so that the kernel the roofline is quoted on is timed alone
     if (need_k1) {
@@ -1073,6 +1104,7 @@ int agx_ocp_create(const agx_model *m, const agx_ocp_desc *d, int batch, int dev
   if (const char *e = getenv("AGX_NO_EMPTY_LAUNCHES")) o->no_empty = (e[0] != '0');
   o->fold_publish = batch <= 204;
   if (const char *e = getenv("AGX_FOLD_PUBLISH")) o->fold_publish = (e[0] != '0');
+  if (const char *e = getenv("AGX_ADMM_LOOP")) { o->admm_loop = (e[0] != '0'); o->admm_loop_always = (e[0] == '2'); }
   if (const char *e = getenv("AGX_K1_FUSED")) o->k1_fused = (e[0] != '0');
   o->T = d->horizon; o->B = batch; o->device = device;
   {

@@ -618,6 +618,9 @@ __global__ void __launch_bounds__(64 * kSeg) k_riccati_admm(const DevOcp *__rest
   const int b = blockIdx.x;
   const DevState &S = st[b];
   if (S.done || S.admm_conv) return;
+  // the factorisation of this iteration (k_riccati_lqr_prefactor, launched before this kernel) broke down: k_admm_reduce stops
+  // the instance and k_sqp_head discards the direction -- no gradient sweep on factors that do not exist
+  if (force_vec && S.dir_fail) return;
   if (S.admm_refactor && !force_vec) {  // force_vec: the factors of this Hessian exist already (k_riccati_lqr_prefactor)
     if (threadIdx.x < 64) riccati_body<NV, false, true>(b, op, dts, qts, auxs, Kws, kws, dxs, wss, dus, Kout, st, 1, 0, 0, facs);
   } else if (segP) {
@@ -655,15 +658,14 @@ __global__ void __launch_bounds__(64, 2) k_riccati_lqr_prefactor(const DevOcp *_
 // KKT share through the optimality identity of the augmented QP (constraints):
 //   Lu + Fu' lam' + Gu' y = -[(Luu + preg) du + sigma (du - du_c) + Gu' (rho C d + h - y)]
 //   Lx + Fx' lam' - lam + Gx' y = -[(Lxx + dreg) dx + sigma (dx - dx_c) + Gx' (rho C d + h - y)],  h = y_old - rho z_old
+// (device function: called by k_admm_update for the whole batch and by k_admm_loop for the nodes of its instance; out4: the
+// node's primal / dual residual norms and their scales, zero for lanes without a node)
 template <int NV>
-__global__ void __launch_bounds__(256) k_admm_update(const DevOcp *__restrict__ op, const double *__restrict__ qts,
-                                                     const double *__restrict__ auxs, const double *__restrict__ dxs,
-                                                     const double *__restrict__ wss, double *__restrict__ dus,
-                                                     double *__restrict__ cxs, const double *__restrict__ cg,
-                                                     const double *__restrict__ cjac, double *__restrict__ ys,
-                                                     double *__restrict__ zs, double *__restrict__ nodestat,
-                                                     double *__restrict__ admmstat, double *__restrict__ qt2s,
-                                                     const DevState *__restrict__ st) {
+__device__ __forceinline__ void admm_update_node(const DevOcp *op, const long long node, const bool ok_in, const double *qts,
+                                                 const double *auxs, const double *dxs, const double *wss, double *dus,
+                                                 double *cxs, const double *cg, const double *cjac, double *ys, double *zs,
+                                                 double *nodestat, double *admmstat, double *qt2s, const DevState *st,
+                                                 double *out4) {
   constexpr int NX = 2 * NV;
   typedef QT<NV> Q;
   typedef AUX<NV> A;
@@ -671,8 +673,8 @@ __global__ void __launch_bounds__(256) k_admm_update(const DevOcp *__restrict__ 
   const int T = o.T;
   const int l8 = threadIdx.x & 7;
   const long long n_nodes = (long long)o.B * (T + 1);
-  const long long node = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 3;
-  const bool ok = node < n_nodes;
+  const bool ok = ok_in && node < n_nodes;
+  out4[0] = 0.0; out4[1] = 0.0; out4[2] = 0.0; out4[3] = 0.0;
   const long long nid = ok ? node : 0;
   const int b = (int)(nid / (T + 1)), t = (int)(nid % (T + 1));
   const DevState &S = st[b];
@@ -810,7 +812,46 @@ __global__ void __launch_bounds__(256) k_admm_update(const DevOcp *__restrict__ 
       double *as = admmstat + nid * 4;
       as[0] = primal; as[1] = dual; as[2] = primal_rel; as[3] = drel;
     }
+    out4[0] = primal; out4[1] = dual; out4[2] = primal_rel; out4[3] = drel;
   }
+}
+
+template <int NV>
+__global__ void __launch_bounds__(256) k_admm_update(const DevOcp *__restrict__ op, const double *__restrict__ qts,
+                                                     const double *__restrict__ auxs, const double *__restrict__ dxs,
+                                                     const double *__restrict__ wss, double *__restrict__ dus,
+                                                     double *__restrict__ cxs, const double *__restrict__ cg,
+                                                     const double *__restrict__ cjac, double *__restrict__ ys,
+                                                     double *__restrict__ zs, double *__restrict__ nodestat,
+                                                     double *__restrict__ admmstat, double *__restrict__ qt2s,
+                                                     const DevState *__restrict__ st) {
+  double out4[4];
+  admm_update_node<NV>(op, ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 3, true, qts, auxs, dxs, wss, dus, cxs, cg, cjac, ys, zs,
+                       nodestat, admmstat, qt2s, st, out4);
+}
+
+
+// One thread per instance: rho adaptation (update_rho_vec) and the convergence test from the residual norms of iteration `iter`.
+// Returns 1 when the QP has converged (or ran into max_qp), 2 when rho changed (the next sweep factorises again), else 0.
+__device__ __forceinline__ int admm_reduce_decide(const DevOcp &o, DevState &S, const double np_, const double nd, const double npr,
+                                                  const double ndr, const int iter, int *__restrict__ n_conv) {
+  // update_rho_vec (std::max / std::min semantics for the 0/0 cases)
+  const double scale = sqrt((np_ * ndr) / (nd * npr));
+  double est = scale * S.rho_sparse;
+  est = (est < kRhoMin) ? kRhoMin : est;
+  est = (kRhoMax < est) ? kRhoMax : est;
+  int refactor = 0;
+  if (iter % kRhoInterval == 0 && iter > 1)
+    if (est > S.rho_sparse * kAdaptiveRhoTol || est < S.rho_sparse / kAdaptiveRhoTol) { S.rho_sparse = est; refactor = 1; }
+  S.admm_refactor = refactor;  // unchanged rho: the next sweep only redoes the gradient recursion
+  const bool conv = (np_ <= o.eps_abs + o.eps_rel * npr) && (nd <= o.eps_abs + o.eps_rel * ndr);
+  if (conv || iter == o.max_qp) {
+    S.admm_conv = 1;
+    S.admm_iter = conv ? iter : o.max_qp;
+    atomicAdd(n_conv, 1);
+    return 1;
+  }
+  return refactor ? 2 : 0;
 }
 
 // Per instance: residual norms over the nodes, rho adaptation (update_rho_vec), convergence.
@@ -837,22 +878,58 @@ __global__ void __launch_bounds__(128) k_admm_reduce(const DevOcp *__restrict__ 
     for (int k = 0; k < 4; ++k) red[k][tid >> 6] = v[k];
   __syncthreads();
   if (tid != 0) return;
-  const double np_ = fmax(red[0][0], red[0][1]), nd = fmax(red[1][0], red[1][1]);
-  const double npr = fmax(red[2][0], red[2][1]), ndr = fmax(red[3][0], red[3][1]);
-  // update_rho_vec (std::max / std::min semantics for the 0/0 cases)
-  const double scale = sqrt((np_ * ndr) / (nd * npr));
-  double est = scale * S.rho_sparse;
-  est = (est < kRhoMin) ? kRhoMin : est;
-  est = (kRhoMax < est) ? kRhoMax : est;
-  int refactor = 0;
-  if (iter % kRhoInterval == 0 && iter > 1)
-    if (est > S.rho_sparse * kAdaptiveRhoTol || est < S.rho_sparse / kAdaptiveRhoTol) { S.rho_sparse = est; refactor = 1; }
-  S.admm_refactor = refactor;  // unchanged rho: the next sweep only redoes the gradient recursion
-  const bool conv = (np_ <= o.eps_abs + o.eps_rel * npr) && (nd <= o.eps_abs + o.eps_rel * ndr);
-  if (conv || iter == o.max_qp) {
-    S.admm_conv = 1;
-    S.admm_iter = conv ? iter : o.max_qp;
-    atomicAdd(n_conv, 1);
+  admm_reduce_decide(o, S, fmax(red[0][0], red[0][1]), fmax(red[1][0], red[1][1]), fmax(red[2][0], red[2][1]), fmax(red[3][0], red[3][1]), iter, n_conv);
+}
+
+// Several ADMM iterations of one instance in ONE launch (iterations first .. last, all of them gradient-only sweeps: the
+// host runs the iterations that may factorise again -- the first of an SQP iteration and those after a rho check, every
+// kRhoInterval -- through k_riccati_admm / k_admm_update / k_admm_reduce): the segment-parallel sweep, the node update on
+// the same workgroup (eight lanes per node, 64 kSeg / 8 nodes per pass) and the norms / convergence test without leaving
+// the CU.  Three dependent launches per iteration (4.5 us each from dispatch to completion) and the host's poll every
+// four iterations go away; an instance leaves the loop at its own convergence.  Quorum < 1 keeps the host's schedule
+// (chunks of four iterations: which instances are cut must not depend on how the workgroups happen to progress).
+template <int NV>
+__global__ void __launch_bounds__(64 * kSeg) k_admm_loop(const DevOcp *op, const double *dts, const double *qts, double *qt2s,
+                                                         const double *auxs, const double *Kws, double *kws, double *dxs,
+                                                         double *wss, double *dus, double *cxs, const double *cg,
+                                                         const double *cjac, double *ys, double *zs, double *nodestat,
+                                                         double *admmstat, DevState *st, const double *facs, const double *segP,
+                                                         int first, int last, int *n_conv) {
+  __shared__ double s_red[4][kSeg];
+  __shared__ int s_stop;
+  const DevOcp &o = *op;
+  const int b = blockIdx.x, T = o.T, tid = threadIdx.x;
+  DevState &S = st[b];
+  if (S.done || S.admm_conv || S.dir_fail || S.admm_refactor) return;  // (refactor: left to the host's factorising iteration)
+  for (int iter = first; iter <= last; ++iter) {
+    riccati_vec_segments<NV>(b, op, dts, qt2s, Kws, kws, dxs, wss, facs, segP);
+    __threadfence_block();
+    __syncthreads();  // dx, w of every segment are visible to the whole workgroup
+    double v[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int base = 0; base <= T; base += 8 * kSeg) {
+      const int t = base + (tid >> 3);
+      double out4[4];
+      admm_update_node<NV>(op, (long long)b * (T + 1) + (t <= T ? t : T), t <= T, qts, auxs, dxs, wss, dus, cxs, cg, cjac, ys, zs, nodestat,
+                           admmstat, qt2s, st, out4);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) v[k] = fmax(v[k], out4[k]);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = wave_max(v[k]);
+    if ((tid & 63) == 0)
+      for (int k = 0; k < 4; ++k) s_red[k][tid >> 6] = v[k];
+    __threadfence_block();
+    __syncthreads();  // the next gradient (qt2s), multipliers and prox centre are written; norms are in LDS
+    if (tid == 0) {
+      double m[4];
+      for (int k = 0; k < 4; ++k) {
+        m[k] = s_red[k][0];
+        for (int w = 1; w < kSeg; ++w) m[k] = fmax(m[k], s_red[k][w]);
+      }
+      s_stop = admm_reduce_decide(o, S, m[0], m[1], m[2], m[3], iter, n_conv);
+    }
+    __syncthreads();
+    if (s_stop) break;
   }
 }
 

@@ -300,6 +300,41 @@ def test_hip_lqr_pass_next_to_the_factorisation_is_the_same_solve(monkeypatch):
 
 
 @pytest.mark.gpu
+def test_hip_admm_iterations_in_one_launch_are_the_same_solve(monkeypatch):
+    """k_admm_loop runs the gradient-only ADMM iterations between two rho checks of an instance in one launch (sweep, node update,
+    norms and convergence test on the instance's own workgroup); the solver uses it for the tail of a step, when few instances
+    are left.  AGX_ADMM_LOOP=2 forces it for every instance, 0 launches every iteration as sweep / update / reduce: same ADMM
+    iteration counts and results, against each other and against the checker -- also across a rho update (max_qp_iters 100,
+    loose problem: more than 25 iterations) and with a batch quorum below 1 (chunks of the host's polling schedule)."""
+    from agimus_controller_amd import backend
+
+    lim = np.full(7, 15.0)
+    table, po, ref, x0, xs, us = _control_limit_problem(lim, T=12, B=4, max_qp=100)
+    r_o = _oracle(table, po, 4).solve(ref, None, x0, xs, us, 6)
+    out = {}
+    for mode in ("0", "2"):
+        monkeypatch.setenv("AGX_ADMM_LOOP", mode)
+        hb = backend.HipOcp(table, po, 4)
+        hb.set_refs(ref)
+        out[mode] = hb.solve(x0, xs, us, 6)
+        hb.set_quorum(1.0, 0.75)
+        hb.reset_duals()
+        out[mode + "q"] = hb.solve(x0, xs, us, 6)
+        hb.close()
+    for a, b in ((out["0"], out["2"]), (out["0q"], out["2q"])):
+        for key in ("iter", "qp_iters", "solved", "flags"):
+            assert np.array_equal(a[3][key], b[3][key]), key
+        np.testing.assert_allclose(b[0], a[0], rtol=1e-10, atol=1e-12)
+        np.testing.assert_allclose(b[1], a[1], rtol=1e-10, atol=1e-10)
+        np.testing.assert_allclose(b[2], a[2], rtol=1e-9, atol=1e-9)
+    r_h = out["2"]
+    assert r_h[3]["qp_iters"].max() > 25  # a rho check was crossed
+    assert np.array_equal(r_h[3]["iter"], r_o[3]["iter"]) and np.array_equal(r_h[3]["qp_iters"], r_o[3]["qp_iters"])
+    np.testing.assert_allclose(r_h[0], r_o[0], rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(r_h[1], r_o[1], rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("which", ["rotation+translation", "placement"])
 def test_hip_frame_rotation_and_placement_constraints_match_the_checker(which):
     """ConstraintModelResidual on ResidualModelFrameRotation (log3, 3 components) and
