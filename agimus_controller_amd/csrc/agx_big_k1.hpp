@@ -178,10 +178,6 @@ struct WgIn {
   const double *ref;  // the node's reference tile (stride doubles)
   int stride;
   const int *frames;
-  // the persistent derivative kernel loads a node's inputs one node ahead: thread tid holds x[tid] (tid < nx), xn[tid - 64]
-  // (64 <= tid < 64 + nx), u[tid - 128] (128 <= tid < 128 + nv) in pre_a and ref[tid] in pre_b
-  bool preloaded = false;
-  double pre_a = 0.0, pre_b = 0.0;
 };
 
 // Cost rows of one node, evaluated by ONE wave (lane j: component j of the state / control rows, column j of every
@@ -356,22 +352,13 @@ __device__ __forceinline__ double wg_node(WgNode<NV> &L, const DevModel &m, cons
 
   AGX_WG_STAMP();
   // ---- phase 0: inputs and model index sets into LDS, accumulators cleared
-  if (in.preloaded) {
-    if (tid < NX) L.x[tid] = in.pre_a;
-    if (!TERM) {
-      if (tid >= 64 && tid < 64 + NX) L.xn[tid - 64] = in.pre_a;
-      if (tid >= 128 && tid < 128 + NV) L.u[tid - 128] = in.pre_a;
-    }
-    if (tid < in.stride) L.w.c.ref[tid] = in.pre_b;
-  } else {
-    for (int e = tid; e < NX; e += NT) {
-      L.x[e] = in.x[e] + (in.dx ? in.alpha * in.dx[e] : 0.0);
-      if (!TERM) L.xn[e] = in.xn[e] + (in.dxn ? in.alpha * in.dxn[e] : 0.0);
-    }
-    if (!TERM)
-      for (int e = tid; e < NV; e += NT) L.u[e] = in.u[e] + (in.du ? in.alpha * in.du[e] : 0.0);
-    for (int e = tid; e < in.stride; e += NT) L.w.c.ref[e] = in.ref[e];
+  for (int e = tid; e < NX; e += NT) {
+    L.x[e] = in.x[e] + (in.dx ? in.alpha * in.dx[e] : 0.0);
+    if (!TERM) L.xn[e] = in.xn[e] + (in.dxn ? in.alpha * in.dxn[e] : 0.0);
   }
+  if (!TERM)
+    for (int e = tid; e < NV; e += NT) L.u[e] = in.u[e] + (in.du ? in.alpha * in.du[e] : 0.0);
+  for (int e = tid; e < in.stride; e += NT) L.w.c.ref[e] = in.ref[e];
   if (tid < 32) {
     L.anc[tid] = tid < NV ? m.anc[tid] : 0u;
     L.desc[tid] = tid < NV ? m.desc[tid] : 0u;
@@ -751,39 +738,31 @@ __device__ __forceinline__ double wg_node(WgNode<NV> &L, const DevModel &m, cons
   return cost_tot;
 }
 
-// K1 for large models: running nodes first (unit = b T + t), then the terminal nodes, one workgroup each.  The loads of the
-// node's inputs (state, successor state, control, reference tile: two doubles per thread) are issued before the instance's
-// status word is looked at, so that the two memory round trips overlap.  Measured (round 3, B = 512, T = 50, same box): the
-// launch takes 1.22 ms either way -- the input phase is 6 us of the 34 us a workgroup spends on a node (AGX_WG_PROFILE
-// stamps), but with three workgroups per CU its latency is covered by the other two; what bounds the launch is the
-// work of the three together (and the 284 B of scratch per lane the 168-register cap costs).  A persistent variant (768
-// workgroups walking the units, the next unit's inputs loaded a node ahead) took 2.7 ms: the loop state pushed the
-// scratch to 932 B per lane.
+// K1 for large models: running nodes first (unit = b T + t), then the terminal nodes, one workgroup each.
+// Measured and discarded in round 3 (B = 512, T = 50, same box): the node's inputs loaded ahead of the status check (the input
+// phase is 6 us of the 34 us a workgroup spends on a node, AGX_WG_PROFILE stamps) -- 1.22 ms either way: with three
+// workgroups per CU that latency is covered by the other two; and a persistent variant (768 workgroups walking the units,
+// the next unit's inputs loaded a node ahead) -- 2.7 ms: the loop state pushed the scratch of the 168-register build from
+// 268 to 932 B per lane.
 template <int NV>
 __global__ void __launch_bounds__(256, AGX_WG_MINWAVES) k_calc_qp_wg(const DevModel *__restrict__ mp, const DevOcp *__restrict__ op,
                                                     const double *__restrict__ dts, const double *__restrict__ xs,
                                                     const double *__restrict__ us, RefView rv, double *__restrict__ qts,
                                                     double *__restrict__ auxs, const DevState *__restrict__ st, int phase) {
   constexpr int NX = 2 * NV;
-  static_assert(NX <= 64 && kWgRef <= 256, "thread map of the preloaded inputs");
   __shared__ WgNode<NV> L;
   const DevOcp &o = *op;
-  const int T = o.T, tid = threadIdx.x;
+  const int T = o.T;
   const long long unit = blockIdx.x, n_run = (long long)o.B * T;
   const bool term = unit >= n_run;
   const int b = term ? (int)(unit - n_run) : (int)(unit / T), t = term ? T : (int)(unit % T);
+  if (!k1_active(st[b], phase)) return;  // phase 1: the trial points of the instances in the line search (k_sqp_head / k_sqp_accept)
   const long long node = (long long)b * (T + 1) + t;
   WgIn in;
   in.x = xs + node * NX; in.dx = nullptr; in.xn = in.x + NX; in.dxn = nullptr;
   in.u = us + ((long long)b * T + t) * NV; in.du = nullptr;
-  in.ref = ref_at(rv, b, t, T); in.stride = o.stride; in.frames = frames_at(rv, b, t, T);
-  in.preloaded = true;
-  if (tid < NX) in.pre_a = in.x[tid];
-  else if (!term && tid >= 64 && tid < 64 + NX) in.pre_a = in.xn[tid - 64];
-  else if (!term && tid >= 128 && tid < 128 + NV) in.pre_a = in.u[tid - 128];
-  if (tid < o.stride) in.pre_b = in.ref[tid];
-  if (!k1_active(st[b], phase)) return;  // phase 1: the trial points of the instances in the line search (k_sqp_head / k_sqp_accept)
   in.alpha = 0.0; in.preg = k1_preg(st[b], phase); in.mu_dyn = o.mu_dyn;
+  in.ref = ref_at(rv, b, t, T); in.stride = o.stride; in.frames = frames_at(rv, b, t, T);
   double *qt = qts + node * QT<NV>::SIZE, *ax = auxs + node * AUX<NV>::SIZE;
   if (term) { in.dt = 0.0; wg_node<NV, true, true>(L, *mp, o.rows[1], in, qt, ax); }
   else { in.dt = dts[t]; wg_node<NV, false, true>(L, *mp, o.rows[0], in, qt, ax); }
