@@ -892,6 +892,11 @@ AGX_UNROLL_NV
     for (; t >= 0; t -= kGridDepth) {
 #pragma unroll
       for (int i = 0; i < kGridDepth; ++i) step(tl[i], t - i);
+      // The factorisation of a constrained QP (the sweeps that keep their factors: STORE) stops at a breakdown: the direction
+      // is discarded whatever the remaining nodes give (k_sqp_head), the ADMM loop does not start (k_admm_reduce), and an
+      // instance that sits inside the non-convex zone of a QuadExp cost breaks down in every SQP iteration of every MPC
+      // step (the quorum-1.0 step is eight such iterations of three instances).
+      if (STORE && !GAINS && __any(bad_pivot)) break;
     }
   }
   if (!GAINS) {
@@ -903,6 +908,7 @@ AGX_UNROLL_NV
       S.dir_fail = any_bad ? 1 : 0;
       if (any_bad) atomicOr(&S.flags, 1);  // atomic: the LQR pass of the same instance may raise it at the same time
     }
+    if (STORE && any_bad) return;  // no forward pass on gains that were not computed
   }
   if (GAINS || !forward) return;
   riccati_forward<NV>(b, T, dts, qb, Kw, kw, dxs, wss, s_dt);
