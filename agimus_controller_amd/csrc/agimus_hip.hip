@@ -315,7 +315,7 @@ int fill_cons(const agx_constraint_row *rows, int n, int nv, int nvu, const DevM
 }
 
 // ---- dispatch over the compiled (NV, CHAIN) instantiations --------------------
-// The library is built as one translation unit per group of capacities (AGX_GROUP = 0: 7 joints, 1: 30 and 32, compiled in
+// The library is built as one translation unit per group of capacities (AGX_GROUP = 0: 7 joints, 1: 16, 30 and 32, compiled in
 // parallel by backend.build(), namespace and entry points suffixed per group, csrc/agx_front.py
 // generates the forwarding entry points) or, without AGX_GROUP, as a single translation unit.
 #if defined(AGX_ONLY_NV7) || (defined(AGX_GROUP) && AGX_GROUP == 0)  // AGX_ONLY_NV7: development builds, short compile
