@@ -748,7 +748,8 @@ int admm_direction(agx_ocp *o, bool prefactor = false) {
         last = std::min(last, max_qp);
         hipLaunchKernelGGL((agx::k_admm_loop<NV>), dim3(o->B), dim3(64 * agx::kSeg), 0, o->stream, o->d_ocp, o->d_dt, o->d_qt, o->d_qt2, o->d_aux,
                            o->d_Kws, o->d_kws, o->d_dx, o->d_w, o->d_du, o->d_cx, o->d_cg, o->d_cjac, o->d_y, o->d_z, o->d_nodestat,
-                           o->d_admmstat, o->d_state, o->d_fac, o->d_segP, iter, last, o->d_ndone + 1);
+                           o->d_admmstat, o->d_state, o->d_fac, o->d_segP, iter, last, o->d_ndone + 1,
+                           o->general ? (const double *)o->d_auxg : (const double *)nullptr);
         HIPCHK(hipGetLastError());
         iter = last + 1;
         bool stop;
@@ -768,7 +769,8 @@ int admm_direction(agx_ocp *o, bool prefactor = false) {
         hipLaunchKernelGGL((agx::k_seg_products<NV>), dim3(o->B * agx::kSeg), dim3(64), 0, o->stream, o->d_ocp, o->d_dt, o->d_Kws, o->d_segP,
                            o->d_state);
       hipLaunchKernelGGL((agx::k_admm_update<NV>), dim3(g8), dim3(256), 0, o->stream, o->d_ocp, o->d_qt, o->d_aux, o->d_dx, o->d_w,
-                         o->d_du, o->d_cx, o->d_cg, o->d_cjac, o->d_y, o->d_z, o->d_nodestat, o->d_admmstat, o->d_qt2, o->d_state);
+                         o->d_du, o->d_cx, o->d_cg, o->d_cjac, o->d_y, o->d_z, o->d_nodestat, o->d_admmstat, o->d_qt2, o->d_state,
+                         o->general ? (const double *)o->d_auxg : (const double *)nullptr);
       hipLaunchKernelGGL(agx::k_admm_reduce, dim3(o->B), dim3(128), 0, o->stream, o->d_ocp, o->d_admmstat, o->d_state, iter,
                          o->d_ndone + 1);
       HIPCHK(hipGetLastError());
@@ -1156,7 +1158,6 @@ int agx_ocp_create(const agx_model *m, const agx_ocp_desc *d, int batch, int dev
       fill_cons(d->terminal_constraints, d->n_terminal_constraints, o->nv, o->nvu, m->h, o->ho.cons[1], true)) { delete o; return -1; }
   o->has_con = o->ho.cons[0].nc + o->ho.cons[1].nc > 0;
   o->general = o->ho.rows[0].general || o->ho.rows[1].general;
-  if (o->general && o->has_con) { delete o; return fail("agx_ocp_create: constraints together with ControlGrav / FrameVelocity cost rows are not implemented"); }
   o->ho.has_con = o->has_con ? 1 : 0;
   o->ho.max_qp = d->max_qp_iters > 0 ? d->max_qp_iters : 1000;
   o->ho.eps_abs = d->eps_abs;

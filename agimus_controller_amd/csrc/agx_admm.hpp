@@ -665,7 +665,7 @@ __device__ __forceinline__ void admm_update_node(const DevOcp *op, const long lo
                                                  const double *auxs, const double *dxs, const double *wss, double *dus,
                                                  double *cxs, const double *cg, const double *cjac, double *ys, double *zs,
                                                  double *nodestat, double *admmstat, double *qt2s, const DevState *st,
-                                                 double *out4) {
+                                                 double *out4, const double *auxg = nullptr) {
   constexpr int NX = 2 * NV;
   typedef QT<NV> Q;
   typedef AUX<NV> A;
@@ -764,16 +764,30 @@ __device__ __forceinline__ void admm_update_node(const DevOcp *op, const long lo
       }
     }
   }
+  // general cost rows (ControlGrav / FrameVelocity, agx_general.hpp): the blocks Lqv | Lvvd | Lqu of the node's Hessian in the
+  // optimality identities (as k_node_kkt_gen);  row i on lane i, the operands of the other lanes through the 8-lane shuffle
+  double gen_u = 0.0, gen_q = 0.0, gen_v = 0.0;
+  if (auxg) {
+    const double *ag = auxg + nid * (3 * A::B2);
+    const double *Lqv = ag, *Lvvd = ag + A::B2, *Lqu = ag + 2 * A::B2;
+#pragma unroll
+    for (int l = 0; l < NV; ++l) {
+      const double dq_l = __shfl(dq, l, 8), dv_l = __shfl(dv, l, 8), du_l = __shfl(du, l, 8);
+      gen_u += Lqu[l * A::LD + jj] * dq_l;
+      gen_q += Lqv[jj * A::LD + l] * dv_l + Lqu[jj * A::LD + l] * du_l;
+      gen_v += Lqv[l * A::LD + jj] * dq_l + Lvvd[jj * A::LD + l] * dv_l;
+    }
+  }
   // KKT shares
-  if (t < T && jl) kkt = fmax(kkt, fabs((ax[A::Luu + l8] + preg) * du + sig * (du - duc) + e_u));
+  if (t < T && jl) kkt = fmax(kkt, fabs((ax[A::Luu + l8] + preg) * du + gen_u + sig * (du - duc) + e_u));
   if (t > 0) {
     double pr[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) pr[i] = (i < NV) ? ax[A::Lqq + i * A::LD + l8] * dq : 0.0;
     const double hq = transpose_reduce8(pr, l8);
     if (jl) {
-      kkt = fmax(kkt, fabs(hq + dreg * dq + sig * (dq - cq) + e_q));
-      kkt = fmax(kkt, fabs((ax[A::Lvv + l8] + dreg) * dv + sig * (dv - cv) + e_v));
+      kkt = fmax(kkt, fabs(hq + gen_q + dreg * dq + sig * (dq - cq) + e_q));
+      kkt = fmax(kkt, fabs((ax[A::Lvv + l8] + dreg) * dv + gen_v + sig * (dv - cv) + e_v));
     }
   }
   double dual = fmax(fabs(dual_q), fmax(fabs(dual_v), fabs(dual_u)));
@@ -824,10 +838,10 @@ __global__ void __launch_bounds__(256) k_admm_update(const DevOcp *__restrict__ 
                                                      const double *__restrict__ cjac, double *__restrict__ ys,
                                                      double *__restrict__ zs, double *__restrict__ nodestat,
                                                      double *__restrict__ admmstat, double *__restrict__ qt2s,
-                                                     const DevState *__restrict__ st) {
+                                                     const DevState *__restrict__ st, const double *__restrict__ auxg) {
   double out4[4];
   admm_update_node<NV>(op, ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 3, true, qts, auxs, dxs, wss, dus, cxs, cg, cjac, ys, zs,
-                       nodestat, admmstat, qt2s, st, out4);
+                       nodestat, admmstat, qt2s, st, out4, auxg);
 }
 
 
@@ -894,7 +908,7 @@ __global__ void __launch_bounds__(64 * kSeg) k_admm_loop(const DevOcp *op, const
                                                          double *wss, double *dus, double *cxs, const double *cg,
                                                          const double *cjac, double *ys, double *zs, double *nodestat,
                                                          double *admmstat, DevState *st, const double *facs, const double *segP,
-                                                         int first, int last, int *n_conv) {
+                                                         int first, int last, int *n_conv, const double *auxg) {
   __shared__ double s_red[4][kSeg];
   __shared__ int s_stop;
   const DevOcp &o = *op;
@@ -910,7 +924,7 @@ __global__ void __launch_bounds__(64 * kSeg) k_admm_loop(const DevOcp *op, const
       const int t = base + (tid >> 3);
       double out4[4];
       admm_update_node<NV>(op, (long long)b * (T + 1) + (t <= T ? t : T), t <= T, qts, auxs, dxs, wss, dus, cxs, cg, cjac, ys, zs, nodestat,
-                           admmstat, qt2s, st, out4);
+                           admmstat, qt2s, st, out4, auxg);
 #pragma unroll
       for (int k = 0; k < 4; ++k) v[k] = fmax(v[k], out4[k]);
     }

@@ -156,3 +156,32 @@ def test_filter_line_search_with_general_rows(hip_backend):
     np.testing.assert_allclose(xs_h, xs_o, rtol=1e-8, atol=1e-10)
     np.testing.assert_allclose(us_h, us_o, rtol=1e-8, atol=1e-8)
     h.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("model", ["panda", "chain4"])
+def test_general_rows_together_with_constraints(hip_backend, model):
+    """ControlGrav / FrameVelocity cost rows AND constraints (ConstraintModelControlLimit-like bounds on u, bounds on the joint
+    velocities) in one problem: the one-lane GEN derivative kernel feeds the ADMM loop, whose node update carries the blocks
+    Lqv | Lvvd | Lqu of the general rows in its optimality identities.  Same SQP / ADMM iterations and iterate as the checker."""
+    table = rt.panda_table(0.1) if model == "panda" else rt.chain_table(4, seed=3)
+    nv = table.nv
+    B, T = 3, 10
+    po0, ref, x0, xs, us = general_problem(table, T, B, seed=21 + nv, ref_frame=2)
+    lim = np.full(nv, 12.0)
+    vmax = np.full(2 * nv, np.inf)
+    vmax[nv:] = 1.5
+    con = [_abi.ConstraintSpec(_abi.RES_CONTROL, lower=-lim, upper=lim, name="ctrl_limit"),
+           _abi.ConstraintSpec(_abi.RES_STATE, lower=-vmax, upper=vmax, name="velocity_limit")]
+    po = _abi.PackedOcp(nv, [0.01] * T, po0.running, po0.terminal, max_qp_iters=100, running_constraints=con)
+    h, o = hip_backend.HipOcp(table, po, B), Oracle(table, po, B)
+    h.set_refs(ref)
+    r_h = h.solve(x0, xs, us, 6)
+    r_o = o.solve(ref, None, x0, xs, us, 6)
+    assert np.array_equal(r_h[3]["iter"], r_o[3]["iter"]) and np.array_equal(r_h[3]["qp_iters"], r_o[3]["qp_iters"])
+    assert np.array_equal(r_h[3]["solved"], r_o[3]["solved"])
+    np.testing.assert_allclose(r_h[3]["kkt"], r_o[3]["kkt"], rtol=1e-5, atol=1e-9)
+    np.testing.assert_allclose(r_h[0], r_o[0], rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(r_h[1], r_o[1], rtol=1e-5, atol=1e-5)
+    assert np.abs(r_h[1]).max() <= 12.0 + 1e-3
+    h.close()
