@@ -691,8 +691,51 @@ int admm_direction(agx_ocp *o, bool prefactor = false) {
   return dispatch(o->nv, o->chain, [&](auto NVc, auto CHc) -> int {
     constexpr int NV = decltype(NVc)::value;
     constexpr bool CH = decltype(CHc)::value;
-    if constexpr (NV > 7) return fail("constraints need nv <= 7");
-    else {
+    if constexpr (NV > 7) {
+      // Large models: control-limit rows only (agx_ocp_create), every ADMM iteration factorises (k_riccati_blk on the
+      // augmented tile); the node kernels are k_admm_tile_big / k_admm_update_big (agx_big.hpp), norms and rho schedule
+      // as for the 7-joint path (k_admm_reduce).
+      (void)CH; (void)prefactor;
+      if constexpr (NV < 16) return fail("constraints for large models need the blocked sweep (capacity >= 16)");
+      else {
+      const long long nodes = (long long)o->B * (o->T + 1);
+      const int g1 = (int)((nodes + 255) / 256);
+      if (launch_step(o, 0, 0, 0, true, false)) return -1;  // du of the initial guess (k_node_kkt_big)
+      HIPCHK(hipMemsetAsync(o->d_ndone + 1, 0, sizeof(int), o->stream));
+      hipLaunchKernelGGL((agx::k_admm_init<NV>), dim3(g1), dim3(256), 0, o->stream, o->d_ocp, o->d_dx, o->d_cx, o->d_z, o->d_state, o->d_ndone + 1);
+      hipLaunchKernelGGL((agx::k_con_eval_u_big<NV>), dim3(g1), dim3(256), 0, o->stream, o->d_ocp, o->d_us, o->d_cg, o->d_nodestat, o->d_state, 0);
+      HIPCHK(hipGetLastError());
+      const int max_qp = o->ho.max_qp;
+      for (int iter = 1; iter <= max_qp; ++iter) {
+        if (iter == 1 || (iter > 2 && (iter - 1) % agx::kRhoInterval == 0))  // Hessian part: first iteration and after a rho update
+          hipLaunchKernelGGL((agx::k_admm_tile_big<NV>), dim3((int)nodes), dim3(256), 0, o->stream, o->d_ocp, o->d_qt, o->d_qt2, o->d_aux, o->d_cx,
+                             o->d_du, o->d_y, o->d_z, o->d_state);
+        hipLaunchKernelGGL((agx::k_riccati_blk<NV>), dim3(o->B), dim3(256), 0, o->stream, o->d_ocp, o->d_dt, o->d_qt2, o->d_Kws, o->d_kws, o->d_dx,
+                           o->d_w, o->d_state, 1, 0);
+        hipLaunchKernelGGL((agx::k_admm_update_big<NV>), dim3((int)((nodes + 1) / 2)), dim3(64), 0, o->stream, o->d_ocp, o->d_qt, o->d_aux, o->d_dx,
+                           o->d_w, o->d_du, o->d_cx, o->d_cg, o->d_y, o->d_z, o->d_nodestat, o->d_admmstat, o->d_qt2, o->d_state);
+        hipLaunchKernelGGL(agx::k_admm_reduce, dim3(o->B), dim3(128), 0, o->stream, o->d_ocp, o->d_admmstat, o->d_state, iter, o->d_ndone + 1);
+        HIPCHK(hipGetLastError());
+        if (iter % 4 == 0 || iter == max_qp) {
+          int n_conv = 0;
+          if (read_int(o, o->d_ndone + 1, 4, 5, &n_conv)) return -1;
+          if (n_conv >= quorum_count(o->B, o->quorum_qp)) {
+            if (n_conv < o->B && iter < max_qp) {
+              hipLaunchKernelGGL(agx::k_admm_cap, dim3((o->B + 255) / 256), dim3(256), 0, o->stream, o->d_state, o->B, iter);
+              HIPCHK(hipGetLastError());
+            }
+            break;
+          }
+        }
+      }
+      // the gains the solver reports: those of the last ADMM backward pass, in u-space
+      const long long units = (long long)o->B * o->T * 64;
+      hipLaunchKernelGGL((agx::k_gains_to_u_big<NV>), dim3((int)((units + 255) / 256)), dim3(256), 0, o->stream, o->d_ocp, o->d_aux, o->d_Kws,
+                         o->d_Kout, (const DevState *)nullptr);
+      HIPCHK(hipGetLastError());
+      return 0;
+      }
+    } else {
     const long long nodes = (long long)o->B * (o->T + 1);
     const int g8 = (int)((nodes * 8 + 255) / 256), g8b = (int)((nodes * 8 + 127) / 128), g1 = (int)((nodes + 255) / 256);
     if (prefactor) {
@@ -838,6 +881,11 @@ int line_search_rounds(agx_ocp *o, int it, int max_iter, bool *need_k1, int *n_d
         const long long nodes = (long long)o->B * (o->T + 1);
         hipLaunchKernelGGL((agx::k_con_eval<NV, CH>), dim3((int)((nodes + 63) / 64)), dim3(64), 0, o->stream, o->d_model, o->d_ocp, xs_t, us_t,
                            o->d_cg, o->d_cjac, o->d_nodestat, o->d_state, 1);
+      }
+      if constexpr (NV > 7) if (o->has_con) {
+        const long long nodes = (long long)o->B * (o->T + 1);
+        hipLaunchKernelGGL((agx::k_con_eval_u_big<NV>), dim3((int)((nodes + 255) / 256)), dim3(256), 0, o->stream, o->d_ocp, us_t, o->d_cg,
+                           o->d_nodestat, o->d_state, 1);
       }
       if (prof_mark(o, 2, true)) return -1;
       hipLaunchKernelGGL((agx::k_sqp_accept<NV>), dim3(o->B), dim3(128), 0, o->stream, o->d_ocp, o->d_xs, o->d_us, o->d_dx, o->d_du, xs_t, us_t,
@@ -1164,7 +1212,14 @@ int agx_ocp_create(const agx_model *m, const agx_ocp_desc *d, int batch, int dev
   o->ho.eps_rel = d->eps_rel;
   o->ho.use_filter = d->use_filter_line_search ? 1 : 0;
   // (the filter test lives in k_sqp_accept, which serves every model size and every kind of cost row)
-  if (o->has_con && o->nv > 7) { delete o; return fail("agx_ocp_create: constraints need the register Riccati kernel (nv <= 7)"); }
+  if (o->has_con && o->nv > 7) {  // large models: ConstraintModelControlLimit only (agx_big.hpp)
+    for (int lay = 0; lay < 2; ++lay)
+      for (int r = 0; r < o->ho.cons[lay].n; ++r)
+        if (o->ho.cons[lay].kind[r] != AGX_RES_CONTROL) {
+          delete o;
+          return fail("agx_ocp_create: models above 7 joints (after padding: nv > 7) take control-limit constraints only");
+        }
+  }
   {
     auto n_frame_rows = [](const DevRows &r) {
       int n = 0;
@@ -1259,7 +1314,7 @@ int agx_ocp_create(const agx_model *m, const agx_ocp_desc *d, int batch, int dev
   }
   if (o->general) ALLOC(o->d_auxg, B * (T + 1) * (size_t)(3 * o->nv * 8));
   if (o->has_con) {
-    ALLOC(o->d_qt2, B * (T + 1) * (size_t)o->qt_size);
+    if (!o->d_qt2) ALLOC(o->d_qt2, B * (T + 1) * (size_t)o->qt_size);
     ALLOC(o->d_cg, B * (T + 1) * AGX_MAX_NC);
     ALLOC(o->d_cjac, B * (T + 1) * AGX_MAX_DENSE * 24);
     ALLOC(o->d_y, B * (T + 1) * AGX_MAX_NC);

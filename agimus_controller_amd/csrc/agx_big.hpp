@@ -286,6 +286,223 @@ __global__ void __launch_bounds__(64) k_node_kkt_big(const DevOcp *__restrict__ 
   }
 }
 
+// ---------------------------------------------------------------------------
+// Constraints for large models (8 < nv <= 32): ConstraintModelControlLimit (`ocp_croco_generic.py:624-640`: lower / upper bounds
+// on u, the constraint of the reference's robots with torque limits) through the ADMM loop of agx_admm.hpp.  The constraint
+// Jacobian is the identity on u, i.e. the rows [taux | M] in the (dx, w) coordinates of the QP tiles.  Correctness-first: every
+// ADMM iteration factorises again (k_riccati_blk on the augmented tile; the stored-factor gradient sweeps of the 7-joint path
+// have no counterpart here), the node kernels follow k_admm_tile / k_admm_update.  Other constraint kinds are refused for nv > 7.
+// ---------------------------------------------------------------------------
+// g = u and the l1 violation of every node at (xs, us); one thread per node
+template <int NV>
+__global__ void __launch_bounds__(256) k_con_eval_u_big(const DevOcp *__restrict__ op, const double *__restrict__ us,
+                                                        double *__restrict__ cg, double *__restrict__ nodestat,
+                                                        const DevState *__restrict__ st, int phase) {
+  const DevOcp &o = *op;
+  const int T = o.T;
+  const long long node = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (node >= (long long)o.B * (T + 1)) return;
+  const int b = (int)(node / (T + 1)), t = (int)(node % (T + 1));
+  if (!k1_active(st[b], phase)) return;
+  const DevCons &c = o.cons[t == T ? 1 : 0];
+  double v = 0.0;
+  for (int r = 0; r < c.n; ++r)  // control rows only (agx_ocp_create), absent at the terminal node
+    for (int k = 0; k < NV; ++k) {
+      const double g = us[((long long)b * T + t) * NV + k];
+      cg[node * AGX_MAX_NC + c.off[r] + k] = g;
+      v += fmax(c.lb[c.off[r] + k] - g, 0.0) + fmax(g - c.ub[c.off[r] + k], 0.0);
+    }
+  nodestat[node * 4 + 3] = v;
+}
+
+// Augmented QP tile of one node (k_admm_tile for large models; instances whose rho changed, or at the first ADMM iteration):
+//   H += [taux M]' diag(sigma + rho_u) [taux M] + sigma I_x,    g += [taux M]' (h_u - sigma du_c) - sigma dx_c,   h = y - rho z
+// one 256-thread workgroup per node, M | tq | tv staged in LDS, thread (i, j) forms element [i][j] of the six blocks.
+template <int NV>
+__global__ void __launch_bounds__(256) k_admm_tile_big(const DevOcp *__restrict__ op, const double *__restrict__ qts,
+                                                       double *__restrict__ qt2s, const double *__restrict__ auxs,
+                                                       const double *__restrict__ cxs, const double *__restrict__ dus,
+                                                       const double *__restrict__ ys, const double *__restrict__ zs,
+                                                       const DevState *__restrict__ st) {
+  constexpr int NX = 2 * NV;
+  typedef QT<NV> Q;
+  typedef AUX<NV> A;
+  __shared__ double sM[NV * NV], sq[NV * NV], sv[NV * NV], wu[32], eu[32];
+  const DevOcp &o = *op;
+  const int T = o.T, tid = threadIdx.x, nt = blockDim.x;
+  const long long node = blockIdx.x;
+  const int b = (int)(node / (T + 1)), t = (int)(node % (T + 1));
+  const DevState &S = st[b];
+  if (S.done || S.admm_conv || !S.admm_refactor) return;  // uniform over the workgroup
+  const double *qt = qts + node * Q::SIZE;
+  double *q2 = qt2s + node * Q::SIZE;
+  const double *ax = auxs + node * A::SIZE;
+  const double *cx = cxs + node * NX;
+  const DevCons &c = o.cons[t == T ? 1 : 0];
+  const double sig = kSigma, rs = S.rho_sparse;
+  if (t < T) {
+    for (int e = tid; e < NV * NV; e += nt) {
+      const int i = e / NV, j = e % NV;
+      sM[e] = ax[A::M + i * A::LD + j]; sq[e] = ax[A::tq + i * A::LD + j]; sv[e] = ax[A::tv + i * A::LD + j];
+    }
+    if (tid < NV) {
+      double w = sig, h = 0.0;
+      for (int r = 0; r < c.n; ++r) {
+        const int k = c.off[r] + tid;
+        const double rho = admm_rho(c.lb[k], c.ub[k], rs);
+        w += rho;
+        h += ys[node * AGX_MAX_NC + k] - rho * zs[node * AGX_MAX_NC + k];
+      }
+      wu[tid] = w;
+      eu[tid] = h - sig * dus[((long long)b * T + t) * NV + tid];
+    }
+  }
+  __syncthreads();
+  for (int e = tid; e < NV * NV; e += nt) {
+    const int i = e / NV, j = e % NV;
+    double hww = 0.0, hqw = 0.0, hvw = 0.0, hqq = 0.0, hqv = 0.0, hvv = 0.0;
+    if (t < T)
+      for (int l = 0; l < NV; ++l) {
+        const double d = wu[l];
+        const double Mli = sM[l * NV + i], tqli = sq[l * NV + i], tvli = sv[l * NV + i];
+        const double Mlj = d * sM[l * NV + j], tqlj = d * sq[l * NV + j], tvlj = d * sv[l * NV + j];
+        hww += Mli * Mlj; hqw += tqli * Mlj; hvw += tvli * Mlj;
+        hqq += tqli * tqlj; hqv += tqli * tvlj; hvv += tvli * tvlj;
+      }
+    const double d = (i == j) ? sig : 0.0;
+    const int o2 = i * Q::LD + j;
+    q2[Q::Hqq + o2] = qt[Q::Hqq + o2] + hqq + d;
+    q2[Q::Hqv + o2] = qt[Q::Hqv + o2] + hqv;
+    q2[Q::Hvv + o2] = qt[Q::Hvv + o2] + hvv + d;
+    if (t < T) {
+      q2[Q::Hww + o2] = qt[Q::Hww + o2] + hww;
+      q2[Q::Hqw + o2] = qt[Q::Hqw + o2] + hqw;
+      q2[Q::Hvw + o2] = qt[Q::Hvw + o2] + hvw;
+    }
+  }
+  if (tid < NV) {  // gradient, gap, cost
+    const int i = tid;
+    double gw = 0.0, gq = -sig * cx[i], gv = -sig * cx[NV + i];
+    if (t < T)
+      for (int l = 0; l < NV; ++l) { gw += sM[l * NV + i] * eu[l]; gq += sq[l * NV + i] * eu[l]; gv += sv[l * NV + i] * eu[l]; }
+    if (t < T) q2[Q::gw + i] = qt[Q::gw + i] + gw;
+    q2[Q::gx + i] = qt[Q::gx + i] + gq;
+    q2[Q::gx + NV + i] = qt[Q::gx + NV + i] + gv;
+    q2[Q::f + i] = qt[Q::f + i];
+    q2[Q::f + NV + i] = qt[Q::f + NV + i];
+  }
+  if (tid == 255) q2[Q::cost] = qt[Q::cost];
+}
+
+// After the sweep on the augmented tiles (k_admm_update for large models, control-limit rows): du, z / y update, the node's
+// shares of the ADMM residual norms and of the KKT residual, the gradient of the next iteration's augmented tile.
+// 32 lanes per node, lane l = component l / column l of every matrix row (as k_node_kkt_big).
+template <int NV>
+__global__ void __launch_bounds__(64) k_admm_update_big(const DevOcp *__restrict__ op, const double *__restrict__ qts,
+                                                        const double *__restrict__ auxs, const double *__restrict__ dxs,
+                                                        const double *__restrict__ wss, double *__restrict__ dus,
+                                                        double *__restrict__ cxs, const double *__restrict__ cg,
+                                                        double *__restrict__ ys, double *__restrict__ zs,
+                                                        double *__restrict__ nodestat, double *__restrict__ admmstat,
+                                                        double *__restrict__ qt2s, const DevState *__restrict__ st) {
+  static_assert(NV <= 32, "a matrix row per 32 lanes");
+  constexpr int NX = 2 * NV;
+  typedef QT<NV> Q;
+  typedef AUX<NV> A;
+  const DevOcp &o = *op;
+  const int T = o.T, l = threadIdx.x & 31, half = threadIdx.x & 32;
+  const long long n_nodes = (long long)o.B * (T + 1);
+  const long long node_raw = (long long)blockIdx.x * 2 + (threadIdx.x >> 5);
+  const bool ok = node_raw < n_nodes;
+  const long long node = ok ? node_raw : n_nodes - 1;
+  const int b = (int)(node / (T + 1)), t = (int)(node % (T + 1));
+  const DevState &S = st[b];
+  const bool act = ok && !S.done && !S.admm_conv && !S.dir_fail;
+  if (!__any(act)) return;
+  const double preg = S.preg, dreg = S.dreg, rs = S.rho_sparse, sig = kSigma;
+  const double *qt = qts + node * Q::SIZE;
+  const double *ax = auxs + node * A::SIZE;
+  const double *dx = dxs + node * NX;
+  double *cx = cxs + node * NX;
+  double *y = ys + node * AGX_MAX_NC, *z = zs + node * AGX_MAX_NC;
+  const double *g = cg + node * AGX_MAX_NC;
+  const DevCons &c = o.cons[t == T ? 1 : 0];
+  const bool in = l < NV;
+  const int lc = in ? l : 0;
+  const double m = in ? 1.0 : 0.0;
+  const double dq = dx[lc] * m, dv = dx[NV + lc] * m, cq = cx[lc] * m, cv = cx[NV + lc] * m;
+  double kkt = 0.0, gap = 0.0;
+  if (t < T) {
+    const double fq = qt[Q::f + lc] * m, fv = qt[Q::f + NV + lc] * m;
+    kkt = fmax(fabs(fq), fabs(fv));
+    gap = fabs(fq) + fabs(fv);
+  }
+  const double w = (t < T) ? wss[((long long)b * T + t) * NV + lc] * m : 0.0;
+  const double tm = (t < T) ? 1.0 : 0.0, sm = (t > 0) ? 1.0 : 0.0;
+  double du = 0.0, hq = 0.0;
+#pragma unroll 2
+  for (int i = 0; i < NV; ++i) {
+    const double p = (ax[A::M + i * A::LD + lc] * w + ax[A::tq + i * A::LD + lc] * dq + ax[A::tv + i * A::LD + lc] * dv) * tm;
+    const double q = ax[A::Lqq + i * A::LD + lc] * dq;
+    const double s = sum32(p), h = sum32(q);
+    if (l == i) { du = s; hq = h; }
+  }
+  const double duc = (t < T && in) ? dus[((long long)b * T + t) * NV + l] : 0.0;
+  // control-limit rows: component l on lane l, C d = du
+  double primal = 0.0, primal_rel = 0.0, dual_u = 0.0, drel_u = 0.0, e_u = 0.0, hn_u = 0.0;
+  if (in && t < T)
+    for (int r = 0; r < c.n; ++r) {
+      const int k = c.off[r] + l;
+      const double rho = admm_rho(c.lb[k], c.ub[k], rs);
+      const double z0 = z[k], y0 = y[k];
+      const double zrel = kAlphaRelax * du + (1.0 - kAlphaRelax) * z0;
+      double zn = zrel + y0 / rho;
+      zn = fmin(fmax(zn, c.lb[k] - g[k]), c.ub[k] - g[k]);
+      const double yn = y0 + rho * (zrel - zn);
+      primal = fmax(primal, fabs(du - zn));
+      primal_rel = fmax(primal_rel, fmax(fabs(du), fabs(zn)));
+      dual_u += rho * (zn - z0);
+      drel_u += yn;
+      e_u += rho * du + (y0 - rho * z0) - yn;
+      hn_u += yn - rho * zn;
+      if (act) { z[k] = zn; y[k] = yn; }
+    }
+  if (in) {
+    if (t < T) kkt = fmax(kkt, fabs((ax[A::Luu + l] + preg) * du + sig * (du - duc) + e_u));
+    kkt = fmax(kkt, sm * fmax(fabs(hq + dreg * dq + sig * (dq - cq)), fabs((ax[A::Lvv + l] + dreg) * dv + sig * (dv - cv))));
+  }
+  kkt = max32(kkt);
+  gap = sum32(gap);
+  primal = max32(primal);
+  primal_rel = max32(primal_rel);
+  const double dual = max32(fabs(dual_u)), drel = max32(fabs(drel_u));
+  // gradient of the next iteration's augmented tile:  g = g0 + [taux M]' (h_u - sigma du) - sigma dx
+  const double e_own = (t < T && in) ? hn_u - sig * du : 0.0;
+  double gwn = 0.0, gqn = -sig * dq, gvn = -sig * dv;
+  for (int k = 0; k < NV; ++k) {
+    const double e = __shfl(e_own, half + k, 64);
+    gwn += ax[A::M + k * A::LD + lc] * e * tm;
+    gqn += ax[A::tq + k * A::LD + lc] * e * tm;
+    gvn += ax[A::tv + k * A::LD + lc] * e * tm;
+  }
+  if (act) {
+    if (in) {
+      double *q2 = qt2s + node * Q::SIZE;
+      if (t < T) q2[Q::gw + l] = qt[Q::gw + l] + gwn;
+      q2[Q::gx + l] = qt[Q::gx + l] + gqn;
+      q2[Q::gx + NV + l] = qt[Q::gx + NV + l] + gvn;
+      if (t < T) dus[((long long)b * T + t) * NV + l] = du;
+      cx[l] = dq; cx[NV + l] = dv;  // prox centre of the next iteration
+    }
+    if (l == 0) {
+      double *ns = nodestat + node * 4;
+      ns[0] = kkt; ns[1] = qt[Q::cost]; ns[2] = gap;
+      double *as = admmstat + node * 4;
+      as[0] = primal; as[1] = dual; as[2] = primal_rel; as[3] = drel;
+    }
+  }
+}
+
 // K3 for problems with general cost rows (agx_general.hpp): the optimality identities with every block,
 //   Lu + Fu' lam' = -(Lqu' dq + (Luu + preg) du)
 //   Lx + Fx' lam' - lam = -(Lxx dx + Lxu du + dreg dx),  Lxx = [[Lqq, Lqv], [Lqv', diag(Lvv) + Lvvd]]
@@ -404,7 +621,7 @@ __global__ void __launch_bounds__(256) k_gains_to_u_big(const DevOcp *__restrict
   const int j = (int)(unit & 63);
   if (node >= (long long)o.B * T || j >= NX) return;
   const int b = (int)(node / T), t = (int)(node % T);
-  if (!st[b].ls_acc) return;  // the sigma sweep in front of this launch skipped the instance: its Kws hold direction gains
+  if (st ? !st[b].ls_acc : false) return;  // the sigma sweep in front of this launch skipped the instance: its Kws hold direction gains (st == null: every instance, constrained path)
   const double *ax = auxs + ((long long)b * (T + 1) + t) * A::SIZE;
   const double *Kw = Kws + node * NV * NX;
   double *K = Kout + node * NV * NX;

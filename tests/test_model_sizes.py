@@ -159,3 +159,33 @@ def test_filter_line_search_for_large_models(hip_backend, nv, kind):
     np.testing.assert_allclose(xs_h, xs_o, rtol=1e-8, atol=1e-10)
     np.testing.assert_allclose(us_h, us_o, rtol=1e-8, atol=1e-8)
     h.close()
+
+
+@pytest.mark.parametrize("nv,kind,limit", [(9, "panda_fingers", 6.0), (16, "tree", 5.0), (30, "humanoid", 40.0), (31, "chain", 8.0)])
+def test_control_limits_on_large_models(hip_backend, nv, kind, limit):
+    """ConstraintModelControlLimit (ocp_croco_generic.py:624-640) for models above 7 joints: bounds on u through the ADMM loop on
+    the workgroup-per-node path (k_admm_tile_big / k_riccati_blk on the augmented tile / k_admm_update_big, csrc/agx_big.hpp).
+    Same SQP and ADMM iteration counts, iterate and bounded controls as the checker; other constraint kinds are refused."""
+    table = rt.humanoid30_table() if kind == "humanoid" else _model(nv, kind)
+    assert table.nv == nv
+    frame = len(table.frame_names) - 1
+    B, T = 2, 8
+    po0, ref, x0, xs, us = workloads.random_goal_problem(table, T, 0.02, B, seed=500 + nv, frame=frame)
+    lim = np.full(nv, limit)
+    con = [_abi.ConstraintSpec(_abi.RES_CONTROL, lower=-lim, upper=lim, name="ctrl_limit")]
+    po = _abi.PackedOcp(nv, [0.02] * T, po0.running, po0.terminal, max_qp_iters=100, running_constraints=con)
+    h, o = hip_backend.HipOcp(table, po, B), Oracle(table, po, B)
+    h.set_refs(ref)
+    xs_h, us_h, K_h, st_h = h.solve(x0, xs, us, 6)
+    xs_o, us_o, K_o, st_o = o.solve(ref, None, x0, xs, us, 6)
+    assert np.abs(us_o).max() > 0.98 * limit  # the bound is active
+    assert np.array_equal(st_h["iter"], st_o["iter"]) and np.array_equal(st_h["qp_iters"], st_o["qp_iters"])
+    np.testing.assert_allclose(xs_h, xs_o, rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(us_h, us_o, rtol=1e-5, atol=1e-5)
+    assert np.abs(us_h).max() <= limit + 1e-3
+    h.close()
+    # a state bound on a large model is refused with a message
+    bad = [_abi.ConstraintSpec(_abi.RES_STATE, lower=-np.ones(2 * nv), upper=np.ones(2 * nv), name="state_box")]
+    if 2 * nv <= 32:
+        with pytest.raises(Exception, match="control-limit constraints only"):
+            hip_backend.HipOcp(table, _abi.PackedOcp(nv, [0.02] * T, po0.running, po0.terminal, running_constraints=bad), B)
