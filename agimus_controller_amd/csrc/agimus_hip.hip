@@ -703,17 +703,18 @@ int admm_direction(agx_ocp *o, bool prefactor = false) {
       if (launch_step(o, 0, 0, 0, true, false)) return -1;  // du of the initial guess (k_node_kkt_big)
       HIPCHK(hipMemsetAsync(o->d_ndone + 1, 0, sizeof(int), o->stream));
       hipLaunchKernelGGL((agx::k_admm_init<NV>), dim3(g1), dim3(256), 0, o->stream, o->d_ocp, o->d_dx, o->d_cx, o->d_z, o->d_state, o->d_ndone + 1);
-      hipLaunchKernelGGL((agx::k_con_eval_u_big<NV>), dim3(g1), dim3(256), 0, o->stream, o->d_ocp, o->d_us, o->d_cg, o->d_nodestat, o->d_state, 0);
+      hipLaunchKernelGGL((agx::k_con_eval_wg<NV>), dim3((int)nodes), dim3(256), 0, o->stream, o->d_model, o->d_ocp, o->d_xs, o->d_us, o->d_cg, o->d_cjac,
+                         o->d_nodestat, o->d_state, 0);
       HIPCHK(hipGetLastError());
       const int max_qp = o->ho.max_qp;
       for (int iter = 1; iter <= max_qp; ++iter) {
         if (iter == 1 || (iter > 2 && (iter - 1) % agx::kRhoInterval == 0))  // Hessian part: first iteration and after a rho update
           hipLaunchKernelGGL((agx::k_admm_tile_big<NV>), dim3((int)nodes), dim3(256), 0, o->stream, o->d_ocp, o->d_qt, o->d_qt2, o->d_aux, o->d_cx,
-                             o->d_du, o->d_y, o->d_z, o->d_state);
+                             o->d_du, o->d_cjac, o->d_y, o->d_z, o->d_state);
         hipLaunchKernelGGL((agx::k_riccati_blk<NV>), dim3(o->B), dim3(256), 0, o->stream, o->d_ocp, o->d_dt, o->d_qt2, o->d_Kws, o->d_kws, o->d_dx,
                            o->d_w, o->d_state, 1, 0);
         hipLaunchKernelGGL((agx::k_admm_update_big<NV>), dim3((int)((nodes + 1) / 2)), dim3(64), 0, o->stream, o->d_ocp, o->d_qt, o->d_aux, o->d_dx,
-                           o->d_w, o->d_du, o->d_cx, o->d_cg, o->d_y, o->d_z, o->d_nodestat, o->d_admmstat, o->d_qt2, o->d_state);
+                           o->d_w, o->d_du, o->d_cx, o->d_cg, o->d_cjac, o->d_y, o->d_z, o->d_nodestat, o->d_admmstat, o->d_qt2, o->d_state);
         hipLaunchKernelGGL(agx::k_admm_reduce, dim3(o->B), dim3(128), 0, o->stream, o->d_ocp, o->d_admmstat, o->d_state, iter, o->d_ndone + 1);
         HIPCHK(hipGetLastError());
         if (iter % 4 == 0 || iter == max_qp) {
@@ -884,7 +885,7 @@ int line_search_rounds(agx_ocp *o, int it, int max_iter, bool *need_k1, int *n_d
       }
       if constexpr (NV > 7) if (o->has_con) {
         const long long nodes = (long long)o->B * (o->T + 1);
-        hipLaunchKernelGGL((agx::k_con_eval_u_big<NV>), dim3((int)((nodes + 255) / 256)), dim3(256), 0, o->stream, o->d_ocp, us_t, o->d_cg,
+        hipLaunchKernelGGL((agx::k_con_eval_wg<NV>), dim3((int)nodes), dim3(256), 0, o->stream, o->d_model, o->d_ocp, xs_t, us_t, o->d_cg, o->d_cjac,
                            o->d_nodestat, o->d_state, 1);
       }
       if (prof_mark(o, 2, true)) return -1;
@@ -1215,9 +1216,9 @@ int agx_ocp_create(const agx_model *m, const agx_ocp_desc *d, int batch, int dev
   if (o->has_con && o->nv > 7) {  // large models: ConstraintModelControlLimit only (agx_big.hpp)
     for (int lay = 0; lay < 2; ++lay)
       for (int r = 0; r < o->ho.cons[lay].n; ++r)
-        if (o->ho.cons[lay].kind[r] != AGX_RES_CONTROL) {
+        if (o->ho.cons[lay].kind[r] != AGX_RES_CONTROL && o->ho.cons[lay].kind[r] != AGX_RES_COLLISION) {
           delete o;
-          return fail("agx_ocp_create: models above 7 joints (after padding: nv > 7) take control-limit constraints only");
+          return fail("agx_ocp_create: models above 7 joints (after padding: nv > 7) take control-limit and collision-distance constraints only");
         }
   }
   {
@@ -1316,7 +1317,7 @@ int agx_ocp_create(const agx_model *m, const agx_ocp_desc *d, int batch, int dev
   if (o->has_con) {
     if (!o->d_qt2) ALLOC(o->d_qt2, B * (T + 1) * (size_t)o->qt_size);
     ALLOC(o->d_cg, B * (T + 1) * AGX_MAX_NC);
-    ALLOC(o->d_cjac, B * (T + 1) * AGX_MAX_DENSE * 24);
+    ALLOC(o->d_cjac, B * (T + 1) * AGX_MAX_DENSE * 32);  // 24 per row up to 7 joints (q | v | u, 8 each), 32 above (q only)
     ALLOC(o->d_y, B * (T + 1) * AGX_MAX_NC);
     ALLOC(o->d_z, B * (T + 1) * AGX_MAX_NC);
     ALLOC(o->d_cx, B * (T + 1) * nx);

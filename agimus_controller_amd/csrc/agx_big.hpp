@@ -287,34 +287,13 @@ __global__ void __launch_bounds__(64) k_node_kkt_big(const DevOcp *__restrict__ 
 }
 
 // ---------------------------------------------------------------------------
-// Constraints for large models (8 < nv <= 32): ConstraintModelControlLimit (`ocp_croco_generic.py:624-640`: lower / upper bounds
-// on u, the constraint of the reference's robots with torque limits) through the ADMM loop of agx_admm.hpp.  The constraint
-// Jacobian is the identity on u, i.e. the rows [taux | M] in the (dx, w) coordinates of the QP tiles.  Correctness-first: every
-// ADMM iteration factorises again (k_riccati_blk on the augmented tile; the stored-factor gradient sweeps of the 7-joint path
-// have no counterpart here), the node kernels follow k_admm_tile / k_admm_update.  Other constraint kinds are refused for nv > 7.
+// Constraints for large models (8 < nv <= 32) through the ADMM loop of agx_admm.hpp: ConstraintModelControlLimit
+// (`ocp_croco_generic.py:624-640`: lower / upper bounds on u; identity Jacobian on u, i.e. the rows [taux | M] in the (dx, w)
+// coordinates of the QP tiles) and collision-distance rows (`ocp_traj_tracking_collision_avoidance.yaml:48-56`; one Jacobian row
+// on q each, k_con_eval_wg in agx_big_k1.hpp).  Correctness-first: every ADMM iteration factorises again (k_riccati_blk on the
+// augmented tile; the stored-factor gradient sweeps of the 7-joint path have no counterpart here), the node kernels follow
+// k_admm_tile / k_admm_update.  Other constraint kinds are refused for nv > 7.
 // ---------------------------------------------------------------------------
-// g = u and the l1 violation of every node at (xs, us); one thread per node
-template <int NV>
-__global__ void __launch_bounds__(256) k_con_eval_u_big(const DevOcp *__restrict__ op, const double *__restrict__ us,
-                                                        double *__restrict__ cg, double *__restrict__ nodestat,
-                                                        const DevState *__restrict__ st, int phase) {
-  const DevOcp &o = *op;
-  const int T = o.T;
-  const long long node = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (node >= (long long)o.B * (T + 1)) return;
-  const int b = (int)(node / (T + 1)), t = (int)(node % (T + 1));
-  if (!k1_active(st[b], phase)) return;
-  const DevCons &c = o.cons[t == T ? 1 : 0];
-  double v = 0.0;
-  for (int r = 0; r < c.n; ++r)  // control rows only (agx_ocp_create), absent at the terminal node
-    for (int k = 0; k < NV; ++k) {
-      const double g = us[((long long)b * T + t) * NV + k];
-      cg[node * AGX_MAX_NC + c.off[r] + k] = g;
-      v += fmax(c.lb[c.off[r] + k] - g, 0.0) + fmax(g - c.ub[c.off[r] + k], 0.0);
-    }
-  nodestat[node * 4 + 3] = v;
-}
-
 // Augmented QP tile of one node (k_admm_tile for large models; instances whose rho changed, or at the first ADMM iteration):
 //   H += [taux M]' diag(sigma + rho_u) [taux M] + sigma I_x,    g += [taux M]' (h_u - sigma du_c) - sigma dx_c,   h = y - rho z
 // one 256-thread workgroup per node, M | tq | tv staged in LDS, thread (i, j) forms element [i][j] of the six blocks.
@@ -322,12 +301,13 @@ template <int NV>
 __global__ void __launch_bounds__(256) k_admm_tile_big(const DevOcp *__restrict__ op, const double *__restrict__ qts,
                                                        double *__restrict__ qt2s, const double *__restrict__ auxs,
                                                        const double *__restrict__ cxs, const double *__restrict__ dus,
-                                                       const double *__restrict__ ys, const double *__restrict__ zs,
-                                                       const DevState *__restrict__ st) {
+                                                       const double *__restrict__ cjac, const double *__restrict__ ys,
+                                                       const double *__restrict__ zs, const DevState *__restrict__ st) {
   constexpr int NX = 2 * NV;
   typedef QT<NV> Q;
   typedef AUX<NV> A;
   __shared__ double sM[NV * NV], sq[NV * NV], sv[NV * NV], wu[32], eu[32];
+  __shared__ double sg[AGX_MAX_DENSE][32], srho[AGX_MAX_DENSE], sh[AGX_MAX_DENSE];  // collision rows: Jacobian row on q, rho, h = y - rho z
   const DevOcp &o = *op;
   const int T = o.T, tid = threadIdx.x, nt = blockDim.x;
   const long long node = blockIdx.x;
@@ -348,6 +328,7 @@ __global__ void __launch_bounds__(256) k_admm_tile_big(const DevOcp *__restrict_
     if (tid < NV) {
       double w = sig, h = 0.0;
       for (int r = 0; r < c.n; ++r) {
+        if (c.kind[r] != AGX_RES_CONTROL) continue;
         const int k = c.off[r] + tid;
         const double rho = admm_rho(c.lb[k], c.ub[k], rs);
         w += rho;
@@ -357,6 +338,18 @@ __global__ void __launch_bounds__(256) k_admm_tile_big(const DevOcp *__restrict_
       eu[tid] = h - sig * dus[((long long)b * T + t) * NV + tid];
     }
   }
+  int nd = 0;  // dense rows of this node type (uniform)
+  for (int r = 0; r < c.n; ++r)
+    if (c.kind[r] == AGX_RES_COLLISION) {
+      const int k = c.off[r];
+      if (tid < 32) sg[nd][tid] = tid < NV ? cjac[(node * AGX_MAX_DENSE + c.coll_slot[r]) * 32 + tid] : 0.0;
+      if (tid == 32) {
+        const double rho = admm_rho(c.lb[k], c.ub[k], rs);
+        srho[nd] = rho;
+        sh[nd] = ys[node * AGX_MAX_NC + k] - rho * zs[node * AGX_MAX_NC + k];
+      }
+      ++nd;
+    }
   __syncthreads();
   for (int e = tid; e < NV * NV; e += nt) {
     const int i = e / NV, j = e % NV;
@@ -369,6 +362,7 @@ __global__ void __launch_bounds__(256) k_admm_tile_big(const DevOcp *__restrict_
         hww += Mli * Mlj; hqw += tqli * Mlj; hvw += tvli * Mlj;
         hqq += tqli * tqlj; hqv += tqli * tvlj; hvv += tvli * tvlj;
       }
+    for (int s = 0; s < nd; ++s) hqq += srho[s] * sg[s][i] * sg[s][j];  // rho g g' of the rows on q
     const double d = (i == j) ? sig : 0.0;
     const int o2 = i * Q::LD + j;
     q2[Q::Hqq + o2] = qt[Q::Hqq + o2] + hqq + d;
@@ -385,6 +379,7 @@ __global__ void __launch_bounds__(256) k_admm_tile_big(const DevOcp *__restrict_
     double gw = 0.0, gq = -sig * cx[i], gv = -sig * cx[NV + i];
     if (t < T)
       for (int l = 0; l < NV; ++l) { gw += sM[l * NV + i] * eu[l]; gq += sq[l * NV + i] * eu[l]; gv += sv[l * NV + i] * eu[l]; }
+    for (int s = 0; s < nd; ++s) gq += sh[s] * sg[s][i];
     if (t < T) q2[Q::gw + i] = qt[Q::gw + i] + gw;
     q2[Q::gx + i] = qt[Q::gx + i] + gq;
     q2[Q::gx + NV + i] = qt[Q::gx + NV + i] + gv;
@@ -402,7 +397,7 @@ __global__ void __launch_bounds__(64) k_admm_update_big(const DevOcp *__restrict
                                                         const double *__restrict__ auxs, const double *__restrict__ dxs,
                                                         const double *__restrict__ wss, double *__restrict__ dus,
                                                         double *__restrict__ cxs, const double *__restrict__ cg,
-                                                        double *__restrict__ ys, double *__restrict__ zs,
+                                                        const double *__restrict__ cjac, double *__restrict__ ys, double *__restrict__ zs,
                                                         double *__restrict__ nodestat, double *__restrict__ admmstat,
                                                         double *__restrict__ qt2s, const DevState *__restrict__ st) {
   static_assert(NV <= 32, "a matrix row per 32 lanes");
@@ -452,6 +447,7 @@ __global__ void __launch_bounds__(64) k_admm_update_big(const DevOcp *__restrict
   double primal = 0.0, primal_rel = 0.0, dual_u = 0.0, drel_u = 0.0, e_u = 0.0, hn_u = 0.0;
   if (in && t < T)
     for (int r = 0; r < c.n; ++r) {
+      if (c.kind[r] != AGX_RES_CONTROL) continue;
       const int k = c.off[r] + l;
       const double rho = admm_rho(c.lb[k], c.ub[k], rs);
       const double z0 = z[k], y0 = y[k];
@@ -467,18 +463,40 @@ __global__ void __launch_bounds__(64) k_admm_update_big(const DevOcp *__restrict
       hn_u += yn - rho * zn;
       if (act) { z[k] = zn; y[k] = yn; }
     }
+  // collision rows: one Jacobian row on q each, C d = g . dq (the same on the 32 lanes of the node)
+  double dual_q = 0.0, drel_q = 0.0, e_q = 0.0, hn_q = 0.0;
+  for (int r = 0; r < c.n; ++r) {
+    if (c.kind[r] != AGX_RES_COLLISION) continue;
+    const int k = c.off[r];
+    const double gq = in ? cjac[(node * AGX_MAX_DENSE + c.coll_slot[r]) * 32 + l] : 0.0;
+    const double Cd = sum32(gq * dq);
+    const double rho = admm_rho(c.lb[k], c.ub[k], rs);
+    const double z0 = z[k], y0 = y[k];
+    const double zrel = kAlphaRelax * Cd + (1.0 - kAlphaRelax) * z0;
+    double zn = zrel + y0 / rho;
+    zn = fmin(fmax(zn, c.lb[k] - g[k]), c.ub[k] - g[k]);
+    const double yn = y0 + rho * (zrel - zn);
+    primal = fmax(primal, fabs(Cd - zn));
+    primal_rel = fmax(primal_rel, fmax(fabs(Cd), fabs(zn)));
+    dual_q += gq * rho * (zn - z0);
+    drel_q += gq * yn;
+    e_q += gq * (rho * Cd + (y0 - rho * z0) - yn);
+    hn_q += gq * (yn - rho * zn);
+    __builtin_amdgcn_wave_barrier();  // every lane has read z0, y0
+    if (act && l == 0) { z[k] = zn; y[k] = yn; }
+  }
   if (in) {
     if (t < T) kkt = fmax(kkt, fabs((ax[A::Luu + l] + preg) * du + sig * (du - duc) + e_u));
-    kkt = fmax(kkt, sm * fmax(fabs(hq + dreg * dq + sig * (dq - cq)), fabs((ax[A::Lvv + l] + dreg) * dv + sig * (dv - cv))));
+    kkt = fmax(kkt, sm * fmax(fabs(hq + dreg * dq + sig * (dq - cq) + e_q), fabs((ax[A::Lvv + l] + dreg) * dv + sig * (dv - cv))));
   }
   kkt = max32(kkt);
   gap = sum32(gap);
   primal = max32(primal);
   primal_rel = max32(primal_rel);
-  const double dual = max32(fabs(dual_u)), drel = max32(fabs(drel_u));
+  const double dual = max32(fmax(fabs(dual_u), fabs(dual_q))), drel = max32(fmax(fabs(drel_u), fabs(drel_q)));
   // gradient of the next iteration's augmented tile:  g = g0 + [taux M]' (h_u - sigma du) - sigma dx
   const double e_own = (t < T && in) ? hn_u - sig * du : 0.0;
-  double gwn = 0.0, gqn = -sig * dq, gvn = -sig * dv;
+  double gwn = 0.0, gqn = hn_q - sig * dq, gvn = -sig * dv;
   for (int k = 0; k < NV; ++k) {
     const double e = __shfl(e_own, half + k, 64);
     gwn += ax[A::M + k * A::LD + lc] * e * tm;

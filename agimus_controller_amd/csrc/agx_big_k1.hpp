@@ -178,6 +178,7 @@ struct WgIn {
   const double *ref;  // the node's reference tile (stride doubles)
   int stride;
   const int *frames;
+  bool kin_only = false;  // stop after the kinematics (k_con_eval_wg)
 };
 
 // Cost rows of one node, evaluated by ONE wave (lane j: component j of the state / control rows, column j of every
@@ -456,6 +457,7 @@ __device__ __forceinline__ double wg_node(WgNode<NV> &L, const DevModel &m, cons
   }
   __syncthreads();
   AGX_WG_STAMP();
+  if (in.kin_only) return 0.0;  // constraint evaluation (k_con_eval_wg): world placements and joint axes are in LDS
 
   if (TERM) {
     if (wave == 1) wg_costs<NV, TERM, DIFF>(L, m, rows, in, lane, sc);
@@ -766,6 +768,74 @@ __global__ void __launch_bounds__(256, AGX_WG_MINWAVES) k_calc_qp_wg(const DevMo
   double *qt = qts + node * QT<NV>::SIZE, *ax = auxs + node * AUX<NV>::SIZE;
   if (term) { in.dt = 0.0; wg_node<NV, true, true>(L, *mp, o.rows[1], in, qt, ax); }
   else { in.dt = dts[t]; wg_node<NV, false, true>(L, *mp, o.rows[0], in, qt, ax); }
+}
+
+// Constraint values, Jacobians and the l1 violation of every node for large models (k_con_eval of agx_admm.hpp): control-limit
+// rows (g = u - ref, identity Jacobian on u) and collision-distance rows (colmpc.ResidualDistanceCollision: g = d(q), Jacobian
+// row on q as in wg_costs).  One workgroup per node: the kinematics of wg_node, then wave 0 evaluates the rows, lane j its
+// column.  cg [B][T+1][AGX_MAX_NC], cjac [B][T+1][AGX_MAX_DENSE][32] (d / dq only: no supported row depends on v; u rows are I).
+template <int NV>
+__global__ void __launch_bounds__(256, AGX_WG_MINWAVES) k_con_eval_wg(const DevModel *__restrict__ mp, const DevOcp *__restrict__ op,
+                                                                      const double *__restrict__ xs, const double *__restrict__ us,
+                                                                      double *__restrict__ cg, double *__restrict__ cjac,
+                                                                      double *__restrict__ nodestat, const DevState *__restrict__ st,
+                                                                      int phase) {
+  constexpr int NX = 2 * NV;
+  __shared__ WgNode<NV> L;
+  __shared__ DevRows none;
+  const DevOcp &o = *op;
+  const DevModel &m = *mp;
+  const int T = o.T, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long long node = blockIdx.x;
+  const int b = (int)(node / (T + 1)), t = (int)(node % (T + 1));
+  if (!k1_active(st[b], phase)) return;
+  const DevCons &c = o.cons[t == T ? 1 : 0];
+  if (threadIdx.x == 0) none.n = 0;
+  if (c.ncoll > 0) {
+    WgIn in;
+    in.x = xs + node * NX; in.dx = nullptr; in.xn = in.x; in.dxn = nullptr;
+    in.u = us + ((long long)b * T + (t < T ? t : T - 1)) * NV; in.du = nullptr; in.alpha = 0.0; in.preg = 0.0; in.mu_dyn = 0.0; in.dt = 0.0;
+    in.ref = nullptr; in.stride = 0; in.frames = nullptr; in.kin_only = true;
+    __syncthreads();
+    wg_node<NV, true, false>(L, m, none, in, nullptr, nullptr);  // TERM: no successor state / control is read
+  }
+  if (wave != 0) return;
+  const int j = lane < NV ? lane : NV - 1;
+  const bool jl = lane < NV;
+  double v = 0.0;
+  for (int r = 0; r < c.n; ++r) {
+    const int off = c.off[r];
+    if (c.kind[r] == AGX_RES_CONTROL) {
+      const double g = (t < T) ? us[((long long)b * T + t) * NV + j] - c.ref[r][j] : 0.0;
+      if (jl) {
+        cg[node * AGX_MAX_NC + off + j] = g;
+        v += fmax(c.lb[off + j] - g, 0.0) + fmax(g - c.ub[off + j], 0.0);
+      }
+    } else if (c.kind[r] == AGX_RES_COLLISION) {
+      double Ra[9], pa[3], Rb[9], pb[3], ca[3], cb[3], n[3];
+      int ja, jb;
+      wg_frame_world<NV>(L, m, c.frame[r], Ra, pa, &ja);
+      wg_frame_world<NV>(L, m, c.frame_b[r], Rb, pb, &jb);
+      const double d = collision_distance_placed(m, c.frame[r], c.frame_b[r], Ra, pa, Rb, pb, ca, cb, n);
+      const bool ona = (ja >= 0) && ((L.anc[ja >= 0 ? ja : 0] >> j) & 1u);
+      const bool onb = (jb >= 0) && ((L.anc[jb >= 0 ? jb : 0] >> j) & 1u);
+      const double *Sj = L.S[j], *pj = L.w.c.pw[j];
+      double da[3], db[3], ta[3], tb[3];
+#pragma unroll
+      for (int e = 0; e < 3; ++e) { da[e] = ca[e] - pj[e]; db[e] = cb[e] - pj[e]; }
+      cross3(Sj + 3, da, ta);
+      cross3(Sj + 3, db, tb);
+      const double gq = (ona ? dot3(n, ta) : 0.0) - (onb ? dot3(n, tb) : 0.0);
+      if (lane < 32) cjac[(node * AGX_MAX_DENSE + c.coll_slot[r]) * 32 + lane] = jl ? gq : 0.0;
+      if (lane == 0) {
+        cg[node * AGX_MAX_NC + off] = d;
+        v += fmax(c.lb[off] - d, 0.0) + fmax(d - c.ub[off], 0.0);
+      }
+    }
+  }
+#pragma unroll
+  for (int sft = 1; sft < 64; sft <<= 1) v += __shfl_xor(v, sft, 64);
+  if (lane == 0) nodestat[node * 4 + 3] = v;
 }
 
 // One semi-implicit Euler step (OCPBaseCroco.integrate, ocp_base_croco.py:184-189): forward dynamics only, one

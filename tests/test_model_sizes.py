@@ -187,5 +187,52 @@ def test_control_limits_on_large_models(hip_backend, nv, kind, limit):
     # a state bound on a large model is refused with a message
     bad = [_abi.ConstraintSpec(_abi.RES_STATE, lower=-np.ones(2 * nv), upper=np.ones(2 * nv), name="state_box")]
     if 2 * nv <= 32:
-        with pytest.raises(Exception, match="control-limit constraints only"):
+        with pytest.raises(Exception, match="constraints only"):
             hip_backend.HipOcp(table, _abi.PackedOcp(nv, [0.02] * T, po0.running, po0.terminal, running_constraints=bad), B)
+
+
+def _panda_collision_with_fingers():
+    """The collision-avoidance Panda of tests/test_constraints.py (arm capsules, one obstacle) with its two finger joints unlocked:
+    nv = 9, runs at the 16-joint capacity."""
+    import dataclasses
+
+    p = rt.panda_collision_table(0.1, obstacle_xyz=(0.45, 0.1, 0.45), obstacle_radius=0.08, obstacle_length=0.3)
+    f = rt.chain_table(2, seed=5, armature=0.1)
+
+    def cat(a, b):
+        return np.concatenate([np.asarray(a), np.asarray(b)])
+
+    return dataclasses.replace(
+        p, name="panda_collision_fingers", joint_names=list(p.joint_names) + ["finger_joint1", "finger_joint2"],
+        parent=np.arange(-1, 8, dtype=np.int32), placement=cat(p.placement, f.placement), axis=cat(p.axis, f.axis),
+        mass=cat(p.mass, 0.05 * f.mass), com=cat(p.com, 0.2 * f.com), inertia=cat(p.inertia, 1e-3 * f.inertia),
+        armature=cat(p.armature, f.armature), effort_limit=cat(p.effort_limit, [20.0, 20.0]),
+        lower_position_limit=cat(p.lower_position_limit, [-0.5, -0.5]), upper_position_limit=cat(p.upper_position_limit, [0.5, 0.5]),
+        velocity_limit=cat(p.velocity_limit, [1.0, 1.0]))
+
+
+def test_collision_constraint_and_torque_limits_on_nine_joints(hip_backend):
+    """The constraint of ocp_traj_tracking_collision_avoidance.yaml (distance of a capsule pair >= bound) together with torque limits
+    for the Panda with unlocked fingers: constraint values and Jacobian rows from k_con_eval_wg, ADMM on the workgroup path."""
+    table = _panda_collision_with_fingers()
+    nv = table.nv
+    assert nv == 9
+    tcp = table.frame_id("panda_hand_tcp")
+    T, B = 10, 3
+    running, terminal = workloads.collision_avoidance_rows(table, tcp, alpha=0.05)
+    fa, fb = table.frame_id("panda_link7_capsule_0"), table.frame_id("obstacle")
+    lim = np.full(nv, 30.0)
+    con = [_abi.ConstraintSpec(_abi.RES_COLLISION, lower=0.05, upper=np.inf, frame=fa, frame_b=fb, name="collision"),
+           _abi.ConstraintSpec(_abi.RES_CONTROL, lower=-lim, upper=lim, name="ctrl_limit")]
+    po = _abi.PackedOcp(nv, [0.01] * T, running, terminal, max_qp_iters=100, running_constraints=con,
+                        terminal_constraints=[con[0]])
+    _, ref, x0, xs, us = workloads.random_goal_problem(table, T, 0.01, B, 23, frame=tcp, rows="collision")
+    h, o = hip_backend.HipOcp(table, po, B), Oracle(table, po, B)
+    h.set_refs(ref)
+    r_o = o.solve(ref, None, x0, xs, us, 3)
+    r_h = h.solve(x0, xs, us, 3)
+    assert np.array_equal(r_h[3]["iter"], r_o[3]["iter"]) and np.array_equal(r_h[3]["qp_iters"], r_o[3]["qp_iters"])
+    np.testing.assert_allclose(r_h[0], r_o[0], rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(r_h[1], r_o[1], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(r_h[3]["kkt"], r_o[3]["kkt"], rtol=1e-4, atol=1e-8)
+    h.close()
