@@ -1216,9 +1216,9 @@ int agx_ocp_create(const agx_model *m, const agx_ocp_desc *d, int batch, int dev
   if (o->has_con && o->nv > 7) {  // large models: ConstraintModelControlLimit only (agx_big.hpp)
     for (int lay = 0; lay < 2; ++lay)
       for (int r = 0; r < o->ho.cons[lay].n; ++r)
-        if (o->ho.cons[lay].kind[r] != AGX_RES_CONTROL && o->ho.cons[lay].kind[r] != AGX_RES_COLLISION) {
+        if (o->ho.cons[lay].kind[r] == AGX_RES_STATE || o->ho.cons[lay].kind[r] == AGX_RES_FRAME_VELOCITY || o->ho.cons[lay].kind[r] == AGX_RES_CONTROL_GRAV) {
           delete o;
-          return fail("agx_ocp_create: models above 7 joints (after padding: nv > 7) take control-limit and collision-distance constraints only");
+          return fail("agx_ocp_create: models above 7 joints (after padding: nv > 7) take control-limit, collision-distance and frame translation / rotation / placement constraints only");
         }
   }
   {

@@ -282,7 +282,8 @@ __global__ void __launch_bounds__(64) k_node_kkt_big(const DevOcp *__restrict__ 
   gap = sum32(gap);
   if (act && l == 0) {
     double *ns = nodestat + node * 4;
-    ns[0] = kkt; ns[1] = qt[Q::cost]; ns[2] = gap; ns[3] = 0.0;
+    ns[0] = kkt; ns[1] = qt[Q::cost]; ns[2] = gap;
+    if (!o.has_con) ns[3] = 0.0;  // constrained problems: the violation share of the constraint evaluation (which may run before this kernel) stays
   }
 }
 
@@ -340,16 +341,17 @@ __global__ void __launch_bounds__(256) k_admm_tile_big(const DevOcp *__restrict_
   }
   int nd = 0;  // dense rows of this node type (uniform)
   for (int r = 0; r < c.n; ++r)
-    if (c.kind[r] == AGX_RES_COLLISION) {
-      const int k = c.off[r];
-      if (tid < 32) sg[nd][tid] = tid < NV ? cjac[(node * AGX_MAX_DENSE + c.coll_slot[r]) * 32 + tid] : 0.0;
-      if (tid == 32) {
-        const double rho = admm_rho(c.lb[k], c.ub[k], rs);
-        srho[nd] = rho;
-        sh[nd] = ys[node * AGX_MAX_NC + k] - rho * zs[node * AGX_MAX_NC + k];
+    if (c.kind[r] != AGX_RES_CONTROL)  // rows with Jacobian rows on q: collision distance (1), frame translation / rotation (3), placement (6)
+      for (int e = 0; e < c.nr[r]; ++e) {
+        const int k = c.off[r] + e;
+        if (tid < 32) sg[nd][tid] = tid < NV ? cjac[(node * AGX_MAX_DENSE + c.coll_slot[r] + e) * 32 + tid] : 0.0;
+        if (tid == 32) {
+          const double rho = admm_rho(c.lb[k], c.ub[k], rs);
+          srho[nd] = rho;
+          sh[nd] = ys[node * AGX_MAX_NC + k] - rho * zs[node * AGX_MAX_NC + k];
+        }
+        ++nd;
       }
-      ++nd;
-    }
   __syncthreads();
   for (int e = tid; e < NV * NV; e += nt) {
     const int i = e / NV, j = e % NV;
@@ -463,12 +465,12 @@ __global__ void __launch_bounds__(64) k_admm_update_big(const DevOcp *__restrict
       hn_u += yn - rho * zn;
       if (act) { z[k] = zn; y[k] = yn; }
     }
-  // collision rows: one Jacobian row on q each, C d = g . dq (the same on the 32 lanes of the node)
+  // rows on q (collision distance, frame residuals): one Jacobian row per component, C d = g . dq (the same on the 32 lanes of the node)
   double dual_q = 0.0, drel_q = 0.0, e_q = 0.0, hn_q = 0.0;
-  for (int r = 0; r < c.n; ++r) {
-    if (c.kind[r] != AGX_RES_COLLISION) continue;
-    const int k = c.off[r];
-    const double gq = in ? cjac[(node * AGX_MAX_DENSE + c.coll_slot[r]) * 32 + l] : 0.0;
+  for (int r = 0; r < c.n; ++r)
+  for (int e = 0; e < (c.kind[r] != AGX_RES_CONTROL ? c.nr[r] : 0); ++e) {
+    const int k = c.off[r] + e;
+    const double gq = in ? cjac[(node * AGX_MAX_DENSE + c.coll_slot[r] + e) * 32 + l] : 0.0;
     const double Cd = sum32(gq * dq);
     const double rho = admm_rho(c.lb[k], c.ub[k], rs);
     const double z0 = z[k], y0 = y[k];
@@ -575,7 +577,8 @@ __global__ void __launch_bounds__(64) k_node_kkt_gen(const DevOcp *__restrict__ 
       kkt = fmax(kkt, fmax(fabs(hq), fabs(hv)));
     }
   double *ns = nodestat + node * 4;
-  ns[0] = kkt; ns[1] = qt[Q::cost]; ns[2] = gap; ns[3] = 0.0;
+  ns[0] = kkt; ns[1] = qt[Q::cost]; ns[2] = gap;
+  if (!o.has_con) ns[3] = 0.0;  // as k_node_kkt
 }
 
 // Exit path for large nv: the Hessian blocks of every node with CSQP's proximal terms,

@@ -771,8 +771,8 @@ __global__ void __launch_bounds__(256, AGX_WG_MINWAVES) k_calc_qp_wg(const DevMo
 }
 
 // Constraint values, Jacobians and the l1 violation of every node for large models (k_con_eval of agx_admm.hpp): control-limit
-// rows (g = u - ref, identity Jacobian on u) and collision-distance rows (colmpc.ResidualDistanceCollision: g = d(q), Jacobian
-// row on q as in wg_costs).  One workgroup per node: the kinematics of wg_node, then wave 0 evaluates the rows, lane j its
+// rows (g = u - ref, identity Jacobian on u), collision-distance rows (colmpc.ResidualDistanceCollision: g = d(q), Jacobian
+// row on q as in wg_costs) and frame translation / rotation / placement rows (3 / 3 / 6 Jacobian rows on q).  One workgroup per node: the kinematics of wg_node, then wave 0 evaluates the rows, lane j its
 // column.  cg [B][T+1][AGX_MAX_NC], cjac [B][T+1][AGX_MAX_DENSE][32] (d / dq only: no supported row depends on v; u rows are I).
 template <int NV>
 __global__ void __launch_bounds__(256, AGX_WG_MINWAVES) k_con_eval_wg(const DevModel *__restrict__ mp, const DevOcp *__restrict__ op,
@@ -831,6 +831,62 @@ __global__ void __launch_bounds__(256, AGX_WG_MINWAVES) k_con_eval_wg(const DevM
         cg[node * AGX_MAX_NC + off] = d;
         v += fmax(c.lb[off] - d, 0.0) + fmax(d - c.ub[off], 0.0);
       }
+    } else if (c.kind[r] == AGX_RES_FRAME_TRANSLATION || c.kind[r] == AGX_RES_FRAME_ROTATION || c.kind[r] == AGX_RES_FRAME_PLACEMENT) {
+      // the residuals of the cost rows as constraints (constraints_eval, agx_device.hpp): translation p(q) - pref with the
+      // LOCAL_WORLD_ALIGNED linear frame Jacobian, rotation log3(Rref' R) with Jlog3 x LOCAL angular Jacobian, placement
+      // log6(Mref^-1 M) with Jlog6 x LOCAL Jacobian; lane j: column j of the nr Jacobian rows
+      const int kind = c.kind[r], nr = c.nr[r];
+      double RF[9], pF[3];
+      int jf;
+      wg_frame_world<NV>(L, m, c.frame[r], RF, pF, &jf);
+      const double *rr = c.ref[r];
+      double res[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0}, TL[9], TR[9];
+      if (kind == AGX_RES_FRAME_TRANSLATION) {
+#pragma unroll
+        for (int e = 0; e < 3; ++e) res[e] = pF[e] - rr[e];
+      } else if (kind == AGX_RES_FRAME_ROTATION) {
+        double Rrel[9];
+        mtm3(rr, RF, Rrel);
+        log3(Rrel, res);
+        jlog3(res, TL);
+      } else {
+        double Rrel[9], d3[3], prel[3];
+        mtm3(rr, RF, Rrel);
+        d3[0] = pF[0] - rr[9]; d3[1] = pF[1] - rr[10]; d3[2] = pF[2] - rr[11];
+        mtv3(rr, d3, prel);
+        log6<true>(Rrel, prel, res, TL, TR);
+      }
+      const bool on = (jf >= 0) && ((L.anc[jf >= 0 ? jf : 0] >> j) & 1u);
+      const double *Sj = L.S[j], *pj = L.w.c.pw[j];
+      double d3[3], tz[3], lin[3], ang[3], out[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int e = 0; e < 3; ++e) d3[e] = pF[e] - pj[e];
+      cross3(Sj + 3, d3, tz);  // z x (pF - pj)
+      if (kind == AGX_RES_FRAME_TRANSLATION) {
+#pragma unroll
+        for (int e = 0; e < 3; ++e) out[e] = tz[e];
+      } else {
+        mtv3(RF, tz, lin);
+        mtv3(RF, Sj + 3, ang);
+#pragma unroll
+        for (int e = 0; e < 3; ++e) {
+          const double bot = TL[3 * e] * ang[0] + TL[3 * e + 1] * ang[1] + TL[3 * e + 2] * ang[2];
+          if (kind == AGX_RES_FRAME_ROTATION) out[e] = bot;
+          else {
+            out[e] = TL[3 * e] * lin[0] + TL[3 * e + 1] * lin[1] + TL[3 * e + 2] * lin[2] + TR[3 * e] * ang[0] + TR[3 * e + 1] * ang[1] + TR[3 * e + 2] * ang[2];
+            out[3 + e] = bot;
+          }
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < 6; ++e)
+        if (e < nr) {
+          if (lane < 32) cjac[(node * AGX_MAX_DENSE + c.coll_slot[r] + e) * 32 + lane] = (jl && on) ? out[e] : 0.0;
+          if (lane == 0) {
+            cg[node * AGX_MAX_NC + off + e] = res[e];
+            v += fmax(c.lb[off + e] - res[e], 0.0) + fmax(res[e] - c.ub[off + e], 0.0);
+          }
+        }
     }
   }
 #pragma unroll

@@ -236,3 +236,36 @@ def test_collision_constraint_and_torque_limits_on_nine_joints(hip_backend):
     np.testing.assert_allclose(r_h[1], r_o[1], rtol=1e-5, atol=1e-5)
     np.testing.assert_allclose(r_h[3]["kkt"], r_o[3]["kkt"], rtol=1e-4, atol=1e-8)
     h.close()
+
+
+@pytest.mark.parametrize("which", ["translation+collision", "rotation", "placement"])
+def test_frame_constraints_on_nine_joints(hip_backend, which):
+    """ConstraintModelResidual on the frame residuals (ocp_croco_generic.py:198-356, 594-620) for a model above 7 joints: the end
+    effector of the Panda with unlocked fingers confined to a box / its orientation / its pose bounded, next to the collision
+    constraint -- the nr Jacobian rows on q of each row come from k_con_eval_wg.  Same ADMM iteration counts as the checker."""
+    table = _panda_collision_with_fingers()
+    nv = table.nv
+    tcp = table.frame_id("panda_hand_tcp")
+    T, B = 10, 3
+    running, terminal = workloads.goal_reaching_rows(tcp)
+    _, ref, x0, xs, us = workloads.random_goal_problem(table, T, 0.01, B, 23, frame=tcp)
+    o0 = Oracle(table, _abi.PackedOcp(nv, [0.01] * T, running, terminal), B)
+    P0 = o0.frame_placement(tcp, x0[:, :nv])
+    fa, fb = table.frame_id("panda_link7_capsule_0"), table.frame_id("obstacle")
+    if which == "translation+collision":
+        con = [_abi.ConstraintSpec(_abi.RES_FRAME_TRANSLATION, lower=[-0.02, -0.03, -0.01], upper=[0.02, 0.01, 0.03], ref=P0[:, 9:].mean(0), frame=tcp, name="ee_box"),
+               _abi.ConstraintSpec(_abi.RES_COLLISION, lower=0.05, upper=np.inf, frame=fa, frame_b=fb, name="collision")]
+    elif which == "rotation":
+        con = [_abi.ConstraintSpec(_abi.RES_FRAME_ROTATION, lower=-0.05, upper=0.05, ref=P0[0, :9], frame=tcp, name="ee_rot")]
+    else:
+        con = [_abi.ConstraintSpec(_abi.RES_FRAME_PLACEMENT, lower=-0.04, upper=0.04, ref=P0[0], frame=tcp, name="ee_pose")]
+    po = _abi.PackedOcp(nv, [0.01] * T, running, terminal, max_qp_iters=100, running_constraints=con, terminal_constraints=con)
+    h, o = hip_backend.HipOcp(table, po, B), Oracle(table, po, B)
+    h.set_refs(ref)
+    r_o = o.solve(ref, None, x0, xs, us, 2)
+    r_h = h.solve(x0, xs, us, 2)
+    assert np.array_equal(r_h[3]["qp_iters"], r_o[3]["qp_iters"])
+    np.testing.assert_allclose(r_h[0], r_o[0], rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(r_h[1], r_o[1], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(r_h[3]["kkt"], r_o[3]["kkt"], rtol=1e-4, atol=1e-8)
+    h.close()
