@@ -280,7 +280,7 @@ int fill_cons(const agx_constraint_row *rows, int n, int nv, int nvu, const DevM
     if (c.kind != AGX_RES_STATE && c.kind != AGX_RES_CONTROL && !agx::cons_has_dense_rows(c.kind))
       return fail("agx_ocp_create: unknown constraint residual kind");
     const int nr = agx_row_nr(c.kind, nv), nref = agx_row_nref(c.kind, nv);
-    if (off + nr > AGX_MAX_NC) return fail("agx_ocp_create: more than 32 constraint components per node");
+    if (off + nr > AGX_MAX_NC) return fail("agx_ocp_create: more than " + std::to_string(AGX_MAX_NC) + " constraint components per node");
     if (!c.lower || !c.upper) return fail("agx_ocp_create: constraint bounds missing");
     const int i = d.n++;
     d.kind[i] = c.kind; d.frame[i] = c.frame; d.frame_b[i] = c.frame_b; d.off[i] = off; d.nr[i] = nr;
@@ -1216,9 +1216,9 @@ int agx_ocp_create(const agx_model *m, const agx_ocp_desc *d, int batch, int dev
   if (o->has_con && o->nv > 7) {  // large models: ConstraintModelControlLimit only (agx_big.hpp)
     for (int lay = 0; lay < 2; ++lay)
       for (int r = 0; r < o->ho.cons[lay].n; ++r)
-        if (o->ho.cons[lay].kind[r] == AGX_RES_STATE || o->ho.cons[lay].kind[r] == AGX_RES_FRAME_VELOCITY || o->ho.cons[lay].kind[r] == AGX_RES_CONTROL_GRAV) {
+        if (o->ho.cons[lay].kind[r] == AGX_RES_FRAME_VELOCITY || o->ho.cons[lay].kind[r] == AGX_RES_CONTROL_GRAV) {
           delete o;
-          return fail("agx_ocp_create: models above 7 joints (after padding: nv > 7) take control-limit, collision-distance and frame translation / rotation / placement constraints only");
+          return fail("agx_ocp_create: FrameVelocity / ControlGrav constraints are implemented for models of at most 7 joints (after padding)");
         }
   }
   {

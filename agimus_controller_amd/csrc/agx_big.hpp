@@ -308,7 +308,8 @@ __global__ void __launch_bounds__(256) k_admm_tile_big(const DevOcp *__restrict_
   typedef QT<NV> Q;
   typedef AUX<NV> A;
   __shared__ double sM[NV * NV], sq[NV * NV], sv[NV * NV], wu[32], eu[32];
-  __shared__ double sg[AGX_MAX_DENSE][32], srho[AGX_MAX_DENSE], sh[AGX_MAX_DENSE];  // collision rows: Jacobian row on q, rho, h = y - rho z
+  __shared__ double sg[AGX_MAX_DENSE][32], srho[AGX_MAX_DENSE], sh[AGX_MAX_DENSE];  // rows on q: Jacobian row, rho, h = y - rho z
+  __shared__ double sxr[2][32], sxh[2][32];  // state bounds: rho and h of the q | v component of every joint
   const DevOcp &o = *op;
   const int T = o.T, tid = threadIdx.x, nt = blockDim.x;
   const long long node = blockIdx.x;
@@ -339,9 +340,21 @@ __global__ void __launch_bounds__(256) k_admm_tile_big(const DevOcp *__restrict_
       eu[tid] = h - sig * dus[((long long)b * T + t) * NV + tid];
     }
   }
+  if (tid < NV) {
+    double rq = 0.0, rv = 0.0, hq = 0.0, hv = 0.0;
+    for (int r = 0; r < c.n; ++r) {
+      if (c.kind[r] != AGX_RES_STATE) continue;
+      const int kq = c.off[r] + tid, kv = kq + NV;
+      const double a = admm_rho(c.lb[kq], c.ub[kq], rs), bb = admm_rho(c.lb[kv], c.ub[kv], rs);
+      rq += a; rv += bb;
+      hq += ys[node * AGX_MAX_NC + kq] - a * zs[node * AGX_MAX_NC + kq];
+      hv += ys[node * AGX_MAX_NC + kv] - bb * zs[node * AGX_MAX_NC + kv];
+    }
+    sxr[0][tid] = rq; sxr[1][tid] = rv; sxh[0][tid] = hq; sxh[1][tid] = hv;
+  }
   int nd = 0;  // dense rows of this node type (uniform)
   for (int r = 0; r < c.n; ++r)
-    if (c.kind[r] != AGX_RES_CONTROL)  // rows with Jacobian rows on q: collision distance (1), frame translation / rotation (3), placement (6)
+    if (c.kind[r] != AGX_RES_CONTROL && c.kind[r] != AGX_RES_STATE)  // rows with Jacobian rows on q: collision distance (1), frame translation / rotation (3), placement (6)
       for (int e = 0; e < c.nr[r]; ++e) {
         const int k = c.off[r] + e;
         if (tid < 32) sg[nd][tid] = tid < NV ? cjac[(node * AGX_MAX_DENSE + c.coll_slot[r] + e) * 32 + tid] : 0.0;
@@ -367,9 +380,9 @@ __global__ void __launch_bounds__(256) k_admm_tile_big(const DevOcp *__restrict_
     for (int s = 0; s < nd; ++s) hqq += srho[s] * sg[s][i] * sg[s][j];  // rho g g' of the rows on q
     const double d = (i == j) ? sig : 0.0;
     const int o2 = i * Q::LD + j;
-    q2[Q::Hqq + o2] = qt[Q::Hqq + o2] + hqq + d;
+    q2[Q::Hqq + o2] = qt[Q::Hqq + o2] + hqq + d + ((i == j) ? sxr[0][i] : 0.0);
     q2[Q::Hqv + o2] = qt[Q::Hqv + o2] + hqv;
-    q2[Q::Hvv + o2] = qt[Q::Hvv + o2] + hvv + d;
+    q2[Q::Hvv + o2] = qt[Q::Hvv + o2] + hvv + d + ((i == j) ? sxr[1][i] : 0.0);
     if (t < T) {
       q2[Q::Hww + o2] = qt[Q::Hww + o2] + hww;
       q2[Q::Hqw + o2] = qt[Q::Hqw + o2] + hqw;
@@ -378,7 +391,7 @@ __global__ void __launch_bounds__(256) k_admm_tile_big(const DevOcp *__restrict_
   }
   if (tid < NV) {  // gradient, gap, cost
     const int i = tid;
-    double gw = 0.0, gq = -sig * cx[i], gv = -sig * cx[NV + i];
+    double gw = 0.0, gq = -sig * cx[i] + sxh[0][i], gv = -sig * cx[NV + i] + sxh[1][i];
     if (t < T)
       for (int l = 0; l < NV; ++l) { gw += sM[l * NV + i] * eu[l]; gq += sq[l * NV + i] * eu[l]; gv += sv[l * NV + i] * eu[l]; }
     for (int s = 0; s < nd; ++s) gq += sh[s] * sg[s][i];
@@ -467,8 +480,30 @@ __global__ void __launch_bounds__(64) k_admm_update_big(const DevOcp *__restrict
     }
   // rows on q (collision distance, frame residuals): one Jacobian row per component, C d = g . dq (the same on the 32 lanes of the node)
   double dual_q = 0.0, drel_q = 0.0, e_q = 0.0, hn_q = 0.0;
+  double dual_v = 0.0, drel_v = 0.0, e_v = 0.0, hn_v = 0.0;
+  if (in)
+    for (int r = 0; r < c.n; ++r) {  // state bounds: components q_l and v_l on lane l
+      if (c.kind[r] != AGX_RES_STATE) continue;
+#pragma unroll
+      for (int hv = 0; hv < 2; ++hv) {
+        const int k = c.off[r] + hv * NV + l;
+        const double Cd = hv ? dv : dq;
+        const double rho = admm_rho(c.lb[k], c.ub[k], rs);
+        const double z0 = z[k], y0 = y[k];
+        const double zrel = kAlphaRelax * Cd + (1.0 - kAlphaRelax) * z0;
+        double zn = zrel + y0 / rho;
+        zn = fmin(fmax(zn, c.lb[k] - g[k]), c.ub[k] - g[k]);
+        const double yn = y0 + rho * (zrel - zn);
+        primal = fmax(primal, fabs(Cd - zn));
+        primal_rel = fmax(primal_rel, fmax(fabs(Cd), fabs(zn)));
+        const double dz = rho * (zn - z0), de = rho * Cd + (y0 - rho * z0) - yn, hn = yn - rho * zn;
+        if (hv) { dual_v += dz; drel_v += yn; e_v += de; hn_v += hn; }
+        else { dual_q += dz; drel_q += yn; e_q += de; hn_q += hn; }
+        if (act) { z[k] = zn; y[k] = yn; }
+      }
+    }
   for (int r = 0; r < c.n; ++r)
-  for (int e = 0; e < (c.kind[r] != AGX_RES_CONTROL ? c.nr[r] : 0); ++e) {
+  for (int e = 0; e < ((c.kind[r] != AGX_RES_CONTROL && c.kind[r] != AGX_RES_STATE) ? c.nr[r] : 0); ++e) {
     const int k = c.off[r] + e;
     const double gq = in ? cjac[(node * AGX_MAX_DENSE + c.coll_slot[r] + e) * 32 + l] : 0.0;
     const double Cd = sum32(gq * dq);
@@ -489,16 +524,16 @@ __global__ void __launch_bounds__(64) k_admm_update_big(const DevOcp *__restrict
   }
   if (in) {
     if (t < T) kkt = fmax(kkt, fabs((ax[A::Luu + l] + preg) * du + sig * (du - duc) + e_u));
-    kkt = fmax(kkt, sm * fmax(fabs(hq + dreg * dq + sig * (dq - cq) + e_q), fabs((ax[A::Lvv + l] + dreg) * dv + sig * (dv - cv))));
+    kkt = fmax(kkt, sm * fmax(fabs(hq + dreg * dq + sig * (dq - cq) + e_q), fabs((ax[A::Lvv + l] + dreg) * dv + sig * (dv - cv) + e_v)));
   }
   kkt = max32(kkt);
   gap = sum32(gap);
   primal = max32(primal);
   primal_rel = max32(primal_rel);
-  const double dual = max32(fmax(fabs(dual_u), fabs(dual_q))), drel = max32(fmax(fabs(drel_u), fabs(drel_q)));
+  const double dual = max32(fmax(fabs(dual_u), fmax(fabs(dual_q), fabs(dual_v)))), drel = max32(fmax(fabs(drel_u), fmax(fabs(drel_q), fabs(drel_v))));
   // gradient of the next iteration's augmented tile:  g = g0 + [taux M]' (h_u - sigma du) - sigma dx
   const double e_own = (t < T && in) ? hn_u - sig * du : 0.0;
-  double gwn = 0.0, gqn = hn_q - sig * dq, gvn = -sig * dv;
+  double gwn = 0.0, gqn = hn_q - sig * dq, gvn = hn_v - sig * dv;
   for (int k = 0; k < NV; ++k) {
     const double e = __shfl(e_own, half + k, 64);
     gwn += ax[A::M + k * A::LD + lc] * e * tm;

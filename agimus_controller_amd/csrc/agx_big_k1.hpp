@@ -771,7 +771,7 @@ __global__ void __launch_bounds__(256, AGX_WG_MINWAVES) k_calc_qp_wg(const DevMo
 }
 
 // Constraint values, Jacobians and the l1 violation of every node for large models (k_con_eval of agx_admm.hpp): control-limit
-// rows (g = u - ref, identity Jacobian on u), collision-distance rows (colmpc.ResidualDistanceCollision: g = d(q), Jacobian
+// rows (g = u - ref, identity Jacobian on u), state bounds (g = x - ref, identity on x), collision-distance rows (colmpc.ResidualDistanceCollision: g = d(q), Jacobian
 // row on q as in wg_costs) and frame translation / rotation / placement rows (3 / 3 / 6 Jacobian rows on q).  One workgroup per node: the kinematics of wg_node, then wave 0 evaluates the rows, lane j its
 // column.  cg [B][T+1][AGX_MAX_NC], cjac [B][T+1][AGX_MAX_DENSE][32] (d / dq only: no supported row depends on v; u rows are I).
 template <int NV>
@@ -810,6 +810,13 @@ __global__ void __launch_bounds__(256, AGX_WG_MINWAVES) k_con_eval_wg(const DevM
       if (jl) {
         cg[node * AGX_MAX_NC + off + j] = g;
         v += fmax(c.lb[off + j] - g, 0.0) + fmax(g - c.ub[off + j], 0.0);
+      }
+    } else if (c.kind[r] == AGX_RES_STATE) {
+      const double gq = xs[node * NX + j] - c.ref[r][j], gv = xs[node * NX + NV + j] - c.ref[r][NV + j];
+      if (jl) {
+        cg[node * AGX_MAX_NC + off + j] = gq;
+        cg[node * AGX_MAX_NC + off + NV + j] = gv;
+        v += fmax(c.lb[off + j] - gq, 0.0) + fmax(gq - c.ub[off + j], 0.0) + fmax(c.lb[off + NV + j] - gv, 0.0) + fmax(gv - c.ub[off + NV + j], 0.0);
       }
     } else if (c.kind[r] == AGX_RES_COLLISION) {
       double Ra[9], pa[3], Rb[9], pb[3], ca[3], cb[3], n[3];

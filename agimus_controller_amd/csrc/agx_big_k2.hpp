@@ -31,9 +31,10 @@ __device__ __forceinline__ agx_v4d tile_xty(const agx_v4d &X, const agx_v4d &Y, 
 // One pivot of the in-place Gauss-Jordan inversion of a 16 x 16 tile in the accumulator layout (g = lane >> 4, j = lane & 15;
 // x[r] = X[g + 4 r][j]):  p = 1 / a_kk;  a_kj <- a_kj p;  a_ij <- a_ij - a_ik a_kj (i, j != k);  a_ik <- -a_ik p;  a_kk <- p.
 template <int K>
-__device__ __forceinline__ void tile_inv_pivot(agx_v4d &x, const int g, const int j) {
+__device__ __forceinline__ void tile_inv_pivot(agx_v4d &x, const int g, const int j, bool &bad) {
   constexpr int rk = K >> 2, gk = K & 3;
   const double piv = readlane_f64(x[rk], 16 * gk + K);
+  bad = bad || !(piv > 0.0);  // the matrix is not positive definite (or not finite): the checker's LLT fails at the same place
   const double rp = chain_rcp(piv);
   const double rowk = __shfl(x[rk], 16 * gk + j, 64);  // the pivot row at my column
   const bool colk = (j == K);
@@ -48,14 +49,14 @@ __device__ __forceinline__ void tile_inv_pivot(agx_v4d &x, const int g, const in
   }
 }
 template <int K0, int K1>
-__device__ __forceinline__ void tile_inv_range(agx_v4d &x, const int g, const int j) {
+__device__ __forceinline__ void tile_inv_range(agx_v4d &x, const int g, const int j, bool &bad) {
   if constexpr (K0 < K1) {
-    tile_inv_pivot<K0>(x, g, j);
-    tile_inv_range<K0 + 1, K1>(x, g, j);
+    tile_inv_pivot<K0>(x, g, j, bad);
+    tile_inv_range<K0 + 1, K1>(x, g, j, bad);
   }
 }
-// inverse of a symmetric positive definite tile (no pivoting), in place
-__device__ __forceinline__ void tile_inverse(agx_v4d &x, const int g, const int j) { tile_inv_range<0, 16>(x, g, j); }
+// inverse of a symmetric positive definite tile (no pivoting), in place; bad: some pivot was not positive
+__device__ __forceinline__ void tile_inverse(agx_v4d &x, const int g, const int j, bool &bad) { tile_inv_range<0, 16>(x, g, j, bad); }
 
 // (Tried and discarded, round 3: the rank-one update of a pivot as ONE MFMA -- for a symmetric tile both operands are the
 // pivot row's own registers -- with the next pivot's reciprocal formed ahead of the update.  Fewer instructions, but the
@@ -88,6 +89,7 @@ __global__ void __launch_bounds__(256, 2) k_riccati_blk(const DevOcp *__restrict
   // Qw0 keeps the matrix for the refinement step.
   __shared__ double V[NX][LV], Qxw[NX + 1][LQ], Qww[NW][LQ], Qw0[NW][LQ], Kl[NV][LV];
   __shared__ double vx[NX], vp[NX], fl[NX], qx[NX], dxl[NX], wl[NV];
+  __shared__ int s_bad;  // Qww of some node not positive definite (the checker's LLT fails: the direction is discarded, k_sqp_head)
   constexpr int NT = (NX + 1 + 15) / 16;  // right-hand-side tiles of 16 columns: 4 (nv = 30: the gradient takes a spare column), 5 (nv = 32)
   const DevOcp &o = *op;
   const int T = o.T, b = blockIdx.x, tid = threadIdx.x, nt = 256, lane = tid & 63, wave = tid >> 6;
@@ -147,6 +149,7 @@ __global__ void __launch_bounds__(256, 2) k_riccati_blk(const DevOcp *__restrict
       Qw0[r][c] = (r == c && r >= NV) ? 1.0 : 0.0;
     }
     if (tid < LQ) Qxw[NX][tid] = 0.0;
+    if (tid == 0) s_bad = 0;
   }
   fetch(T - 1);
   if (tid < NX) fl[tid] = pf;
@@ -216,7 +219,8 @@ __global__ void __launch_bounds__(256, 2) k_riccati_blk(const DevOcp *__restrict
       agx_v4d A11;
 #pragma unroll
       for (int r = 0; r < 4; ++r) A11[r] = Qww[l4 + 4 * r][l15];
-      tile_inverse(A11, l4, l15);  // inv11
+      bool bad = false;
+      tile_inverse(A11, l4, l15, bad);  // inv11
       if constexpr (NWT == 1) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) Qww[l4 + 4 * r][l15] = A11[r];
@@ -231,7 +235,7 @@ __global__ void __launch_bounds__(256, 2) k_riccati_blk(const DevOcp *__restrict
         const agx_v4d W = tile_xty(A11, A12, zero);              // inv11 A12
         const agx_v4d Wt = tile_xty(A12, A11, zero);             // A12' inv11 = W'
         agx_v4d Sc = tile_xty<true>(A12, W, A22);                // A22 - A12' W
-        tile_inverse(Sc, l4, l15);                               // invS
+        tile_inverse(Sc, l4, l15, bad);                          // invS
         const agx_v4d B21 = tile_xty<true>(Sc, Wt, zero);        // -invS W'
         const agx_v4d B11 = tile_xty<true>(Wt, B21, A11);        // inv11 - W B21
 #pragma unroll
@@ -242,6 +246,7 @@ __global__ void __launch_bounds__(256, 2) k_riccati_blk(const DevOcp *__restrict
           Qww[16 + l4 + 4 * r][16 + l15] = Sc[r];
         }
       }
+      if (bad && lane == 0) s_bad = 1;
     }
     __syncthreads();
     AGX_BLK_T(3);
@@ -356,6 +361,14 @@ __global__ void __launch_bounds__(256, 2) k_riccati_blk(const DevOcp *__restrict
   if (tid == 0 && b == 0)
     printf("k_riccati_blk phases (10 ns ticks over %d nodes): p1 %lld p2 %lld p3 %lld p4 %lld p5 %lld p6 %lld\n", T, ph_[1], ph_[2], ph_[3], ph_[4], ph_[5], ph_[6]);
 #endif
+  if (!gains_pass) {
+    const int bad = s_bad;  // (written before the last barriers of the loop)
+    if (tid == 0) {
+      S.dir_fail = bad;
+      if (bad) atomicOr(&S.flags, 1);
+    }
+    if (bad) return;  // no forward pass on gains of an indefinite problem
+  }
   if (gains_pass || !forward) return;
   // ---- forward pass: w = -kw - Kw dx (8 lanes per row, columns strided over them), then the state update
   double *dx = dxs + (long long)b * (T + 1) * NX, *ws = wss + (long long)b * T * NV;

@@ -58,7 +58,13 @@ struct DevRows {
 // ConstraintListItem rows of one node type:  lb <= g(x, u) <= ub, g stacked over the rows.
 #define AGX_MAX_CONS 4
 #define AGX_MAX_DENSE 8  // constraint components with a dense Jacobian in q per node type (collision 1, translation / rotation 3, placement 6)
+// constraint components per node: 32 for the 7-joint capacity (its constraint kernels keep them in registers), state bounds +
+// control limits of a 32-joint model + dense rows for the workgroup path (2 x 32 + 32 + 8)
+#if (defined(AGX_GROUP) && AGX_GROUP == 0) || defined(AGX_ONLY_NV7)
 #define AGX_MAX_NC 32
+#else
+#define AGX_MAX_NC 104
+#endif
 struct DevCons {
   int n, nc, ncoll, pad;  // rows, components, Jacobian slots in use (ncoll: historically the collision rows)
   int kind[AGX_MAX_CONS], frame[AGX_MAX_CONS], frame_b[AGX_MAX_CONS], off[AGX_MAX_CONS], nr[AGX_MAX_CONS];

@@ -1082,8 +1082,11 @@ bool direction(int nv, int T, const double *tiles, Direction &d, double sigma = 
     for (int i = 0; i < nx; ++i) { Qxx[i * nx + i] += sigma; if (cx) Qx[i] -= sigma * cx[(size_t)t * nx + i]; }
     for (int i = 0; i < nu; ++i) { Quu[i * nu + i] += sigma + preg; if (cu) Qu[i] -= sigma * cu[(size_t)t * nu + i]; }
     L = Quu;
-    for (int j = 0; j < nu; ++j) { double dd = L[j * nu + j]; for (int k = 0; k < j; ++k) dd -= L[j * nu + k] * L[j * nu + k]; if (!(dd > 0.0)) ok = false; }
     cholesky(nu, L.data());
+    // LLT failure (SolverCSQP backwardPass): a pivot of the factorisation that is not positive (sqrt of it: not a positive number).
+    // (Until round 3 this tested  a_jj - sum_{k<j} a_jk^2  of the UNFACTORED matrix, which is not the pivot: it flagged positive
+    // definite matrices with large off-diagonal entries.)
+    for (int j = 0; j < nu; ++j) if (!(L[j * nu + j] > 0.0)) ok = false;
     double *K = &d.K[(size_t)t * nu * nx], *kk = &d.k[(size_t)t * nu];
     for (int j = 0; j < nx; ++j) {
       for (int i = 0; i < nu; ++i) col[i] = Qxu[j * nu + i];

@@ -184,11 +184,10 @@ def test_control_limits_on_large_models(hip_backend, nv, kind, limit):
     np.testing.assert_allclose(us_h, us_o, rtol=1e-5, atol=1e-5)
     assert np.abs(us_h).max() <= limit + 1e-3
     h.close()
-    # a state bound on a large model is refused with a message
-    bad = [_abi.ConstraintSpec(_abi.RES_STATE, lower=-np.ones(2 * nv), upper=np.ones(2 * nv), name="state_box")]
-    if 2 * nv <= 32:
-        with pytest.raises(Exception, match="constraints only"):
-            hip_backend.HipOcp(table, _abi.PackedOcp(nv, [0.02] * T, po0.running, po0.terminal, running_constraints=bad), B)
+    # a FrameVelocity constraint on a large model is refused with a message
+    bad = [_abi.ConstraintSpec(_abi.RES_FRAME_VELOCITY, lower=-np.ones(6), upper=np.ones(6), frame=frame, name="ee_twist")]
+    with pytest.raises(Exception, match="at most 7 joints"):
+        hip_backend.HipOcp(table, _abi.PackedOcp(nv, [0.02] * T, po0.running, po0.terminal, running_constraints=bad), B)
 
 
 def _panda_collision_with_fingers():
@@ -265,6 +264,31 @@ def test_frame_constraints_on_nine_joints(hip_backend, which):
     r_o = o.solve(ref, None, x0, xs, us, 2)
     r_h = h.solve(x0, xs, us, 2)
     assert np.array_equal(r_h[3]["qp_iters"], r_o[3]["qp_iters"])
+    np.testing.assert_allclose(r_h[0], r_o[0], rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(r_h[1], r_o[1], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(r_h[3]["kkt"], r_o[3]["kkt"], rtol=1e-4, atol=1e-8)
+    h.close()
+
+
+@pytest.mark.parametrize("nv,kind", [(9, "panda_fingers"), (30, "humanoid")])
+def test_state_bounds_and_torque_limits_on_large_models(hip_backend, nv, kind):
+    """Bounds on the state (here: joint-velocity limits) together with torque limits for models above 7 joints: 2 nv + nv
+    constraint components per node (the workgroup path takes up to 104)."""
+    table = rt.humanoid30_table() if kind == "humanoid" else _model(nv, kind)
+    frame = len(table.frame_names) - 1
+    B, T = 2, 8
+    po0, ref, x0, xs, us = workloads.random_goal_problem(table, T, 0.02, B, seed=600 + nv, frame=frame)
+    lim = np.full(nv, 40.0 if kind == "humanoid" else 6.0)
+    xb = np.full(2 * nv, np.inf)
+    xb[nv:] = 0.6
+    con = [_abi.ConstraintSpec(_abi.RES_STATE, lower=-xb, upper=xb, name="velocity_limit"),
+           _abi.ConstraintSpec(_abi.RES_CONTROL, lower=-lim, upper=lim, name="ctrl_limit")]
+    po = _abi.PackedOcp(nv, [0.02] * T, po0.running, po0.terminal, max_qp_iters=100, running_constraints=con, terminal_constraints=[con[0]])
+    h, o = hip_backend.HipOcp(table, po, B), Oracle(table, po, B)
+    h.set_refs(ref)
+    r_h = h.solve(x0, xs, us, 4)
+    r_o = o.solve(ref, None, x0, xs, us, 4)
+    assert np.array_equal(r_h[3]["iter"], r_o[3]["iter"]) and np.array_equal(r_h[3]["qp_iters"], r_o[3]["qp_iters"])
     np.testing.assert_allclose(r_h[0], r_o[0], rtol=1e-6, atol=1e-7)
     np.testing.assert_allclose(r_h[1], r_o[1], rtol=1e-5, atol=1e-5)
     np.testing.assert_allclose(r_h[3]["kkt"], r_o[3]["kkt"], rtol=1e-4, atol=1e-8)
