@@ -83,7 +83,9 @@ typedef struct agx_cost_row {
  * reference frame 0 WORLD / 1 LOCAL / 2 LOCAL_WORLD_ALIGNED); at most 4 rows and 8
  * components with a dense Jacobian (collision 1, translation / rotation 3,
  * placement / velocity 6, ControlGrav nv) per node type; residuals on u are
- * dropped at the terminal node.                                                 */
+ * dropped at the terminal node.  Models above 7 joints (after padding to the compiled
+ * capacity): State, Control, collision and frame translation / rotation / placement
+ * rows, up to 104 components per node; FrameVelocity / ControlGrav rows are refused. */
 typedef struct agx_constraint_row {
   int32_t kind;        /* agx_residual_kind                                     */
   int32_t active;      /* ConstraintListItem.active                             */
