@@ -867,7 +867,8 @@ int ensure_copy_stream(agx_ocp *o) {
 int line_search_rounds(agx_ocp *o, int it, int max_iter, bool *need_k1, int *n_done_out) {
   double *xs_t = o->d_xs + (size_t)o->B * (o->T + 1) * o->nx, *us_t = o->d_us + (size_t)o->B * o->T * o->nu;
   for (int round = 0; round < 10; ++round) {
-    if (o->prof && round == 0) {  // the kernel the roofline is quoted on, timed alone: running nodes of the trial pass
+    if (o->prof && round == 0 && it == 0) {  // the kernel the roofline is quoted on, timed alone: running nodes of the trial pass of the first
+                                             // iteration (every unfinished instance searches; later iterations serve a few stragglers: not the launch the bytes are counted for)
       if (prof_mark(o, 0, true)) return -1;
       if (launch_calc_qp(o, true, false, 1)) return -1;
       if (prof_mark(o, 0, false)) return -1;
