@@ -40,6 +40,9 @@ def main():
         head = (f"# {cmd}   (MI355X, ROCm 7.2, round 3; scripts/collect_profiles.sh {w})\n"
                 f"# B = {B} instances, T = {T}; {N_STEPS} MPC steps in the run; summary of the rocpd database (scripts/rocpd_stats.py).\n"
                 "# AGX_NO_EMPTY_LAUNCHES=1 skips the trial launches of the line search when nobody searches, AGX_K1_FUSED=0 launches running and terminal nodes separately.\n")
+        if w in ("cartesian", "collision"):
+            head += ("# The derivative kernel's AVERAGE covers every launch of the 10 SQP iterations of a step, most of which serve the few instances still\n"
+                     "# iterating (DESIGN.md section 5); the launch the roofline of bench.py is quoted on is the full one of the first iteration: the MAX column.\n")
         (ROOT / "profiles" / f"{ROUND}_kernel_stats_{w}.txt").write_text(head + (src / "kernel_stats.txt").read_text())
         fetch, write = parse_pmc(src / "pmc_fetch.txt"), parse_pmc(src / "pmc_write.txt")
         lines = [f"# HBM counters of the same command, separate passes: rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (KiB per dispatch).",
