@@ -95,6 +95,7 @@ struct agx_ocp {
   // iterate (solved = 0 / qp_iters = max_qp_iters) and continue from it at the next MPC step, as a lone controller
   // that ran into max_solve_time would.  1.0 = wait for everyone (the default).
   double quorum_sqp = 1.0, quorum_qp = 1.0;
+  bool con_lanes = true;          // constraint rows are control limits / state bounds / collision distances: k_con_eval_lj (AGX_CON_LANES=0: one lane per node)
   bool admm_loop_always = false;  // AGX_ADMM_LOOP=2 (tests): k_admm_loop whatever the number of unfinished instances
   bool admm_loop = true;      // AGX_ADMM_LOOP=0: every ADMM iteration as three launches (sweep, update, reduce) instead of k_admm_loop
   int n_unfinished = 1 << 30; // instances the SQP loop still works on (host's last count): k_admm_loop serves the tail of a step, when
@@ -683,6 +684,21 @@ int quorum_count(int B, double q) {
   return n < 1 ? 1 : (n > B ? B : n);
 }
 
+// Constraint values / Jacobian rows / violation of every node at (xs, us): 8 lanes per node for serial chains whose rows are
+// control limits, state bounds and collision distances (k_con_eval_lj), else one lane per node (k_con_eval).
+template <int NV, bool CH>
+void launch_con_eval(agx_ocp *o, const double *xs, const double *us, int phase) {
+  if constexpr (NV <= 7) {
+    const long long nodes = (long long)o->B * (o->T + 1);
+    if (CH && o->con_lanes)
+      hipLaunchKernelGGL((agx::k_con_eval_lj<NV>), dim3((int)((nodes * 8 + 63) / 64)), dim3(64), 0, o->stream, o->d_model, o->d_ocp, xs, us, o->d_cg,
+                         o->d_cjac, o->d_nodestat, o->d_state, phase);
+    else
+      hipLaunchKernelGGL((agx::k_con_eval<NV, CH>), dim3((int)((nodes + 63) / 64)), dim3(64), 0, o->stream, o->d_model, o->d_ocp, xs, us, o->d_cg,
+                         o->d_cjac, o->d_nodestat, o->d_state, phase);
+  }
+}
+
 // Constrained direction of one SQP iteration (SolverCSQP::computeDirection): the plain LQR pass has
 // run (equality-QP initial guess: dx, w); now du, the constraint data and the ADMM loop.
 // prefactor: the plain LQR pass has NOT run yet -- it is launched here, in one kernel with the factorisation of the
@@ -745,8 +761,7 @@ int admm_direction(agx_ocp *o, bool prefactor = false) {
         HIPCHK(hipMalloc((void **)&o->d_kws_lqr, sizeof(double) * (size_t)o->B * o->T * o->nu));
       }
       // constraint data and the augmented Hessians need only (xs, us) and rho: before the LQR pass
-      hipLaunchKernelGGL((agx::k_con_eval<NV, CH>), dim3((int)((nodes + 63) / 64)), dim3(64), 0, o->stream, o->d_model, o->d_ocp, o->d_xs,
-                         o->d_us, o->d_cg, o->d_cjac, o->d_nodestat, o->d_state, 0);
+      launch_con_eval<NV, CH>(o, o->d_xs, o->d_us, 0);
       hipLaunchKernelGGL(agx::k_admm_pre, dim3((o->B + 255) / 256), dim3(256), 0, o->stream, o->d_ocp, o->d_state);
       hipLaunchKernelGGL((agx::k_admm_tile<NV>), dim3(g8b), dim3(128), 0, o->stream, o->d_ocp, o->d_qt, o->d_qt2, o->d_aux, o->d_cx,
                          o->d_du, o->d_cjac, o->d_y, o->d_z, o->d_state, 0);  // its gradient part is rewritten below
@@ -762,8 +777,7 @@ int admm_direction(agx_ocp *o, bool prefactor = false) {
     hipLaunchKernelGGL((agx::k_admm_init<NV>), dim3(g1), dim3(256), 0, o->stream, o->d_ocp, o->d_dx, o->d_cx, o->d_z, o->d_state,
                        o->d_ndone + 1);
     if (!prefactor)
-      hipLaunchKernelGGL((agx::k_con_eval<NV, CH>), dim3((int)((nodes + 63) / 64)), dim3(64), 0, o->stream, o->d_model, o->d_ocp, o->d_xs,
-                         o->d_us, o->d_cg, o->d_cjac, o->d_nodestat, o->d_state, 0);
+      launch_con_eval<NV, CH>(o, o->d_xs, o->d_us, 0);
     HIPCHK(hipGetLastError());
     const int max_qp = o->ho.max_qp;
     // Polls the count of converged QPs; true when the loop ends here (quorum reached: the others are capped at `iter`)
@@ -880,9 +894,7 @@ int line_search_rounds(agx_ocp *o, int it, int max_iter, bool *need_k1, int *n_d
       constexpr bool CH = decltype(CHc)::value;
       (void)CH;
       if constexpr (NV <= 7) if (o->has_con) {
-        const long long nodes = (long long)o->B * (o->T + 1);
-        hipLaunchKernelGGL((agx::k_con_eval<NV, CH>), dim3((int)((nodes + 63) / 64)), dim3(64), 0, o->stream, o->d_model, o->d_ocp, xs_t, us_t,
-                           o->d_cg, o->d_cjac, o->d_nodestat, o->d_state, 1);
+        launch_con_eval<NV, CH>(o, xs_t, us_t, 1);
       }
       if constexpr (NV > 7) if (o->has_con) {
         const long long nodes = (long long)o->B * (o->T + 1);
@@ -1206,6 +1218,12 @@ int agx_ocp_create(const agx_model *m, const agx_ocp_desc *d, int batch, int dev
   }
   if (fill_cons(d->running_constraints, d->n_running_constraints, o->nv, o->nvu, m->h, o->ho.cons[0], false) ||
       fill_cons(d->terminal_constraints, d->n_terminal_constraints, o->nv, o->nvu, m->h, o->ho.cons[1], true)) { delete o; return -1; }
+  for (int lay = 0; lay < 2; ++lay)
+    for (int r = 0; r < o->ho.cons[lay].n; ++r) {
+      const int k = o->ho.cons[lay].kind[r];
+      if (k != AGX_RES_CONTROL && k != AGX_RES_STATE && k != AGX_RES_COLLISION) o->con_lanes = false;
+    }
+  if (const char *e = getenv("AGX_CON_LANES")) o->con_lanes = o->con_lanes && (e[0] != '0');
   o->has_con = o->ho.cons[0].nc + o->ho.cons[1].nc > 0;
   o->general = o->ho.rows[0].general || o->ho.rows[1].general;
   o->ho.has_con = o->has_con ? 1 : 0;

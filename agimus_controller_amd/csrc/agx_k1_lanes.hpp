@@ -711,4 +711,141 @@ __global__ void __launch_bounds__(64, AGX_K1_WAVES) k_calc_qp_lj_all(const DevMo
     calc_qp_lj_body<NV, true, COLL>((long long)blockIdx.x - n_run, lds, lmod, mp, op, dts, xs, us, rv, qts, auxs, st, phase);
 }
 
+// Constraint values, Jacobian rows and the l1 violation of every node (k_con_eval, agx_admm.hpp) with 8 lanes per node for the
+// row kinds of the shipped problems: Control (ConstraintModelControlLimit), State, collision distance.  Lane j holds joint
+// j: the SE3 prefix product of k_calc_qp_lj gives the world placements, the closest points of a pair are evaluated
+// redundantly by the 8 lanes, lane j writes its column of the distance gradient.  The one-lane kernel (512 VGPRs, private
+// arrays) took 90 us per launch at B = 256, T = 200; problems with other constraint kinds still use it.
+// cg [B][T+1][AGX_MAX_NC], cjac [B][T+1][AGX_MAX_DENSE][24] (d/dq | d/dv | d/du, 8 each).
+template <int NV>
+__global__ void __launch_bounds__(64) k_con_eval_lj(const DevModel *__restrict__ mp, const DevOcp *__restrict__ op,
+                                                    const double *__restrict__ xs, const double *__restrict__ us,
+                                                    double *__restrict__ cg, double *__restrict__ cjac,
+                                                    double *__restrict__ nodestat, const DevState *__restrict__ st, int phase) {
+  constexpr int NX = 2 * NV;
+  __shared__ double s_mod[8][16];  // placement 12 | axis 3 of every joint
+  const DevModel &m = *mp;
+  const DevOcp &o = *op;
+  const int T = o.T, l8 = threadIdx.x & 7;
+  const long long n_nodes = (long long)o.B * (T + 1);
+  const long long node_raw = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 3;
+  const bool ok = node_raw < n_nodes;
+  const long long node = ok ? node_raw : n_nodes - 1;
+  const int b = (int)(node / (T + 1)), t = (int)(node % (T + 1));
+  const bool act = ok && k1_active(st[b], phase);
+  if (!__any(act)) return;
+  if (threadIdx.x < 8) {
+    const int jj = threadIdx.x < NV ? threadIdx.x : NV - 1;
+#pragma unroll
+    for (int e = 0; e < 12; ++e) s_mod[threadIdx.x][e] = m.placement[jj][e];
+#pragma unroll
+    for (int e = 0; e < 3; ++e) s_mod[threadIdx.x][12 + e] = m.axis[jj][e];
+  }
+  __syncthreads();
+  const DevCons &c = o.cons[t == T ? 1 : 0];
+  const bool jl = l8 < NV;
+  const int j = jl ? l8 : NV - 1;
+  const double *xp = xs + node * NX;
+  const double qj = xp[j], vj = xp[NV + j];
+  const double uj = (t < T) ? us[((long long)b * T + t) * NV + j] : 0.0;
+  // kinematics: local placement, then the SE3 prefix product along the chain (as calc_qp_lj_body)
+  double R[9], p[3], z[3];
+  if (c.ncoll > 0) {
+    const double *mj = s_mod[l8];
+    const double *ax3 = mj + 12;
+    double sn, cs;
+    sincos(qj, &sn, &cs);
+    const double omc = 1.0 - cs;
+    double Rq[9];
+    Rq[0] = cs + omc * ax3[0] * ax3[0];
+    Rq[1] = omc * ax3[0] * ax3[1] - sn * ax3[2];
+    Rq[2] = omc * ax3[0] * ax3[2] + sn * ax3[1];
+    Rq[3] = omc * ax3[1] * ax3[0] + sn * ax3[2];
+    Rq[4] = cs + omc * ax3[1] * ax3[1];
+    Rq[5] = omc * ax3[1] * ax3[2] - sn * ax3[0];
+    Rq[6] = omc * ax3[2] * ax3[0] - sn * ax3[1];
+    Rq[7] = omc * ax3[2] * ax3[1] + sn * ax3[0];
+    Rq[8] = cs + omc * ax3[2] * ax3[2];
+    mm3(mj, Rq, R);
+    p[0] = mj[9]; p[1] = mj[10]; p[2] = mj[11];
+    auto se3_step = [&](auto OFFc) {
+      constexpr int OFF = decltype(OFFc)::value;
+      double Rp[9], pp[3];
+#pragma unroll
+      for (int e = 0; e < 9; ++e) Rp[e] = g_up<OFF>(R[e]);
+#pragma unroll
+      for (int e = 0; e < 3; ++e) pp[e] = g_up<OFF>(p[e]);
+      if (l8 >= OFF) {
+        double tt[3];
+        mv3(Rp, p, tt);
+        p[0] = pp[0] + tt[0]; p[1] = pp[1] + tt[1]; p[2] = pp[2] + tt[2];
+        mm3(Rp, R, R);
+      }
+    };
+    se3_step(std::integral_constant<int, 1>());
+    se3_step(std::integral_constant<int, 2>());
+    se3_step(std::integral_constant<int, 4>());
+    mv3(R, ax3, z);  // joint axis in the world
+  }
+  double v = 0.0;
+  for (int r = 0; r < c.n; ++r) {
+    const int kind = c.kind[r], off = c.off[r];
+    if (kind == AGX_RES_CONTROL) {
+      const double g = uj - c.ref[r][j];
+      if (jl) {
+        if (act) cg[node * AGX_MAX_NC + off + j] = g;
+        v += fmax(c.lb[off + j] - g, 0.0) + fmax(g - c.ub[off + j], 0.0);
+      }
+    } else if (kind == AGX_RES_STATE) {
+      const double gq = qj - c.ref[r][j], gv = vj - c.ref[r][NV + j];
+      if (jl) {
+        if (act) { cg[node * AGX_MAX_NC + off + j] = gq; cg[node * AGX_MAX_NC + off + NV + j] = gv; }
+        v += fmax(c.lb[off + j] - gq, 0.0) + fmax(gq - c.ub[off + j], 0.0) + fmax(c.lb[off + NV + j] - gv, 0.0) + fmax(gv - c.ub[off + NV + j], 0.0);
+      }
+    } else {  // collision distance (the host selects this kernel only for these three kinds)
+      double Rg[2][9], pg[2][3];
+      int jp[2];
+#pragma unroll
+      for (int gi = 0; gi < 2; ++gi) {
+        const int frame = gi == 0 ? c.frame[r] : c.frame_b[r];
+        const double *fpl = m.frame_placement[frame];
+        const int jf = m.frame_parent[frame];
+        jp[gi] = jf;
+        if (jf >= 0) {
+          double Rp[9], pp[3], tt[3];
+#pragma unroll
+          for (int e = 0; e < 9; ++e) Rp[e] = g_bc(R[e], jf);
+#pragma unroll
+          for (int e = 0; e < 3; ++e) pp[e] = g_bc(p[e], jf);
+          mm3(Rp, fpl, Rg[gi]);
+          mv3(Rp, fpl + 9, tt);
+          pg[gi][0] = pp[0] + tt[0]; pg[gi][1] = pp[1] + tt[1]; pg[gi][2] = pp[2] + tt[2];
+        } else {
+#pragma unroll
+          for (int e = 0; e < 9; ++e) Rg[gi][e] = fpl[e];
+#pragma unroll
+          for (int e = 0; e < 3; ++e) pg[gi][e] = fpl[9 + e];
+        }
+      }
+      double ca[3], cb[3], nn[3];
+      const double d = collision_distance_placed(m, c.frame[r], c.frame_b[r], Rg[0], pg[0], Rg[1], pg[1], ca, cb, nn);
+      const bool ona = jl && (l8 <= jp[0]), onb = jl && (l8 <= jp[1]);  // serial chain: joints up to the parent move the frame
+      double da[3], db[3], ta[3], tb[3];
+#pragma unroll
+      for (int e = 0; e < 3; ++e) { da[e] = ca[e] - p[e]; db[e] = cb[e] - p[e]; }
+      cross3(z, da, ta);
+      cross3(z, db, tb);
+      const double gj = (ona ? dot3(nn, ta) : 0.0) - (onb ? dot3(nn, tb) : 0.0);
+      if (act) {
+        double *row = cjac + (node * AGX_MAX_DENSE + c.coll_slot[r]) * 24;
+        row[l8] = jl ? gj : 0.0; row[8 + l8] = 0.0; row[16 + l8] = 0.0;
+        if (l8 == 0) cg[node * AGX_MAX_NC + off] = d;
+      }
+      if (l8 == 0) v += fmax(c.lb[off] - d, 0.0) + fmax(d - c.ub[off], 0.0);
+    }
+  }
+  v += dpp_xor4(v); v += dpp_xor2(v); v += dpp_xor1(v);
+  if (act && l8 == 0) nodestat[node * 4 + 3] = v;
+}
+
 }  // namespace agx
