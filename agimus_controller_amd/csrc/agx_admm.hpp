@@ -363,7 +363,7 @@ __global__ void __launch_bounds__(64) k_seg_products(const DevOcp *__restrict__ 
   const DevOcp &o = *op;
   const int T = o.T, b = blockIdx.x / kSeg, sg = blockIdx.x % kSeg, lane = threadIdx.x;
   const DevState &S = st[b];
-  if (S.done || S.admm_conv || !S.admm_refactor) return;
+  if (S.done || S.admm_conv || !S.admm_refactor || S.dir_fail) return;  // (dir_fail: the factorisation these products belong to broke down)
   const int L = seg_len(T), ta = sg * L, tb = min(T, ta + L);
   const int r = lane >> 3, c = lane & 7;
   const bool in = (r < NV) && (c < NV);
