@@ -225,3 +225,30 @@ def test_full_size_humanoid_replicas_are_bit_identical(hip_backend, humanoid):
     xs_o, us_o, K_o, st_o = o.solve(ref, None, x0, xs, us, 4, nthreads=4)
     np.testing.assert_array_equal(st_h["iter"][:n], st_o["iter"])
     assert rel(xs_h[:n], xs_o) < 1e-8 and rel(us_h[:n], us_o) < 1e-7 and rel(K_h[:n], K_o) < 1e-6
+
+
+def test_full_size_humanoid_with_torque_limits(hip_backend, humanoid):
+    """BASELINE configs[4] shape (B = 512, T = 50) with ConstraintModelControlLimit: the ADMM path of the large models at full
+    size -- replicas of three instances come out bit-identical, the controls respect the bound, and the three agree with the
+    checker (same SQP / ADMM iteration counts)."""
+    frame = len(humanoid.frame_names) - 1
+    B, T, n = 512, 50, 3
+    po0, ref, x0, xs, us = workloads.random_goal_problem(humanoid, T, 0.01, n, seed=17, frame=frame)
+    lim = np.full(30, 60.0)
+    con = [_abi.ConstraintSpec(_abi.RES_CONTROL, lower=-lim, upper=lim, name="ctrl_limit")]
+    po = _abi.PackedOcp(30, [0.01] * T, po0.running, po0.terminal, max_qp_iters=50, running_constraints=con)
+    rep = lambda a: np.ascontiguousarray(np.tile(a, (B // n + 1,) + (1,) * (a.ndim - 1))[:B])  # noqa: E731
+    h = hip_backend.HipOcp(humanoid, po, B)
+    h.set_refs(rep(ref))
+    xs_h, us_h, K_h, st_h = h.solve(rep(x0), rep(xs), rep(us), 2)
+    h.close()
+    for k in range(n, B):
+        assert np.array_equal(xs_h[k], xs_h[k % n]) and np.array_equal(us_h[k], us_h[k % n]), k
+        assert st_h["qp_iters"][k] == st_h["qp_iters"][k % n]
+    assert np.abs(us_h).max() <= 60.0 + 1e-2
+    o = Oracle(humanoid, po, n)
+    xs_o, us_o, K_o, st_o = o.solve(ref, None, x0, xs, us, 2, nthreads=4)
+    assert np.abs(us_o).max() > 0.9 * 60.0  # the bound matters
+    np.testing.assert_array_equal(st_h["iter"][:n], st_o["iter"])
+    np.testing.assert_array_equal(st_h["qp_iters"][:n], st_o["qp_iters"])
+    assert rel(xs_h[:n], xs_o) < 1e-6 and rel(us_h[:n], us_o) < 1e-5
