@@ -77,3 +77,48 @@ def test_random_problem_definitions(hip_backend, seed):
         np.testing.assert_allclose(r_h[0], r_o[0], rtol=1e-6, atol=1e-7)
         np.testing.assert_allclose(r_h[1], r_o[1], rtol=1e-5, atol=1e-5)
     h.close()
+
+
+def _constrained_case(seed):
+    rng = np.random.default_rng(5000 + seed)
+    nv = int(rng.choice([4, 6, 7, 9, 14, 24]))
+    chain = bool(rng.integers(2)) or nv == 7
+    table = rt.chain_table(nv, seed=100 + seed) if chain else rt.tree_table(nv, seed=100 + seed)
+    frame = len(table.frame_names) - 1
+    T, B = int(rng.integers(4, 9)), 2
+    po0, ref, x0, xs, us = workloads.random_goal_problem(table, T, 0.01, B, seed=seed, frame=frame)
+    o0 = Oracle(table, po0, B)
+    p0 = o0.frame_placement(frame, x0[:, :nv])
+    con, tcon = [], []
+    if rng.random() < 0.6:
+        lim = np.full(nv, float(rng.uniform(20.0, 60.0)))
+        con.append(_abi.ConstraintSpec(_abi.RES_CONTROL, lower=-lim, upper=lim, name="ctrl_limit"))
+    if rng.random() < 0.5:
+        xb = np.full(2 * nv, np.inf)
+        xb[nv:] = float(rng.uniform(1.0, 3.0))
+        c = _abi.ConstraintSpec(_abi.RES_STATE, lower=-xb, upper=xb, name="velocity_limit")
+        con.append(c)
+        tcon.append(c)
+    if rng.random() < 0.5 or not con:
+        half = float(rng.uniform(0.05, 0.2))
+        c = _abi.ConstraintSpec(_abi.RES_FRAME_TRANSLATION, lower=-half, upper=half, ref=p0[:, 9:].mean(0), frame=frame, name="ee_box")
+        con.append(c)
+        tcon.append(c)
+    po = _abi.PackedOcp(nv, [0.01] * T, po0.running, po0.terminal, max_qp_iters=50, running_constraints=con, terminal_constraints=tcon)
+    return table, po, ref, x0, xs, us, B
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("AGX_FUZZ_SEEDS", "12"))))
+def test_random_constraint_sets(hip_backend, seed):
+    """Torque limits, velocity bounds and an end-effector box in random combinations on models of every capacity: the ADMM
+    paths (8 lanes per node / one lane per node for the constraint evaluation up to 7 joints, workgroup kernels above)."""
+    table, po, ref, x0, xs, us, B = _constrained_case(seed)
+    h, o = hip_backend.HipOcp(table, po, B), Oracle(table, po, B)
+    h.set_refs(ref)
+    r_h, r_o = h.solve(x0, xs, us, 2), o.solve(ref, None, x0, xs, us, 2)
+    assert np.array_equal(r_h[3]["iter"], r_o[3]["iter"]) and np.array_equal(r_h[3]["qp_iters"], r_o[3]["qp_iters"]), seed
+    assert np.array_equal(r_h[3]["flags"], r_o[3]["flags"]), seed
+    if not np.any(r_o[3]["flags"]):
+        np.testing.assert_allclose(r_h[0], r_o[0], rtol=1e-6, atol=1e-7)
+        np.testing.assert_allclose(r_h[1], r_o[1], rtol=1e-5, atol=1e-5)
+    h.close()
