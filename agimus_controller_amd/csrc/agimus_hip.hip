@@ -475,7 +475,7 @@ int launch_riccati(agx_ocp *o, int forward, bool pair = false, int iter = 0, con
     if constexpr (NV <= 7) {
       const int fwd = forward ? (fused_kkt(o) ? 2 : 1) : 0;  // 2: K3 rides along in the forward pass
       if (pair && o->riccati_mx)
-        hipLaunchKernelGGL((agx::k_riccati_mx_pair<NV>), dim3(2 * o->B), dim3(64), 0, o->stream, o->d_ocp, o->d_dt, o->d_qt, o->d_aux,
+        hipLaunchKernelGGL((agx::k_riccati_mx_pair<NV>), dim3(16 * ((o->B + 7) / 8)), dim3(64), 0, o->stream, o->d_ocp, o->d_dt, o->d_qt, o->d_aux,
                            o->d_Kws, o->d_kws, o->d_dx, o->d_w, o->d_Kout, o->d_state, iter, fused_kkt(o) ? 2 : 1, o->d_du, o->d_nodestat);
       else if (pair)
         hipLaunchKernelGGL((agx::k_riccati_pair<NV>), dim3(2 * o->B), dim3(64), 0, o->stream, o->d_ocp, o->d_dt, o->d_qt, o->d_aux,

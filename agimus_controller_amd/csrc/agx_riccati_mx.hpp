@@ -357,8 +357,12 @@ __global__ void __launch_bounds__(64, 2) k_riccati_mx_pair(const DevOcp *__restr
                                                         double *__restrict__ Kws, double *__restrict__ kws, double *__restrict__ dxs,
                                                         double *__restrict__ wss, double *__restrict__ Kout, DevState *__restrict__ st,
                                                         int iter, int forward, double *__restrict__ dus, double *__restrict__ nodestat) {
-  const int b = blockIdx.x >> 1;
-  if (blockIdx.x & 1)
+  // Workgroups go to the 8 XCDs round robin (blockIdx.x % 8): the two sweeps of an instance take block ids 8 apart, so that both
+  // stream the instance's tiles through the same L2 (grid: 16 workgroups per 8 instances, rounded up)
+  const int grp = blockIdx.x >> 4, w16 = blockIdx.x & 15;
+  const int b = grp * 8 + (w16 & 7);
+  if (b >= op->B) return;
+  if (w16 >> 3)
     riccati_mx_body<NV, true>(b, op, dts, qts, auxs, Kws, kws, dxs, wss, Kout, st, 0, 1, iter);
   else
     riccati_mx_body<NV, false>(b, op, dts, qts, auxs, Kws, kws, dxs, wss, Kout, st, forward, 0, iter, dus, nodestat);
